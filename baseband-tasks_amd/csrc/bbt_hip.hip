@@ -1,0 +1,665 @@
+// libbbt_hip.so -- host side of the C ABI declared in include/bbt_hip.h.
+// Plans, twiddle tables, launch geometry; the kernels are in bbt_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bbt_hip.h"
+#include "bbt_kernels.hpp"
+
+using namespace bbt;
+
+#define BBT_VERSION 100
+
+// ---------------------------------------------------------------------------
+// errors
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                      \
+    } while (0)
+
+#define ARG_TRY(cond, ...) \
+    do {                   \
+        if (!(cond)) return fail(__VA_ARGS__); \
+    } while (0)
+
+static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// ---------------------------------------------------------------------------
+// twiddle tables, per device
+struct FftTables {
+    cf* tw0 = nullptr;  // [16][T]   W_N^{tau c0}
+    cf* tw1 = nullptr;  // [16][R2]  W_T^{b1 c1}
+};
+static std::mutex g_tab_mutex;
+static std::map<std::pair<int, int>, FftTables> g_tables;  // (device, N)
+static std::map<int, cf*> g_wroot;                         // device -> W_4096^m
+
+static int upload(cf** dst, const std::vector<cf>& h) {
+    HIP_TRY(hipMalloc((void**)dst, h.size() * sizeof(cf)));
+    HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static cf unit_root(long long k, long long n) {
+    // exp(-2 pi i k / n), evaluated in double with exact octant reduction
+    k %= n;
+    const double a = -2.0 * M_PI * (double)k / (double)n;
+    return make_float2((float)cos(a), (float)sin(a));
+}
+
+static int get_tables(int n, FftTables* out) {
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto it = g_tables.find({dev, n});
+    if (it != g_tables.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const int r2 = n / 256, t = n / 16;
+    std::vector<cf> h0(16 * t), h1(16 * r2);
+    for (int c = 0; c < 16; ++c)
+        for (int tau = 0; tau < t; ++tau) h0[c * t + tau] = unit_root((long long)tau * c, n);
+    for (int c = 0; c < 16; ++c)
+        for (int b = 0; b < r2; ++b) h1[c * r2 + b] = unit_root((long long)b * c, t);
+    FftTables ft;
+    if (upload(&ft.tw0, h0)) return 1;
+    if (upload(&ft.tw1, h1)) return 1;
+    g_tables[{dev, n}] = ft;
+    *out = ft;
+    return 0;
+}
+
+static int get_wroot(cf** out) {
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto it = g_wroot.find(dev);
+    if (it != g_wroot.end()) {
+        *out = it->second;
+        return 0;
+    }
+    std::vector<cf> h(4096);
+    for (int m = 0; m < 4096; ++m) h[m] = unit_root(m, 4096);
+    cf* d;
+    if (upload(&d, h)) return 1;
+    g_wroot[dev] = d;
+    *out = d;
+    return 0;
+}
+
+static bool fft_len_ok(int64_t n) { return is_pow2(n) && n >= 256 && n <= 4096; }
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* bbt_last_error(void) { return g_err.c_str(); }
+int bbt_version(void) { return BBT_VERSION; }
+
+int bbt_device_count(int* count) {
+    ARG_TRY(count, "bbt_device_count: null argument");
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+int bbt_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+int bbt_get_device(int* device) {
+    ARG_TRY(device, "bbt_get_device: null argument");
+    HIP_TRY(hipGetDevice(device));
+    return 0;
+}
+int bbt_device_name(char* buf, int buflen) {
+    ARG_TRY(buf && buflen > 0, "bbt_device_name: bad buffer");
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return 0;
+}
+
+int bbt_malloc(void** dev_ptr, size_t nbytes) {
+    ARG_TRY(dev_ptr, "bbt_malloc: null argument");
+    HIP_TRY(hipMalloc(dev_ptr, nbytes ? nbytes : 1));
+    return 0;
+}
+int bbt_free(void* dev_ptr) {
+    if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+    return 0;
+}
+int bbt_host_alloc(void** host_ptr, size_t nbytes) {
+    ARG_TRY(host_ptr, "bbt_host_alloc: null argument");
+    HIP_TRY(hipHostMalloc(host_ptr, nbytes ? nbytes : 1, hipHostMallocDefault));
+    return 0;
+}
+int bbt_host_free(void* host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return 0;
+}
+int bbt_memset(void* dev_ptr, int value, size_t nbytes, bbt_stream stream) {
+    HIP_TRY(hipMemsetAsync(dev_ptr, value, nbytes, (hipStream_t)stream));
+    return 0;
+}
+int bbt_memcpy_h2d(void* dst, const void* src, size_t n, bbt_stream s) {
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)s));
+    return 0;
+}
+int bbt_memcpy_d2h(void* dst, const void* src, size_t n, bbt_stream s) {
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return 0;
+}
+int bbt_memcpy_d2d(void* dst, const void* src, size_t n, bbt_stream s) {
+    HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return 0;
+}
+int bbt_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                 size_t height, int kind, bbt_stream s) {
+    ARG_TRY(kind >= 0 && kind <= 2, "bbt_memcpy2d: kind must be 0 (h2d), 1 (d2h) or 2 (d2d)");
+    const hipMemcpyKind k = kind == 0   ? hipMemcpyHostToDevice
+                            : kind == 1 ? hipMemcpyDeviceToHost
+                                        : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, (hipStream_t)s));
+    return 0;
+}
+int bbt_stream_create(bbt_stream* stream) {
+    ARG_TRY(stream, "bbt_stream_create: null argument");
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (bbt_stream)s;
+    return 0;
+}
+int bbt_stream_destroy(bbt_stream stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+int bbt_stream_sync(bbt_stream stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int bbt_device_sync(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+int bbt_event_create(bbt_event* ev) {
+    ARG_TRY(ev, "bbt_event_create: null argument");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = (bbt_event)e;
+    return 0;
+}
+int bbt_event_destroy(bbt_event ev) {
+    if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+int bbt_event_record(bbt_event ev, bbt_stream stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return 0;
+}
+int bbt_event_sync(bbt_event ev) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)ev));
+    return 0;
+}
+int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms) {
+    ARG_TRY(ms, "bbt_event_elapsed_ms: null argument");
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// overlap-save spectral multiply
+struct bbt_osm_plan {
+    int device = 0;
+    int64_t n = 0;
+    int S = 0, npair = 0, C = 0;
+    int n1 = 1, n2 = 0;
+    int chunk = 1;
+    cf* resp = nullptr;        // [C][N1][N2], scaled 1/N
+    int* resp_index = nullptr;  // [S]
+    float2* work = nullptr;     // [chunk][npair][N1][N2] float4
+    size_t work_bytes = 0;
+    FftTables tab2;  // for N2
+    FftTables tab1;  // for N1 == 256
+    cf* wroot = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // 4 per chunk launch: t0, tA, tB, tC
+    double acc_ms[3] = {0, 0, 0};
+    int64_t launches = 0;
+};
+
+template <int N2>
+static void launch_rowpass(bbt_osm_plan* p, int nblk, hipStream_t st) {
+    hipLaunchKernelGGL((k_osm_rowpass<N2>), dim3(p->n1, nblk * p->npair), dim3(N2 / 16), 0, st,
+                       p->work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
+                       p->wroot);
+}
+
+template <int N>
+static void launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
+                         hipStream_t st) {
+    hipLaunchKernelGGL((k_osm_small<N>), dim3(ch.nblk, p->npair), dim3(N / 16), 0, st, in, out, ch,
+                       p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
+}
+
+static int osm_flush_timing(bbt_osm_plan* p) {
+    for (size_t i = 0; i + 3 < p->ev.size(); i += 4) {
+        HIP_TRY(hipEventSynchronize(p->ev[i + 3]));
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->ev[i + k], p->ev[i + k + 1]));
+            p->acc_ms[k] += ms;
+        }
+        p->launches += 1;
+    }
+    for (auto e : p->ev) hipEventDestroy(e);
+    p->ev.clear();
+    return 0;
+}
+
+static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
+                         hipStream_t st) {
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (p->timing) {
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&e[i]));
+        HIP_TRY(hipEventRecord(e[0], st));
+    }
+    if (p->n1 == 1) {
+        switch (p->n2) {
+            case 256: launch_small<256>(p, in, out, ch, st); break;
+            case 512: launch_small<512>(p, in, out, ch, st); break;
+            case 1024: launch_small<1024>(p, in, out, ch, st); break;
+            case 2048: launch_small<2048>(p, in, out, ch, st); break;
+            case 4096: launch_small<4096>(p, in, out, ch, st); break;
+            default: return fail("osm: unsupported n_fft %lld", (long long)p->n);
+        }
+        if (p->timing) {
+            HIP_TRY(hipEventRecord(e[1], st));
+            HIP_TRY(hipEventRecord(e[2], st));
+        }
+    } else {
+        if (p->n1 == 16)
+            hipLaunchKernelGGL((k_osm_col16<true>), dim3(p->n2 / 256, ch.nblk, p->npair), dim3(256),
+                               0, st, in, out, p->work, ch, p->S, p->n2);
+        else
+            hipLaunchKernelGGL((k_osm_col256<true>), dim3(p->n2 / 16, ch.nblk, p->npair), dim3(256),
+                               0, st, in, out, p->work, ch, p->S, p->n2, p->tab1.tw0);
+        if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+        switch (p->n2) {
+            case 256: launch_rowpass<256>(p, ch.nblk, st); break;
+            case 512: launch_rowpass<512>(p, ch.nblk, st); break;
+            case 1024: launch_rowpass<1024>(p, ch.nblk, st); break;
+            case 2048: launch_rowpass<2048>(p, ch.nblk, st); break;
+            case 4096: launch_rowpass<4096>(p, ch.nblk, st); break;
+            default: return fail("osm: unsupported row length %d", p->n2);
+        }
+        if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+        if (p->n1 == 16)
+            hipLaunchKernelGGL((k_osm_col16<false>), dim3(p->n2 / 256, ch.nblk, p->npair),
+                               dim3(256), 0, st, in, out, p->work, ch, p->S, p->n2);
+        else
+            hipLaunchKernelGGL((k_osm_col256<false>), dim3(p->n2 / 16, ch.nblk, p->npair),
+                               dim3(256), 0, st, in, out, p->work, ch, p->S, p->n2, p->tab1.tw0);
+    }
+    HIP_TRY(hipGetLastError());
+    if (p->timing) {
+        HIP_TRY(hipEventRecord(e[3], st));
+        for (int i = 0; i < 4; ++i) p->ev.push_back(e[i]);
+        if (p->ev.size() >= 4096) return osm_flush_timing(p);
+    }
+    return 0;
+}
+
+extern "C" {
+
+int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_resp,
+                        const void* resp, int resp_on_device, const int32_t* resp_index) {
+    ARG_TRY(plan && resp, "bbt_osm_plan_create: null argument");
+    *plan = nullptr;
+    ARG_TRY(is_pow2(n_fft) && n_fft >= 256 && n_fft <= (1 << 20),
+            "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^20]",
+            (long long)n_fft);
+    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
+            "bbt_osm_plan_create: n_stream=%d must be even and >= 2", n_stream);
+    ARG_TRY(n_resp >= 1, "bbt_osm_plan_create: n_resp=%d must be >= 1", n_resp);
+    std::vector<int> idx(n_stream, 0);
+    if (resp_index)
+        for (int s = 0; s < n_stream; ++s) {
+            ARG_TRY(resp_index[s] >= 0 && resp_index[s] < n_resp,
+                    "bbt_osm_plan_create: resp_index[%d]=%d out of range", s, resp_index[s]);
+            idx[s] = resp_index[s];
+        }
+    bbt_osm_plan* p = new bbt_osm_plan;
+    auto bail = [&](int) {
+        bbt_osm_plan_destroy(p);
+        return 1;
+    };
+    if (hipGetDevice(&p->device) != hipSuccess) return bail(fail("hipGetDevice failed"));
+    p->n = n_fft;
+    p->S = n_stream;
+    p->npair = n_stream / 2;
+    p->C = n_resp;
+    if (n_fft <= 4096) {
+        p->n1 = 1;
+    } else if (n_fft <= (1 << 16)) {
+        p->n1 = 16;
+    } else {
+        p->n1 = 256;
+    }
+    p->n2 = (int)(n_fft / p->n1);
+    if (get_tables(p->n2, &p->tab2)) return bail(1);
+    if (p->n1 == 256 && get_tables(256, &p->tab1)) return bail(1);
+    if (get_wroot(&p->wroot)) return bail(1);
+
+    // response: upload (if needed), permute to [C][N1][N2], scale by 1/N
+    const size_t rbytes = (size_t)n_resp * n_fft * sizeof(cf);
+    cf* nat = nullptr;
+    if (resp_on_device) {
+        nat = (cf*)resp;
+    } else {
+        if (hipMalloc((void**)&nat, rbytes) != hipSuccess ||
+            hipMemcpy(nat, resp, rbytes, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail("bbt_osm_plan_create: uploading the response failed"));
+    }
+    if (hipMalloc((void**)&p->resp, rbytes) != hipSuccess)
+        return bail(fail("bbt_osm_plan_create: hipMalloc(response) failed"));
+    hipLaunchKernelGGL(k_permute_resp, dim3((unsigned)((n_fft + 255) / 256), n_resp), dim3(256), 0, 0,
+                       nat, p->resp, p->n1, (long long)p->n2, 1.0f / (float)n_fft);
+    hipError_t e = hipDeviceSynchronize();
+    if (!resp_on_device) hipFree(nat);
+    if (e != hipSuccess)
+        return bail(fail("bbt_osm_plan_create: response permutation failed: %s",
+                         hipGetErrorString(e)));
+    if (hipMalloc((void**)&p->resp_index, n_stream * sizeof(int)) != hipSuccess ||
+        hipMemcpy(p->resp_index, idx.data(), n_stream * sizeof(int), hipMemcpyHostToDevice) !=
+            hipSuccess)
+        return bail(fail("bbt_osm_plan_create: resp_index upload failed"));
+
+    // workspace
+    const size_t per_block = (size_t)p->npair * n_fft * 16;
+    int chunk = (int)((128u << 20) / per_block);
+    if (const char* env = getenv("BBT_OSM_CHUNK")) chunk = atoi(env);
+    if (chunk < 1) chunk = 1;
+    if (chunk > BBT_MAX_CHUNK) chunk = BBT_MAX_CHUNK;
+    p->chunk = chunk;
+    if (p->n1 > 1) {
+        p->work_bytes = per_block * chunk;
+        if (hipMalloc((void**)&p->work, p->work_bytes) != hipSuccess)
+            return bail(fail("bbt_osm_plan_create: hipMalloc(workspace %zu bytes) failed",
+                             p->work_bytes));
+    }
+    *plan = p;
+    return 0;
+}
+
+int bbt_osm_plan_destroy(bbt_osm_plan* p) {
+    if (!p) return 0;
+    for (auto e : p->ev) hipEventDestroy(e);
+    if (p->resp) hipFree(p->resp);
+    if (p->resp_index) hipFree(p->resp_index);
+    if (p->work) hipFree(p->work);
+    delete p;
+    return 0;
+}
+
+int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chunk_blocks, int* n1,
+                      int* n2) {
+    ARG_TRY(p, "bbt_osm_plan_info: null plan");
+    if (workspace_bytes) *workspace_bytes = (int64_t)p->work_bytes;
+    if (chunk_blocks) *chunk_blocks = p->chunk;
+    if (n1) *n1 = p->n1;
+    if (n2) *n2 = p->n2;
+    return 0;
+}
+
+int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,
+                    const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
+                    const int32_t* valid_count, bbt_stream stream) {
+    ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute: null argument");
+    ARG_TRY(n_blocks >= 0, "bbt_osm_execute: n_blocks=%lld < 0", (long long)n_blocks);
+    ARG_TRY(n_blocks == 0 || (in_off && out_off && valid_start && valid_count),
+            "bbt_osm_execute: null descriptor array");
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        ARG_TRY(in_off[b] >= 0 && out_off[b] >= 0, "bbt_osm_execute: negative offset in block %lld",
+                (long long)b);
+        ARG_TRY(valid_start[b] >= 0 && valid_count[b] >= 0 &&
+                    (int64_t)valid_start[b] + valid_count[b] <= p->n,
+                "bbt_osm_execute: block %lld keeps [%d, %d) outside [0, %lld)", (long long)b,
+                valid_start[b], valid_start[b] + valid_count[b], (long long)p->n);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk) {
+        OsmChunk ch;
+        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
+        for (int i = 0; i < ch.nblk; ++i) {
+            ch.b[i].in_off = in_off[b0 + i];
+            ch.b[i].out_off = out_off[b0 + i];
+            ch.b[i].valid_start = valid_start[b0 + i];
+            ch.b[i].valid_count = valid_count[b0 + i];
+        }
+        if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, st)) return 1;
+    }
+    return 0;
+}
+
+int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,
+                            int64_t in_off0, int64_t out_off0, int64_t hop, int32_t valid_start,
+                            bbt_stream stream) {
+    ARG_TRY(p, "bbt_osm_execute_regular: null plan");
+    ARG_TRY(n_blocks >= 0 && hop > 0 && hop <= p->n, "bbt_osm_execute_regular: bad hop %lld",
+            (long long)hop);
+    std::vector<int64_t> io(n_blocks), oo(n_blocks);
+    std::vector<int32_t> vs(n_blocks, valid_start), vc(n_blocks, (int32_t)hop);
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        io[b] = in_off0 + b * hop;
+        oo[b] = out_off0 + b * hop;
+    }
+    return bbt_osm_execute(p, in_dev, out_dev, n_blocks, io.data(), oo.data(), vs.data(),
+                           vc.data(), stream);
+}
+
+int bbt_osm_timing_enable(bbt_osm_plan* p, int enable) {
+    ARG_TRY(p, "bbt_osm_timing_enable: null plan");
+    if (osm_flush_timing(p)) return 1;
+    p->timing = enable != 0;
+    p->acc_ms[0] = p->acc_ms[1] = p->acc_ms[2] = 0;
+    p->launches = 0;
+    return 0;
+}
+
+int bbt_osm_timing_read(bbt_osm_plan* p, double ms[3], int64_t* launches) {
+    ARG_TRY(p && ms, "bbt_osm_timing_read: null argument");
+    if (osm_flush_timing(p)) return 1;
+    for (int k = 0; k < 3; ++k) ms[k] = p->acc_ms[k];
+    if (launches) *launches = p->launches;
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// channelizer
+struct bbt_chan_plan {
+    int n = 0, S = 0, npair = 0, dir = -1;
+    FftTables tab;
+};
+
+template <int N, int SIGN>
+static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, int64_t n_fft,
+                        float scale, hipStream_t st) {
+    constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
+    const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
+    hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW>), dim3(gx, p->npair), dim3(FPW * N / 16), 0, st, in,
+                       out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
+}
+
+template <int SIGN>
+static int chan_dispatch(const bbt_chan_plan* p, const float2* in, float2* out, int64_t n_fft,
+                         float scale, hipStream_t st) {
+    switch (p->n) {
+        case 256: launch_rows<256, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 512: launch_rows<512, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 1024: launch_rows<1024, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 2048: launch_rows<2048, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 4096: launch_rows<4096, SIGN>(p, in, out, n_fft, scale, st); break;
+        default: return fail("channelize: unsupported n_chan %d", p->n);
+    }
+    return 0;
+}
+
+extern "C" {
+
+int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction) {
+    ARG_TRY(plan, "bbt_chan_plan_create: null argument");
+    *plan = nullptr;
+    ARG_TRY(fft_len_ok(n_chan),
+            "bbt_chan_plan_create: n_chan=%d must be a power of two in [256, 4096]", n_chan);
+    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
+            "bbt_chan_plan_create: n_stream=%d must be even and >= 2", n_stream);
+    ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1 or +1");
+    bbt_chan_plan* p = new bbt_chan_plan;
+    p->n = n_chan;
+    p->S = n_stream;
+    p->npair = n_stream / 2;
+    p->dir = direction;
+    if (get_tables(n_chan, &p->tab)) {
+        delete p;
+        return 1;
+    }
+    *plan = p;
+    return 0;
+}
+
+int bbt_chan_plan_destroy(bbt_chan_plan* p) {
+    delete p;
+    return 0;
+}
+
+int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_t n_spectra,
+                     bbt_stream stream) {
+    ARG_TRY(p && in_dev && out_dev, "bbt_chan_execute: null argument");
+    ARG_TRY(n_spectra >= 0, "bbt_chan_execute: n_spectra < 0");
+    if (n_spectra == 0) return 0;
+    // keep grid.x within limits: process in slabs
+    const int64_t slab = (int64_t)1 << 22;
+    const float2* in = (const float2*)in_dev;
+    float2* out = (float2*)out_dev;
+    for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {
+        const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
+        const int64_t off = s0 * p->n * p->S;
+        int rc = (p->dir < 0)
+                     ? chan_dispatch<-1>(p, in + off, out + off, ns, 1.0f, (hipStream_t)stream)
+                     : chan_dispatch<+1>(p, in + off, out + off, ns, 1.0f / (float)p->n,
+                                         (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// polyphase filter bank
+struct bbt_pfb_plan {
+    int n = 0, S = 0, npair = 0, n_tap = 0;
+    float* taps = nullptr;
+    FftTables tab;
+};
+
+template <int N>
+static void launch_pfb(const bbt_pfb_plan* p, const float2* in, float2* out, int64_t n_spec,
+                       hipStream_t st) {
+    constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
+    const unsigned gx = (unsigned)((n_spec + FPW - 1) / FPW);
+    hipLaunchKernelGGL((k_pfb<N, FPW>), dim3(gx, p->npair), dim3(FPW * N / 16), 0, st, in, out,
+                       (long long)n_spec, p->S, p->n_tap, p->taps, p->tab.tw0, p->tab.tw1);
+}
+
+extern "C" {
+
+int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream,
+                        const float* taps_host) {
+    ARG_TRY(plan && taps_host, "bbt_pfb_plan_create: null argument");
+    *plan = nullptr;
+    ARG_TRY(fft_len_ok(n_chan),
+            "bbt_pfb_plan_create: n_chan=%d must be a power of two in [256, 4096]", n_chan);
+    ARG_TRY(n_tap >= 1 && n_tap <= 64, "bbt_pfb_plan_create: n_tap=%d must be in [1, 64]", n_tap);
+    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
+            "bbt_pfb_plan_create: n_stream=%d must be even and >= 2", n_stream);
+    bbt_pfb_plan* p = new bbt_pfb_plan;
+    p->n = n_chan;
+    p->S = n_stream;
+    p->npair = n_stream / 2;
+    p->n_tap = n_tap;
+    const size_t tb = (size_t)n_tap * n_chan * sizeof(float);
+    if (get_tables(n_chan, &p->tab) || hipMalloc((void**)&p->taps, tb) != hipSuccess ||
+        hipMemcpy(p->taps, taps_host, tb, hipMemcpyHostToDevice) != hipSuccess) {
+        if (g_err.empty()) fail("bbt_pfb_plan_create: tap upload failed");
+        bbt_pfb_plan_destroy(p);
+        return 1;
+    }
+    *plan = p;
+    return 0;
+}
+
+int bbt_pfb_plan_destroy(bbt_pfb_plan* p) {
+    if (!p) return 0;
+    if (p->taps) hipFree(p->taps);
+    delete p;
+    return 0;
+}
+
+int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t n_spectra,
+                    bbt_stream stream) {
+    ARG_TRY(p && in_dev && out_dev, "bbt_pfb_execute: null argument");
+    ARG_TRY(n_spectra >= 0, "bbt_pfb_execute: n_spectra < 0");
+    if (n_spectra == 0) return 0;
+    const int64_t slab = (int64_t)1 << 22;
+    const float2* in = (const float2*)in_dev;
+    float2* out = (float2*)out_dev;
+    for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {
+        const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
+        const int64_t off = s0 * p->n * p->S;
+        hipStream_t st = (hipStream_t)stream;
+        switch (p->n) {
+            case 256: launch_pfb<256>(p, in + off, out + off, ns, st); break;
+            case 512: launch_pfb<512>(p, in + off, out + off, ns, st); break;
+            case 1024: launch_pfb<1024>(p, in + off, out + off, ns, st); break;
+            case 2048: launch_pfb<2048>(p, in + off, out + off, ns, st); break;
+            case 4096: launch_pfb<4096>(p, in + off, out + off, ns, st); break;
+            default: return fail("pfb: unsupported n_chan %d", p->n);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// HIP kernels for the dedispersion -> channelizer path on gfx950.
+//
+// Data contract everywhere: C-contiguous, time-major, streams innermost,
+// interleaved (re, im) float32 -- numpy complex64 of shape (n, S).  S (number
+// of streams = prod(sample_shape)) is even; kernels work on stream PAIRS so a
+// complete 2-pol sample is one aligned 16-byte float4.
+//
+//   k_fft_rows      Channelize.task / Dechannelize.task
+//                   (reference baseband_tasks/channelize.py:73-74, 164-165)
+//   k_osm_*         Disperse.task / Convolve.task: ifft(fft(x) * H)[valid]
+//                   (reference dispersion.py:135-139, convolution.py:116-120)
+//                   as a four-step FFT  N = N1 x N2:
+//                     col pass (fwd, over n1) -> row pass (twiddle, fwd over
+//                     n2, * H, inv over k2, conj twiddle) -> col pass (inv
+//                     over k1, writes only the valid samples)
+//   k_pfb           PolyphaseFilterBankSamples.ppf + Channelize.task
+//                   (reference pfb.py:91-100, channelize.py:73-74)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fft_core.hpp"
+
+namespace bbt {
+
+// Blocks dispatched round-robin over the 8 XCDs: give each XCD one contiguous
+// range of virtual block ids so neighbours (which share input lines) share an
+// L2.  Bijective for any nblocks.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned q = nblocks >> 3, r = nblocks & 7u;
+    const unsigned xcd = bid & 7u, local = bid >> 3;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+__device__ __forceinline__ float4 ld4(const float2* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float2* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------
+// Batched FFT over contiguous groups of N complete samples.
+//   in/out : (n_fft * N, S) complex64 ; pair index = blockIdx.y
+template <int N, int SIGN, int FPW>
+__global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restrict__ in,
+                                                           float2* __restrict__ out, long long n_fft,
+                                                           int S, float scale,
+                                                           const cf* __restrict__ tw0,
+                                                           const cf* __restrict__ tw1) {
+    typedef FftGeo<N> G;
+    constexpr int T = G::T;
+    __shared__ cf lds[FPW * G::LDS_ELEMS];
+    const int slot = threadIdx.x / T, tau = threadIdx.x % T;
+    const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * FPW + slot;
+    const int sp = blockIdx.y;
+    const bool active = i < n_fft;
+    cf v[2][16];
+    if (active) {
+        const float2* src = in + ((i * N + tau) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 x = ld4(src + (long long)T * j * S);
+            v[0][j] = make_float2(x.x, x.y);
+            v[1][j] = make_float2(x.z, x.w);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[0][j] = v[1][j] = make_float2(0.f, 0.f);
+    }
+    wg_fft<N, SIGN, 2, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    if (active) {
+        float2* dst = out + ((i * N + tau) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            st4(dst + (long long)T * j * S, make_float4(v[0][j].x * scale, v[0][j].y * scale,
+                                                        v[1][j].x * scale, v[1][j].y * scale));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Overlap-save block descriptors (one launch handles <= BBT_MAX_CHUNK blocks).
+#define BBT_MAX_CHUNK 16
+struct OsmBlock {
+    long long in_off;   // first input complete sample of the block
+    long long out_off;  // output complete sample that receives n == valid_start
+    int valid_start;    // first block sample kept
+    int valid_count;    // number of block samples kept
+};
+struct OsmChunk {
+    int nblk;
+    OsmBlock b[BBT_MAX_CHUNK];
+};
+
+// Response multiply for a stream pair: H laid out [C][N1][N2] (k = k1 + N1 k2),
+// already scaled by 1/N.
+struct RespSel {
+    int c0, c1;  // response column used by stream 2*sp and 2*sp+1
+};
+
+// Single-kernel path, N <= 4096: one workgroup per (block, pair).
+template <int N>
+__global__ __launch_bounds__(N / 16) void k_osm_small(const float2* __restrict__ in,
+                                                       float2* __restrict__ out, OsmChunk ch, int S,
+                                                       const cf* __restrict__ resp,
+                                                       const int* __restrict__ resp_index,
+                                                       const cf* __restrict__ tw0,
+                                                       const cf* __restrict__ tw1) {
+    typedef FftGeo<N> G;
+    constexpr int T = G::T;
+    __shared__ cf lds[G::LDS_ELEMS];
+    const int tau = threadIdx.x, sp = blockIdx.y;
+    const OsmBlock blk = ch.b[blockIdx.x];
+    cf v[2][16];
+    const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float4 x = ld4(src + (long long)T * j * S);
+        v[0][j] = make_float2(x.x, x.y);
+        v[1][j] = make_float2(x.z, x.w);
+    }
+    wg_fft<N, -1, 2, false>(v, lds, tau, 0, tw0, tw1);
+    const cf* h0 = resp + (long long)resp_index[2 * sp] * N + tau;
+    const cf* h1 = resp + (long long)resp_index[2 * sp + 1] * N + tau;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        v[0][j] = cmul(v[0][j], h0[T * j]);
+        v[1][j] = cmul(v[1][j], h1[T * j]);
+    }
+    wg_fft<N, +1, 2, false>(v, lds, tau, 0, tw0, tw1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int n = tau + T * j;
+        const int r = n - blk.valid_start;
+        if (r >= 0 && r < blk.valid_count)
+            st4(out + ((blk.out_off + r) * S + 2 * sp),
+                make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+    }
+}
+
+// Column pass, N1 == 16: one thread per float4 column, radix-16 in registers.
+//   FIRST: stream -> work (forward).  !FIRST: work -> valid output (inverse).
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in,
+                                                   float2* __restrict__ out,
+                                                   float2* __restrict__ work, OsmChunk ch, int S,
+                                                   int N2) {
+    const int n2 = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
+    const OsmBlock blk = ch.b[b];
+    float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
+    cf v[2][16];
+    if (FIRST) {
+        const float2* src = in + ((blk.in_off + n2) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 x = ld4(src + (long long)j * N2 * S);
+            v[0][j] = make_float2(x.x, x.y);
+            v[1][j] = make_float2(x.z, x.w);
+        }
+        radix16<-1>(v[0]);
+        radix16<-1>(v[1]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            st4(w + (long long)j * N2 * 2, make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 x = ld4(w + (long long)j * N2 * 2);
+            v[0][j] = make_float2(x.x, x.y);
+            v[1][j] = make_float2(x.z, x.w);
+        }
+        radix16<+1>(v[0]);
+        radix16<+1>(v[1]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = j * N2 + n2 - blk.valid_start;
+            if (r >= 0 && r < blk.valid_count)
+                st4(out + ((blk.out_off + r) * S + 2 * sp),
+                    make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+        }
+    }
+}
+
+// Column pass, N1 == 256: 256 threads = 16 float4 columns (f, fastest lane
+// index -> 256-byte runs per row) x 16 threads per 256-point transform.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ in,
+                                                    float2* __restrict__ out,
+                                                    float2* __restrict__ work, OsmChunk ch, int S,
+                                                    int N2, const cf* __restrict__ tw0) {
+    typedef FftGeo<256> G;
+    __shared__ cf lds[G::LDS_ELEMS * 16];
+    const int f = threadIdx.x & 15, tau = threadIdx.x >> 4;
+    const int n2 = xcd_remap(blockIdx.x, gridDim.x) * 16 + f;
+    const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
+    const OsmBlock blk = ch.b[b];
+    // work element (k1, n2) of this (block, pair): float4 at ((b*npair+sp)*256 + k1)*N2 + n2
+    float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
+    cf v[2][16];
+    if (FIRST) {
+        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 x = ld4(src + (long long)16 * j * N2 * S);
+            v[0][j] = make_float2(x.x, x.y);
+            v[1][j] = make_float2(x.z, x.w);
+        }
+        wg_fft<256, -1, 2, true>(v, lds, tau, f, tw0, nullptr);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            st4(w + (long long)16 * j * N2 * 2,
+                make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 x = ld4(w + (long long)16 * j * N2 * 2);
+            v[0][j] = make_float2(x.x, x.y);
+            v[1][j] = make_float2(x.z, x.w);
+        }
+        wg_fft<256, +1, 2, true>(v, lds, tau, f, tw0, nullptr);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
+            if (r >= 0 && r < blk.valid_count)
+                st4(out + ((blk.out_off + r) * S + 2 * sp),
+                    make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+        }
+    }
+}
+
+// Row pass: for row k1 of a (block, pair): four-step twiddle, forward FFT
+// over n2, multiply by the response, inverse FFT over k2, conjugate twiddle.
+//   wroot : W_4096^m, m in [0, 4096)
+template <int N2>
+__global__ __launch_bounds__(N2 / 16) void k_osm_rowpass(float2* __restrict__ work, int N1,
+                                                         const cf* __restrict__ resp,
+                                                         const int* __restrict__ resp_index,
+                                                         int npair, const cf* __restrict__ tw0,
+                                                         const cf* __restrict__ tw1,
+                                                         const cf* __restrict__ wroot) {
+    typedef FftGeo<N2> G;
+    constexpr int T = G::T;
+    __shared__ cf lds[G::LDS_ELEMS];
+    const int tau = threadIdx.x;
+    const int k1 = blockIdx.x;
+    const int sp = blockIdx.y % npair;
+    float2* row = work + (((long long)blockIdx.y * N1 + k1) * N2 + tau) * 2;
+    cf v[2][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float4 x = ld4(row + (long long)T * j * 2);
+        v[0][j] = make_float2(x.x, x.y);
+        v[1][j] = make_float2(x.z, x.w);
+    }
+    // W_N^{k1 (tau + T j)} = W_N^{k1 tau} * W_{16 N1}^{k1 j},  N = N1 * N2
+    cf base;
+    {
+        float s, c;
+        const float ang = -2.0f * (float)(k1 * tau) / ((float)N1 * (float)N2);
+        sincospif(ang, &s, &c);
+        base = make_float2(c, s);
+    }
+    const int M = 16 * N1;          // <= 4096
+    const int rstride = 4096 / M;
+    if (N1 > 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const cf wj = cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]);
+            v[0][j] = cmul(v[0][j], wj);
+            v[1][j] = cmul(v[1][j], wj);
+        }
+    }
+    wg_fft<N2, -1, 2, false>(v, lds, tau, 0, tw0, tw1);
+    {
+        const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
+        const cf* h0 = resp + ((long long)c0 * N1 + k1) * N2 + tau;
+        if (c0 == c1) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const cf h = h0[T * j];
+                v[0][j] = cmul(v[0][j], h);
+                v[1][j] = cmul(v[1][j], h);
+            }
+        } else {
+            const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2 + tau;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v[0][j] = cmul(v[0][j], h0[T * j]);
+                v[1][j] = cmul(v[1][j], h1[T * j]);
+            }
+        }
+    }
+    wg_fft<N2, +1, 2, false>(v, lds, tau, 0, tw0, tw1);
+    if (N1 > 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const cf wj = cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]);
+            v[0][j] = cmulc(v[0][j], wj);
+            v[1][j] = cmulc(v[1][j], wj);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        st4(row + (long long)T * j * 2, make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+}
+
+// Response H[c][k] (natural FFT order) -> Hperm[c][k1][k2] * scale, k = k1 + N1 k2.
+__global__ void k_permute_resp(const cf* __restrict__ h, cf* __restrict__ hp, int N1, long long N2,
+                               float scale) {
+    const long long n = (long long)N1 * N2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // k1*N2 + k2
+    if (idx >= n) return;
+    const long long k1 = idx / N2, k2 = idx % N2;
+    const cf x = h[(long long)blockIdx.y * n + k1 + N1 * k2];
+    hp[(long long)blockIdx.y * n + idx] = make_float2(x.x * scale, x.y * scale);
+}
+
+// ---------------------------------------------------------------------------
+// Polyphase filter bank: y[i, c] = sum_t x[(i + t) N + c] h[t, c], then FFT
+// over c.  in: ((n_spec + n_tap - 1) * N, S); out: (n_spec * N, S); taps
+// (n_tap, N) float32.  The n_tap-fold re-read of each input row is served by
+// the XCD's L2 (xcd_remap keeps neighbouring spectra on one XCD).
+template <int N, int FPW>
+__global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ in,
+                                                      float2* __restrict__ out, long long n_spec,
+                                                      int S, int n_tap,
+                                                      const float* __restrict__ taps,
+                                                      const cf* __restrict__ tw0,
+                                                      const cf* __restrict__ tw1) {
+    typedef FftGeo<N> G;
+    constexpr int T = G::T;
+    __shared__ cf lds[FPW * G::LDS_ELEMS];
+    const int slot = threadIdx.x / T, tau = threadIdx.x % T;
+    const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * FPW + slot;
+    const int sp = blockIdx.y;
+    const bool active = i < n_spec;
+    cf v[2][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[0][j] = v[1][j] = make_float2(0.f, 0.f);
+    if (active) {
+        const float2* src = in + ((i * N + tau) * S + 2 * sp);
+        for (int t = 0; t < n_tap; ++t) {
+            const float* ht = taps + (long long)t * N + tau;
+            const float2* st = src + (long long)t * N * S;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 x = ld4(st + (long long)T * j * S);
+                const float h = ht[T * j];
+                v[0][j].x = fmaf(x.x, h, v[0][j].x);
+                v[0][j].y = fmaf(x.y, h, v[0][j].y);
+                v[1][j].x = fmaf(x.z, h, v[1][j].x);
+                v[1][j].y = fmaf(x.w, h, v[1][j].y);
+            }
+        }
+    }
+    wg_fft<N, -1, 2, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    if (active) {
+        float2* dst = out + ((i * N + tau) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            st4(dst + (long long)T * j * S,
+                make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+    }
+}
+
+}  // namespace bbt

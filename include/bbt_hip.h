@@ -1,0 +1,145 @@
+/* bbt_hip.h -- C ABI of libbbt_hip.so: MI355X (gfx950) kernels for the
+ * coherent-dedispersion -> channelizer hot path of baseband-tasks.
+ *
+ * The reference (mhvk/baseband-tasks) is pure Python; the seam this library
+ * sits behind is the task hook `TaskBase.task(self, data) -> ndarray`
+ * (reference baseband_tasks/base.py:699-706) of these operators:
+ *
+ *   bbt_osm_*   Disperse.task / Dedisperse   dispersion.py:135-139
+ *               Convolve.task (and Resample) convolution.py:116-120
+ *               i.e.  ifft(fft(x, axis=0) * H, axis=0)[valid]  per
+ *               overlap-save block (PaddedTaskBase, base.py:743-795)
+ *   bbt_chan_*  Channelize.task / Dechannelize.task
+ *               channelize.py:73-74, 164-165  (fft over groups of n samples)
+ *   bbt_pfb_*   PolyphaseFilterBankSamples.ppf + Channelize.task
+ *               pfb.py:91-100 (definition), 145-154 (Fourier form)
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     bbt_last_error() then describes the failure (thread-local string).
+ *   - no exceptions cross the boundary; handles are opaque.
+ *   - array layout is numpy complex64, C-contiguous, shape (n, S): time
+ *     major, the S = prod(sample_shape) streams innermost, interleaved
+ *     (re, im) float32.  S must be even (callers pad odd S, see
+ *     bbt_memcpy2d).
+ *   - `*_dev` pointers are device pointers on the current device; the caller
+ *     owns them (bbt_malloc, or any other HIP allocation such as a torch
+ *     tensor's data_ptr()).  `stream` is a hipStream_t (NULL = default).
+ *   - execution is asynchronous on `stream`; use bbt_stream_sync.
+ */
+#ifndef BBT_HIP_H
+#define BBT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bbt_stream; /* hipStream_t */
+typedef void* bbt_event;  /* hipEvent_t  */
+typedef struct bbt_osm_plan bbt_osm_plan;
+typedef struct bbt_chan_plan bbt_chan_plan;
+typedef struct bbt_pfb_plan bbt_pfb_plan;
+
+/* ---- library / device ------------------------------------------------- */
+const char* bbt_last_error(void);
+int bbt_version(void);
+int bbt_device_count(int* count);
+int bbt_set_device(int device);
+int bbt_get_device(int* device);
+int bbt_device_name(char* buf, int buflen);
+
+/* ---- memory, streams, events (plumbing) -------------------------------- */
+int bbt_malloc(void** dev_ptr, size_t nbytes);
+int bbt_free(void* dev_ptr);
+int bbt_host_alloc(void** host_ptr, size_t nbytes); /* pinned */
+int bbt_host_free(void* host_ptr);
+int bbt_memset(void* dev_ptr, int value, size_t nbytes, bbt_stream stream);
+int bbt_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes, bbt_stream stream);
+int bbt_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes, bbt_stream stream);
+int bbt_memcpy_d2d(void* dst_dev, const void* src_dev, size_t nbytes, bbt_stream stream);
+/* 2-D copy (rows of `width` bytes, given pitches); kind: 0 h2d, 1 d2h, 2 d2d.
+ * Used to pad an odd stream count to even and to strip the pad again. */
+int bbt_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                 size_t height, int kind, bbt_stream stream);
+int bbt_stream_create(bbt_stream* stream);
+int bbt_stream_destroy(bbt_stream stream);
+int bbt_stream_sync(bbt_stream stream);
+int bbt_device_sync(void);
+int bbt_event_create(bbt_event* ev);
+int bbt_event_destroy(bbt_event ev);
+int bbt_event_record(bbt_event ev, bbt_stream stream);
+int bbt_event_sync(bbt_event ev);
+int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
+
+/* ---- overlap-save spectral multiply: Dedisperse / Disperse / Convolve ---
+ * Replaces Disperse.task (dispersion.py:135-139) and Convolve.task
+ * (convolution.py:116-120).
+ *
+ *   n_fft       block length N (= PaddedTaskBase._ih_samples_per_frame),
+ *               a power of two, 256 <= N <= 2^20
+ *   n_stream    S, even
+ *   n_resp      number of distinct response columns C
+ *   resp        C x N complex64, FFT-natural order, UNSCALED
+ *               (= Disperse.phase_factor, dispersion.py:115-129, or
+ *               Convolve._ft_response, convolution.py:108-114); the 1/N of
+ *               the inverse transform is applied by the library
+ *   resp_on_device  0: `resp` is a host pointer; 1: device pointer
+ *   resp_index  S ints: response column used by each stream (NULL = all 0)
+ */
+int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_resp,
+                        const void* resp, int resp_on_device, const int32_t* resp_index);
+int bbt_osm_plan_destroy(bbt_osm_plan* plan);
+/* Bytes of device workspace the plan holds, and the number of blocks it
+ * processes per kernel launch. */
+int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* chunk_blocks,
+                      int* n1, int* n2);
+/* Process n_blocks overlap-save blocks.  Block b reads input complete
+ * samples [in_off[b], in_off[b] + N) of `in_dev` and writes block samples
+ * [valid_start[b], valid_start[b] + valid_count[b]) to output complete
+ * samples starting at out_off[b] of `out_dev` (all offsets in complete
+ * samples; arrays are host arrays of length n_blocks).  This is
+ * PaddedTaskBase._seek_frame/_read_frame + task()[pad_slice]
+ * (base.py:775-795, dispersion.py:139) for a batch of frames. */
+int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
+                    const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
+                    const int32_t* valid_count, bbt_stream stream);
+/* Regular case: block b has in_off = in_off0 + b*hop, out_off = out_off0 +
+ * b*hop, the same valid_start and valid_count = hop. */
+int bbt_osm_execute_regular(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
+                            int64_t n_blocks, int64_t in_off0, int64_t out_off0, int64_t hop,
+                            int32_t valid_start, bbt_stream stream);
+/* Per-pass timing with HIP events on the launch stream (off by default).
+ * ms[0..2] = accumulated column-forward / row / column-inverse pass time,
+ * launches = number of launches of each pass since enabling. */
+int bbt_osm_timing_enable(bbt_osm_plan* plan, int enable);
+int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
+
+/* ---- channelizer: Channelize / Dechannelize -----------------------------
+ * Replaces Channelize.task (channelize.py:73-74): FFT over each group of
+ * n_chan consecutive complete samples; in (n_spectra*n_chan, S) ->
+ * out (n_spectra, n_chan, S).  direction -1: forward, unnormalised
+ * (Channelize); +1: inverse, scaled by 1/n_chan (Dechannelize,
+ * channelize.py:164-165).  n_chan a power of two, 256..4096. */
+int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction);
+int bbt_chan_plan_destroy(bbt_chan_plan* plan);
+int bbt_chan_execute(bbt_chan_plan* plan, const void* in_dev, void* out_dev, int64_t n_spectra,
+                     bbt_stream stream);
+
+/* ---- polyphase filter bank ----------------------------------------------
+ * Replaces PolyphaseFilterBank(Samples).ppf + Channelize.task
+ * (pfb.py:91-100, 145-154): out[i] = FFT_c( sum_t in[(i+t)*n_chan + c] *
+ * taps[t, c] ).  Reads (n_spectra + n_tap - 1) * n_chan input samples.
+ * taps: host float32 (n_tap, n_chan). */
+int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream,
+                        const float* taps_host);
+int bbt_pfb_plan_destroy(bbt_pfb_plan* plan);
+int bbt_pfb_execute(bbt_pfb_plan* plan, const void* in_dev, void* out_dev, int64_t n_spectra,
+                    bbt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBT_HIP_H */
