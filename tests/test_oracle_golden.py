@@ -1,0 +1,248 @@
+"""Pin the CPU oracle (oracle/bbt_oracle.py) to vectors produced by the real
+reference (tests/golden/make_golden.py) and to the reference's own known
+answers.  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import bbt_oracle as orc
+from conftest import rel_l2, max_over_rms
+
+# The fixtures were produced with numpy 1.26 (float64 pocketfft, cast to c64);
+# the oracle run with fft64=True under numpy 2 differs by rounding of the last
+# complex64 bit at most.
+TIGHT = 2e-7
+
+
+def stats(a):
+    a = np.asarray(a)
+    s = a.sum(dtype=np.complex128)
+    return np.array([s.real, s.imag, (np.abs(a.astype(np.complex128)) ** 2).sum()])
+
+
+def test_noise_generator_bit_exact(golden):
+    f0 = orc.noise_frame(12345, 0, 2**20, (2,))
+    f1 = orc.noise_frame(12345, 2**20, 2**20, (2,))
+    assert np.array_equal(f0[:4], golden['noise_first'])
+    assert np.array_equal(f1[:4], golden['noise_f1_first'])
+    assert hashlib.sha256(f0.tobytes()).hexdigest() == str(golden['noise_sha'][0])
+    assert hashlib.sha256(f1.tobytes()).hexdigest() == str(golden['noise_sha'][1])
+    # SURVEY 8(a) a18 known answers
+    assert str(golden['noise_sha'][0]).startswith('931e72a582290ad9')
+    assert str(golden['noise_sha'][1]).startswith('26e35f0f2f167ed6')
+    s = orc.noise_stream(12345, 2**20 - 3, 6, 2**20, (2,))
+    assert np.array_equal(s, golden['noise_straddle'])
+    small = orc.noise_stream(7, 0, 1200, 500, (3, 2))
+    assert np.array_equal(small, golden['noise_small'])
+
+
+def test_dm_math(golden):
+    assert golden['dm_const'][0] == orc.DISPERSION_DELAY_CONSTANT
+    f = golden['dm_freqs']
+    np.testing.assert_allclose(orc.time_delay(29.1168, f), golden['dm_time_delay_inf'], rtol=1e-14)
+    np.testing.assert_allclose(orc.time_delay(29.1168, f, 350.), golden['dm_time_delay_ref'],
+                               rtol=1e-13, atol=1e-18)
+    np.testing.assert_allclose(orc.phase_delay(29.1168, f), golden['dm_phase_delay_inf'], rtol=1e-14)
+    np.testing.assert_allclose(orc.phase_delay(29.1168, f, 350.), golden['dm_phase_delay_ref'],
+                               rtol=1e-13)
+    # reference tests/test_dm.py: 0.05 s sweep across 128 kHz at 300 MHz
+    dm = 1000. * 0.05 / 0.039342251
+    assert abs(orc.time_delay(dm, 300. - 0.064, 300. + 0.064) - 0.05) < 1e-9
+
+
+def test_next_fast_len(golden):
+    got = np.array([orc.next_fast_len(int(n)) for n in golden['nfl_n']])
+    assert np.array_equal(got, golden['nfl_out'])
+    # reference tests/test_base.py:522-529 style known answers
+    assert orc.next_fast_len(1000003) == 1000188
+    assert orc.next_fast_len(2**20 + 128) == 1049760
+
+
+@pytest.mark.parametrize('fc,spf', [(1000., None), (800., 2**20 - 415021), (1400., None)])
+def test_config_geometry(golden, fc, spf):
+    g = orc.disperse_geometry(16e6, fc, 1, -100.)
+    geo = orc.padded_geometry(8 * 2**20, 2**20, g['pad_start'], g['pad_end'], spf,
+                              orc.next_fast_len)
+    want = golden['geo_dd_fc%d' % fc]
+    assert [g['pad_start'], g['pad_end'], geo['ih_spf'], geo['spf'], geo['n_out'],
+            g['sample_offset']] == list(want)
+    assert g['reference_frequency'] == golden['reffreq_dd_fc%d' % fc][0]
+    assert abs(g['pad_start'] + g['sample_offset'] - golden['shift_dd_fc%d' % fc][0]) < 1e-3
+
+
+REFS = [None, 300., 300.0123456789, 300.064, 299.936, 300.128, 300.123456789, 299.872]
+
+
+@pytest.mark.parametrize('i', range(8))
+def test_giant_pulse_geometry_and_chirp(golden, i):
+    """Geometry + chirp of the reference's impulse test (tests/test_dispersion.py:14-69)."""
+    dm = golden['gp_dm'][0]
+    sb = np.array([1, -1])
+    g = orc.disperse_geometry(128e3, 300., sb, dm, reference_frequency_mhz=REFS[i])
+    geo = orc.padded_geometry(164000, 1000, g['pad_start'], g['pad_end'], None, orc.next_fast_len)
+    want = golden['geo_gp_ref%d' % i]
+    assert [g['pad_start'], g['pad_end'], geo['ih_spf'], geo['spf'], geo['n_out'],
+            g['sample_offset']] == list(want)
+    assert geo['spf'] in (19324, 19200)
+    h = orc.chirp(geo['ih_spf'], 128e3, 300., sb, dm, g['reference_frequency'], g['sample_offset'])
+    n = h.shape[0]
+    sel = h[[0, 1, 17, n // 2 - 1, n // 2, -1]]
+    assert np.abs(sel - golden['gp_chirp%d' % i]).max() < 3e-7
+    np.testing.assert_allclose(stats(h), golden['gp_chirp_sum%d' % i], rtol=0, atol=2e-3)
+
+
+def test_config2_chirp(golden):
+    g = orc.disperse_geometry(16e6, 1000., 1, -100.)
+    h = orc.chirp(2**20, 16e6, 1000., 1, -100., g['reference_frequency'])
+    assert h.shape == (2**20, 1) and h.dtype == np.complex64
+    assert np.abs(h[golden['c2_chirp_idx'], 0] - golden['c2_chirp']).max() < 2e-7
+    np.testing.assert_allclose(stats(h), golden['c2_chirp_stats'], rtol=0, atol=5e-2)
+
+
+def test_config2_dedisperse_and_channelize(golden):
+    """Config 2 + the metric pipeline, full size (4 x 2^20 input samples)."""
+    x = orc.noise_stream(12345, 0, 4 * 2**20, 2**20, (2,))
+    y, info = orc.dedisperse(x, 16e6, 1000., 1, 100., ih_samples_per_frame=2**20)
+    spf = info['spf']
+    assert (info['pad_start'], info['pad_end'], info['ih_spf'], spf) == (104963, 107513, 2**20, 836100)
+    assert list(y.shape) == list(golden['c2_shape'])
+    for name, sl in (('c2_head', slice(0, 2048)), ('c2_seam1', slice(spf - 1024, spf + 1024)),
+                     ('c2_seam_last', slice(3 * spf - 1024, 3 * spf + 1024)),
+                     ('c2_tail', slice(-2048, None))):
+        assert rel_l2(y[sl], golden[name]) < TIGHT, name
+        assert max_over_rms(y[sl], golden[name]) < 1e-6, name
+    got = np.stack([stats(y[i * spf:(i + 1) * spf]) for i in range(4)])
+    np.testing.assert_allclose(got, golden['c2_stats_blocks'], rtol=1e-6, atol=0.5)
+    z = orc.channelize(y[:(y.shape[0] // (1024 * 512)) * 1024 * 512], 1024)
+    assert list(z.shape) == list(golden['c2ch_shape'])
+    k = spf // 1024
+    for name, sl in (('c2ch_head', slice(0, 2)), ('c2ch_seam', slice(k - 1, k + 2)),
+                     ('c2ch_tail', slice(-2, None))):
+        assert rel_l2(z[sl], golden[name]) < TIGHT, name
+    f = orc.channel_frequency(1024, 16e6, 1000., 1).reshape(-1)
+    np.testing.assert_allclose(f[[0, 1, 511, 512, 1023]], golden['c2ch_freq'], rtol=1e-15)
+    assert f[512] == 992.
+
+
+def test_config1_channelize(golden):
+    x = orc.noise_stream(12345, 0, 2**20, 2**20, (2,))
+    z = orc.channelize(x, 1024)
+    assert list(z.shape) == list(golden['c1_shape'])
+    assert rel_l2(z[:4], golden['c1_head']) < TIGHT
+    assert rel_l2(z[-4:], golden['c1_tail']) < TIGHT
+    np.testing.assert_allclose(stats(z), golden['c1_stats'], rtol=1e-6, atol=0.5)
+
+
+def test_sinc_hamming(golden):
+    r = orc.sinc_hamming(12, 1024)
+    np.testing.assert_allclose([r.sum(), r.max(), r[0, 0], r[5, 17], r[11, 1023]],
+                               golden['sh_12_1024_stats'], rtol=1e-14)
+    np.testing.assert_allclose(orc.sinc_hamming(12, 64, 0.95), golden['sh_guppi'], rtol=1e-14, atol=1e-17)
+    # SURVEY 8(a) a11 known answers
+    assert abs(r.sum() - 1021.688) < 1e-3 and abs(r.max() - 0.99999998) < 1e-8
+
+
+def test_config3_pfb(golden):
+    x = orc.noise_stream(12345, 0, 2 * 2**20, 2**20, (2,))
+    z, geo = orc.polyphase_filter_bank(x, orc.sinc_hamming(12, 1024), ih_samples_per_frame=2**20)
+    want = golden['c3_geo']
+    assert [geo['pad_start'], geo['pad_end'], geo['ih_spf'], geo['spf'], geo['chan_spf'],
+            z.shape[0]] == list(want)
+    assert list(z.shape) == list(golden['c3_shape'])
+    k = geo['chan_spf']
+    for name, sl in (('c3_head', slice(0, 3)), ('c3_seam', slice(k - 1, k + 2)),
+                     ('c3_tail', slice(-3, None))):
+        assert rel_l2(z[sl], golden[name]) < TIGHT, name
+    np.testing.assert_allclose(stats(z), golden['c3_stats'], rtol=1e-6, atol=0.5)
+    # the definition (time-domain FIR) agrees with the Fourier form (pfb.py:91-100 vs 145-154)
+    z2, _ = orc.polyphase_filter_bank(x[:64 * 1024], orc.sinc_hamming(12, 1024), 16384, fourier=False)
+    z1, _ = orc.polyphase_filter_bank(x[:64 * 1024], orc.sinc_hamming(12, 1024), 16384, fourier=True)
+    assert rel_l2(z2, z1) < 3e-7
+
+
+SMALL = [('sa', {}), ('sb', dict(samples_per_frame=4096 - 767 - 771)),
+         ('sc', dict(reference_frequency_mhz=300.4)), ('sd', dict(reference_frequency_mhz=300.7))]
+
+
+@pytest.mark.parametrize('tag,kw', SMALL)
+def test_small_dedisperse_full_output(golden, tag, kw):
+    x = orc.noise_stream(11, 0, 10000, 4000, (2,))
+    y, info = orc.dedisperse(x, 1e6, 300., np.array([1, -1]), 5., ih_samples_per_frame=4000, **kw)
+    want = golden[tag + '_geo']
+    assert [info['pad_start'], info['pad_end'], info['ih_spf'], info['spf'], info['n_out'],
+            info['sample_offset']] == list(want)
+    assert abs(info['start_shift_samples'] - golden[tag + '_shift'][0]) < 1e-4
+    assert y.shape == golden[tag + '_out'].shape
+    assert rel_l2(y, golden[tag + '_out']) < TIGHT
+    assert max_over_rms(y, golden[tag + '_out']) < 1e-6
+
+
+def test_small_disperse_per_stream_frequencies(golden):
+    x = orc.noise_stream(12, 0, 12000, 4000, (2, 2))
+    freq = np.array([[300.], [301.]])
+    sb = np.array([[1], [-1]])
+    g = orc.disperse_geometry(1e6, freq, sb, 3.)
+    geo = orc.padded_geometry(12000, 4000, g['pad_start'], g['pad_end'], 8192 - 923 - 913,
+                              orc.next_fast_len)
+    assert [g['pad_start'], g['pad_end'], geo['ih_spf'], geo['spf'], geo['n_out'],
+            g['sample_offset']] == list(golden['se_geo'])
+    h = orc.chirp(geo['ih_spf'], 1e6, freq, sb, 3., g['reference_frequency'], sample_ndim=2)
+    y = orc.overlap_save(x, geo, lambda b: orc.disperse_block(b, h, geo['pad_start'], geo['spf']))
+    assert rel_l2(y, golden['se_out']) < TIGHT
+
+
+def test_small_channelize_dechannelize(golden):
+    x = orc.noise_stream(13, 0, 20 * 256, 1000, (2,))
+    z = orc.channelize(x[:18 * 256], 256)     # 3 spectra per frame -> 18 of 20 kept
+    assert z.shape == golden['sf_chan'].shape
+    assert rel_l2(z, golden['sf_chan']) < TIGHT
+    f = orc.channel_frequency(256, 1e6, 300., 1)
+    np.testing.assert_allclose(f, golden['sf_freq'], rtol=1e-15)
+    assert rel_l2(orc.dechannelize(z), golden['sf_dechan']) < TIGHT
+
+
+def test_small_pfb(golden):
+    resp = orc.sinc_hamming(4, 256)
+    x = orc.noise_stream(14, 0, 40 * 256, 2560, (2,))
+    z, geo = orc.polyphase_filter_bank(x, resp, ih_samples_per_frame=2560, samples_per_frame=8)
+    assert [geo['pad_start'], geo['pad_end'], geo['ih_spf'], geo['spf'], geo['chan_spf'],
+            z.shape[0]] == list(golden['sg_geo'])
+    assert rel_l2(z, golden['sg_pfb']) < TIGHT
+    x1 = orc.noise_stream(15, 0, 40 * 256, 2560, ())
+    zs, _ = orc.polyphase_filter_bank(x1, resp, 2560, 8, fourier=False)
+    zf, _ = orc.polyphase_filter_bank(x1, resp, 2560, 8, fourier=True)
+    assert rel_l2(zs, golden['sg_pfb_samples_1d']) < TIGHT
+    assert rel_l2(zf, golden['sg_pfb_fourier_1d']) < TIGHT
+
+
+def test_small_convolve_and_resample(golden):
+    x = orc.noise_stream(16, 0, 9000, 3000, (2,))
+    y, geo = orc.convolve(x, golden['sh_response'], offset=5, ih_samples_per_frame=3000)
+    assert [geo['pad_start'], geo['pad_end'], geo['ih_spf'], geo['spf'], geo['n_out'], 0] == \
+        list(golden['sh_geo'])
+    assert rel_l2(y, golden['sh_out']) < TIGHT
+    r, info = orc.resample(x, 0.25, pad=32, samples_per_frame=2048 - 64, ih_samples_per_frame=3000)
+    assert [info['pad_start'], info['pad_end'], info['ih_spf'], info['spf'], info['n_out'], 0] == \
+        list(golden['si_geo'])
+    assert info['pointer'] == golden['si_pointer'][0]
+    assert abs(info['start_shift_samples'] - golden['si_shift'][0]) < 1e-4
+    assert rel_l2(r, golden['si_out']) < TIGHT
+    # chained: Dedisperse(Resample)
+    d, dinfo = orc.dedisperse(r, 1e6, 300., 1, 5., samples_per_frame=4096 - 767 - 771,
+                              ih_samples_per_frame=info['spf'])
+    assert [dinfo['pad_start'], dinfo['pad_end'], dinfo['ih_spf'], dinfo['spf'], dinfo['n_out'], 0] \
+        == list(golden['sj_geo'])
+    assert rel_l2(d, golden['sj_out']) < TIGHT
+
+
+def test_config5_geometry(golden):
+    info = orc.padded_geometry(8 * 2**20, 2**20, 64, 64, 2**20 - 128, orc.next_fast_len)
+    assert [64, 64, info['ih_spf'], info['spf'], info['n_out'], 0] == list(golden['c5_rs_geo'])
+    assert golden['c5_rs_pointer'][0] == -64
+    g = orc.disperse_geometry(16e6, 1000., 1, -100.)
+    geo = orc.padded_geometry(info['n_out'], info['spf'], g['pad_start'], g['pad_end'],
+                              2**20 - 212476, orc.next_fast_len)
+    assert [g['pad_start'], g['pad_end'], geo['ih_spf'], geo['spf'], geo['n_out'], 0] == \
+        list(golden['c5_dd_geo'])
+    assert abs(64 + 0.25 + g['pad_start'] - golden['c5_dd_shift'][0]) < 1e-3
