@@ -1,0 +1,22 @@
+"""baseband_tasks_amd: MI355X-native coherent dedispersion and channelization
+behind the stream-reader interface of mhvk/baseband-tasks.
+
+Only the dedispersion -> channelizer hot path is provided;
+every task here runs hand-written gfx950 kernels through libbbt_hip.so and
+raises if that library is missing -- there is no CPU fallback.
+"""
+from . import units
+from .units import Time
+from .base import (Base, BaseTaskBase, TaskBase, PaddedTaskBase, Task, SetAttribute)
+from .generators import (StreamGenerator, EmptyStreamGenerator, Noise, NoiseGenerator,
+                         DeviceStream)
+from .dm import DispersionMeasure
+from .fourier import fft_maker, HipFFTMaker
+from .dispersion import Disperse, Dedisperse
+from .convolution import Convolve
+from .sampling import ShiftAndResample, Resample
+from .channelize import Channelize, Dechannelize
+from .pfb import sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples
+from . import hip
+
+__version__ = '0.1.0'

@@ -1,0 +1,162 @@
+"""Block-FFT channelizer and its inverse on the GPU (reference
+baseband_tasks/channelize.py:12-178)."""
+import operator
+
+import numpy as np
+
+from . import hip
+from .base import TaskBase, getattr_if_none, _stream_rate
+from .device_task import DeviceTaskMixin, fetch_device
+from .fourier import MIN_FFT_LEN, MAX_WG_FFT_LEN
+
+__all__ = ['Channelize', 'Dechannelize']
+
+
+def _prod(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
+
+
+def _check_n(n):
+    if n < MIN_FFT_LEN or n > MAX_WG_FFT_LEN or n & (n - 1):
+        raise ValueError(f"the accelerated channelizer supports power-of-two n in "
+                         f"[{MIN_FFT_LEN}, {MAX_WG_FFT_LEN}]; got {n}.")
+
+
+class _RowFFTTask(DeviceTaskMixin, TaskBase):
+    """Shared frame computation: ``in_per_out`` input samples per output
+    sample (n for channelizing, 1/n for the inverse)."""
+    _plan = None
+    _direction = -1
+
+    def _setup_streams(self, n, n_stream):
+        self._n = n
+        self._n_stream = n_stream
+        self._n_stream_even = n_stream + (n_stream % 2)
+
+    def _get_plan(self):
+        if self._plan is None:
+            self._plan = hip.ChanPlan(self._n, self._n_stream_even, self._direction)
+        return self._plan
+
+    def _run(self, x, n_spectra, out_flat):
+        """x: (n_spectra * n, S) -> out_flat: (n_spectra * n, S)."""
+        s, se = self._n_stream, self._n_stream_even
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+            tmp = hip.DeviceArray((n_spectra * self._n, se), np.complex64)
+            self._get_plan().execute(x, tmp, n_spectra)
+            hip.strip_stream_pad(tmp, n_spectra * self._n, s, out_flat)
+        else:
+            self._get_plan().execute(x, out_flat, n_spectra)
+
+    def close(self):
+        super().close()
+        self._drop_cache()
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+
+
+class Channelize(_RowFFTTask):
+    """Fourier transform blocks of ``n`` samples: output sample shape
+    ``(n,) + ih.sample_shape``, sample rate ``ih.sample_rate / n``, channel
+    frequencies in `numpy.fft.fftfreq` order (unnormalised forward FFT, no
+    shift) -- reference channelize.py:50-74.
+
+    Parameters
+    ----------
+    ih : stream (complex64)
+    n : int
+        Channels; power of two, 256..4096.
+    samples_per_frame : int
+        Spectra per frame (default 1); only affects framing.
+    frequency, sideband : optional overrides of the stream metadata.
+    """
+
+    def __init__(self, ih, n, samples_per_frame=1, *, frequency=None, sideband=None):
+        n = operator.index(n)
+        samples_per_frame = operator.index(samples_per_frame)
+        if np.dtype(ih.dtype) != np.complex64:
+            raise TypeError("the accelerated channelizer handles complex64 streams; "
+                            f"got {ih.dtype}.")
+        _check_n(n)
+        rate = _stream_rate(ih)
+        frequency = getattr_if_none(ih, 'frequency', frequency, required=False)
+        sideband = getattr_if_none(ih, 'sideband', sideband, required=False)
+        if frequency is not None:
+            fft_freq = np.fft.fftfreq(n, d=1. / rate).reshape((n,) + (1,) * (ih.ndim - 1))
+            frequency = frequency + fft_freq * sideband
+        self._setup_streams(n, _prod(ih.shape[1:]))
+        super().__init__(ih, shape=(-1, n) + tuple(ih.shape[1:]), sample_rate=rate / n,
+                         samples_per_frame=samples_per_frame, frequency=frequency,
+                         sideband=sideband, dtype=np.complex64)
+
+    def _compute_frames(self, first, last, out):
+        start, stop = self._frame_span(first, last)
+        n_spectra = stop - start
+        x = fetch_device(self.ih, start * self._n, n_spectra * self._n)
+        x = x.reshape(n_spectra * self._n, self._n_stream)
+        self._run(x, n_spectra, out.reshape(n_spectra * self._n, self._n_stream))
+
+    def task(self, data):
+        """Channelize one frame given on the host (reference channelize.py:73-74)."""
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        n_spectra = data.shape[0] // self._n
+        x = hip.DeviceArray.from_host(data.reshape(n_spectra * self._n, self._n_stream))
+        y = hip.DeviceArray(x.shape, np.complex64)
+        self._run(x, n_spectra, y)
+        return y.to_host().reshape((n_spectra, self._n) + tuple(self.sample_shape[1:]))
+
+    def inverse(self, ih):
+        """`Dechannelize` that undoes this channelization."""
+        return Dechannelize(ih, n=self._n)
+
+
+class Dechannelize(_RowFFTTask):
+    """Inverse FFT over the channel axis, back to a time stream (complex
+    output only; reference channelize.py:90-178)."""
+    _direction = +1
+
+    def __init__(self, ih, n=None, samples_per_frame=None, *, dtype=None, frequency=None,
+                 sideband=None):
+        assert np.dtype(ih.dtype).kind == 'c', "Dechannelization needs complex spectra."
+        if dtype is not None and np.dtype(dtype) != np.complex64:
+            raise TypeError("the accelerated dechannelizer produces complex64 only.")
+        if n is None:
+            n = ih.shape[1]
+        n = operator.index(n)
+        if n != ih.shape[1]:
+            raise ValueError("for complex output n must equal the number of channels.")
+        _check_n(n)
+        if samples_per_frame is None:
+            ih_spf = ih.samples_per_frame
+        else:
+            ih_spf = max(int(round(samples_per_frame / n)), 1)
+        if frequency is None and getattr(ih, 'frequency', None) is not None:
+            frequency = ih.frequency[0] if np.ndim(ih.frequency) >= len(ih.shape) - 1 \
+                else ih.frequency
+        self._setup_streams(n, _prod(ih.shape[2:]))
+        super().__init__(ih, shape=(-1,) + tuple(ih.shape[2:]),
+                         sample_rate=_stream_rate(ih) * n, ih_samples_per_frame=ih_spf,
+                         frequency=frequency, sideband=sideband, dtype=np.complex64)
+
+    def _compute_frames(self, first, last, out):
+        start, stop = self._frame_span(first, last)
+        n_spectra = (stop - start) // self._n
+        x = fetch_device(self.ih, start // self._n, n_spectra)
+        x = x.reshape(n_spectra * self._n, self._n_stream)
+        self._run(x, n_spectra, out.reshape(n_spectra * self._n, self._n_stream))
+
+    def task(self, data):
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        n_spectra = data.shape[0]
+        x = hip.DeviceArray.from_host(data.reshape(n_spectra * self._n, self._n_stream))
+        y = hip.DeviceArray(x.shape, np.complex64)
+        self._run(x, n_spectra, y)
+        return y.to_host().reshape((n_spectra * self._n,) + tuple(self.sample_shape))
+
+    def inverse(self, ih):
+        return Channelize(ih, n=self._n)

@@ -1,0 +1,124 @@
+"""Coherent (de)dispersion on the GPU.
+
+`Disperse` / `Dedisperse` keep the constructor and stream surface of the
+reference (baseband_tasks/dispersion.py:16-190); the per-frame arithmetic
+``ifft(fft(x) * phase_factor)[pad_start:pad_start + spf]``
+(dispersion.py:135-139) runs in libbbt_hip.so.
+"""
+import numpy as np
+
+from . import units as u
+from .base import getattr_if_none, _stream_rate, _stream_start
+from .dm import DispersionMeasure
+from .overlap_save import SpectralMultiplyTask
+
+__all__ = ['Disperse', 'Dedisperse']
+
+
+class Disperse(SpectralMultiplyTask):
+    """Coherently disperse a time stream.
+
+    Parameters
+    ----------
+    ih : stream
+        Input, time along the first axis, complex64.
+    dm : float or `DispersionMeasure`
+        In pc / cm^3; negative values dedisperse.
+    reference_frequency : float or array, optional
+        Frequency (Hz) to which the data are dispersed; default the mean
+        band centre.
+    samples_per_frame : int, optional
+        Output samples per frame.  Default: the block that keeps padding
+        below 25 % of it, rounded up to a length the FFT engine likes.
+    frequency, sideband : optional
+        Override / provide the stream's metadata (frequency in Hz).
+    """
+
+    def __init__(self, ih, dm, *, reference_frequency=None, samples_per_frame=None,
+                 frequency=None, sideband=None):
+        dm = DispersionMeasure(dm)
+        frequency = u.to_hz(getattr_if_none(ih, 'frequency', frequency))
+        sideband = np.asanyarray(getattr_if_none(ih, 'sideband', sideband))
+        rate = _stream_rate(ih)
+        # band edges (dispersion.py:54-61)
+        half = rate / 2.
+        if np.dtype(ih.dtype).kind == 'c':
+            f_lo, f_hi = frequency - half, frequency + half
+        else:
+            f_lo = frequency + np.minimum(sideband, 0.) * half
+            f_hi = frequency + np.maximum(sideband, 0.) * half
+        if reference_frequency is None:
+            reference_frequency = np.mean(f_lo + f_hi) / 2.
+        else:
+            reference_frequency = u.to_hz(reference_frequency)
+        # extreme delays across the band -> padding (dispersion.py:66-74)
+        d_lo = dm.time_delay(f_lo, reference_frequency)
+        d_hi = dm.time_delay(f_hi, reference_frequency)
+        d_max = max(np.max(d_lo), np.max(d_hi))
+        d_min = min(np.min(d_lo), np.min(d_hi))
+        pad_start = int(np.ceil(d_max * rate))
+        pad_end = int(np.ceil(-d_min * rate))
+        # reference frequency outside the band: part of the delay is a plain
+        # shift of the time stamps (dispersion.py:78-93)
+        if pad_start < 0:
+            assert pad_end > 0
+            sample_offset = pad_start
+            pad_end += pad_start
+            pad_start = 0
+        elif pad_end < 0:
+            sample_offset = -pad_end
+            pad_start += pad_end
+            pad_end = 0
+        else:
+            sample_offset = 0
+        start_time = _stream_start(ih) + sample_offset / rate
+        super().__init__(ih, pad_start, pad_end, samples_per_frame=samples_per_frame,
+                         frequency=frequency, sideband=sideband, start_time=start_time)
+        self._dm = dm
+        self.reference_frequency = reference_frequency
+        self._sample_offset = sample_offset
+        self._keep_from = self._pad_start
+        self._pad_slice = slice(self._pad_start, self._pad_start + self.samples_per_frame)
+        self._phase_factor = None
+
+    @property
+    def phase_factor(self):
+        """exp(2 pi i phase) per FFT bin, float64 arithmetic cast to complex64
+        (dispersion.py:115-129); shape ``(N,) +`` broadcastable sample shape."""
+        if self._phase_factor is None:
+            n = self._ih_samples_per_frame
+            fft_freq = np.fft.fftfreq(n, d=1. / self.sample_rate)
+            fft_freq = fft_freq.reshape((n,) + (1,) * len(self.sample_shape))
+            frequency = self.frequency + fft_freq * self.sideband
+            phase = self._dm.phase_delay(frequency, self.reference_frequency)
+            phase = phase * self.sideband
+            if self._sample_offset != 0:
+                phase = phase + (self._sample_offset / self.sample_rate) * fft_freq
+            self._phase_factor = np.exp(phase * (2j * np.pi)).astype(np.complex64)
+        return self._phase_factor
+
+    def _spectral_response(self):
+        return self.phase_factor
+
+    @property
+    def dm(self):
+        return self._dm
+
+    def close(self):
+        super().close()
+        self._phase_factor = None
+
+
+class Dedisperse(Disperse):
+    """Coherently dedisperse a time stream (reference dispersion.py:149-190);
+    parameters as for `Disperse`, with ``dm`` the DM to remove."""
+
+    def __init__(self, ih, dm, *, reference_frequency=None, samples_per_frame=None,
+                 frequency=None, sideband=None):
+        super().__init__(ih, -DispersionMeasure(dm), reference_frequency=reference_frequency,
+                         samples_per_frame=samples_per_frame, frequency=frequency,
+                         sideband=sideband)
+
+    @property
+    def dm(self):
+        return -self._dm

@@ -1,0 +1,432 @@
+"""ctypes binding of libbbt_hip.so (C ABI: include/bbt_hip.h) and thin device
+helpers.  There is deliberately NO fallback: if the library is missing or a
+call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+__all__ = ['HipError', 'HipLibraryMissing', 'lib', 'available', 'DeviceArray',
+           'OsmPlan', 'ChanPlan', 'PfbPlan', 'set_stream', 'get_stream',
+           'synchronize', 'Event', 'device_count', 'set_device']
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libbbt_hip.so')
+
+
+class HipError(RuntimeError):
+    """A call into libbbt_hip.so failed."""
+
+
+class HipLibraryMissing(ImportError):
+    """libbbt_hip.so has not been built (run ``python __graft_entry__.py``)."""
+
+
+_vp, _i64, _i32, _int, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_int, C.c_size_t
+_pvp = C.POINTER(C.c_void_p)
+_pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+
+# name -> argtypes ; every entry point declared in include/bbt_hip.h
+SIGNATURES = {
+    'bbt_version': [],
+    'bbt_device_count': [C.POINTER(_int)],
+    'bbt_set_device': [_int],
+    'bbt_get_device': [C.POINTER(_int)],
+    'bbt_device_name': [C.c_char_p, _int],
+    'bbt_malloc': [_pvp, _sz],
+    'bbt_free': [_vp],
+    'bbt_host_alloc': [_pvp, _sz],
+    'bbt_host_free': [_vp],
+    'bbt_memset': [_vp, _int, _sz, _vp],
+    'bbt_memcpy_h2d': [_vp, _vp, _sz, _vp],
+    'bbt_memcpy_d2h': [_vp, _vp, _sz, _vp],
+    'bbt_memcpy_d2d': [_vp, _vp, _sz, _vp],
+    'bbt_memcpy2d': [_vp, _sz, _vp, _sz, _sz, _sz, _int, _vp],
+    'bbt_stream_create': [_pvp],
+    'bbt_stream_destroy': [_vp],
+    'bbt_stream_sync': [_vp],
+    'bbt_device_sync': [],
+    'bbt_event_create': [_pvp],
+    'bbt_event_destroy': [_vp],
+    'bbt_event_record': [_vp, _vp],
+    'bbt_event_sync': [_vp],
+    'bbt_event_elapsed_ms': [_vp, _vp, C.POINTER(C.c_float)],
+    'bbt_osm_plan_create': [_pvp, _i64, _int, _int, _vp, _int, _pi32],
+    'bbt_osm_plan_destroy': [_vp],
+    'bbt_osm_plan_info': [_vp, _pi64, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
+    'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
+    'bbt_osm_execute_regular': [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    'bbt_osm_timing_enable': [_vp, _int],
+    'bbt_osm_timing_read': [_vp, C.POINTER(C.c_double), _pi64],
+    'bbt_chan_plan_create': [_pvp, _int, _int, _int],
+    'bbt_chan_plan_destroy': [_vp],
+    'bbt_chan_execute': [_vp, _vp, _vp, _i64, _vp],
+    'bbt_pfb_plan_create': [_pvp, _int, _int, _int, C.POINTER(C.c_float)],
+    'bbt_pfb_plan_destroy': [_vp],
+    'bbt_pfb_execute': [_vp, _vp, _vp, _i64, _vp],
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HipLibraryMissing(
+                        f"{LIB_PATH} not found: build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+                handle = C.CDLL(LIB_PATH)
+                handle.bbt_last_error.restype = C.c_char_p
+                handle.bbt_last_error.argtypes = []
+                for name, argtypes in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.argtypes = argtypes
+                    fn.restype = _int
+                _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HipError(lib().bbt_last_error().decode(errors='replace'))
+
+
+def device_count():
+    n = _int(0)
+    check(lib().bbt_device_count(C.byref(n)))
+    return n.value
+
+
+def available():
+    """True if the library loads and sees at least one GPU."""
+    try:
+        return device_count() > 0
+    except (HipError, HipLibraryMissing, OSError):
+        return False
+
+
+def set_device(index):
+    check(lib().bbt_set_device(int(index)))
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    check(lib().bbt_device_name(buf, 256))
+    return buf.value.decode()
+
+
+# The stream all work of this package is queued on (a hipStream_t as int;
+# None / 0 = the default stream).  bench.py points it at torch's stream.
+_stream = None
+
+
+def set_stream(stream):
+    global _stream
+    _stream = int(stream) if stream else None
+
+
+def get_stream():
+    return _stream
+
+
+def synchronize():
+    check(lib().bbt_stream_sync(_stream))
+
+
+class Event:
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(lib().bbt_event_create(C.byref(self._h)))
+
+    def record(self):
+        check(lib().bbt_event_record(self._h, _stream))
+        return self
+
+    def synchronize(self):
+        check(lib().bbt_event_sync(self._h))
+
+    def elapsed_ms(self, later):
+        ms = C.c_float()
+        check(lib().bbt_event_elapsed_ms(self._h, later._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().bbt_event_destroy(self._h)
+        except Exception:
+            pass
+
+
+class _Allocation:
+    """Owns one hipMalloc'ed block."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        check(lib().bbt_malloc(C.byref(self.ptr), max(self.nbytes, 1)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().bbt_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """C-contiguous array in HBM: (ptr, shape, dtype); leading-axis slices are
+    zero-copy views.  ``owner`` keeps the allocation (or a foreign object such
+    as a torch tensor) alive."""
+
+    def __init__(self, shape, dtype=np.complex64, ptr=None, owner=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        if ptr is None:
+            owner = _Allocation(self.nbytes)
+            ptr = owner.ptr.value
+        self.ptr = int(ptr) if ptr else 0
+        self.owner = owner
+
+    @property
+    def size(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def row_bytes(self):
+        n = self.dtype.itemsize
+        for d in self.shape[1:]:
+            n *= d
+        return n
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, item):
+        if not isinstance(item, slice):
+            raise TypeError("DeviceArray supports only leading-axis slices")
+        start, stop, step = item.indices(self.shape[0])
+        if step != 1:
+            raise ValueError("DeviceArray slices must be contiguous")
+        stop = max(stop, start)
+        return DeviceArray((stop - start,) + self.shape[1:], self.dtype,
+                           self.ptr + start * self.row_bytes, self.owner)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and not isinstance(shape[0], int):
+            shape = tuple(shape[0])
+        shape = list(shape)
+        if -1 in shape:
+            known = 1
+            for d in shape:
+                if d != -1:
+                    known *= d
+            shape[shape.index(-1)] = self.size // known if known else 0
+        out = DeviceArray(shape, self.dtype, self.ptr, self.owner)
+        if out.size != self.size:
+            raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
+        return out
+
+    @classmethod
+    def from_host(cls, array, dtype=None):
+        array = np.ascontiguousarray(array, dtype=dtype)
+        out = cls(array.shape, array.dtype)
+        out.copy_from_host(array)
+        return out
+
+    def copy_from_host(self, array):
+        array = np.ascontiguousarray(array, dtype=self.dtype)
+        if array.nbytes != self.nbytes:
+            raise ValueError("size mismatch in host to device copy")
+        if array.nbytes:
+            check(lib().bbt_memcpy_h2d(self.ptr, array.ctypes.data, array.nbytes, _stream))
+            # pageable host memory: make sure the source may be released
+            check(lib().bbt_stream_sync(_stream))
+        return self
+
+    def copy_from_device(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError("size mismatch in device to device copy")
+        if self.nbytes:
+            check(lib().bbt_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _stream))
+        return self
+
+    def to_host(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        elif (not isinstance(out, np.ndarray) or out.dtype != self.dtype
+              or not out.flags.c_contiguous or out.shape != self.shape):
+            tmp = self.to_host()
+            out[...] = tmp
+            return out
+        if self.nbytes:
+            check(lib().bbt_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, _stream))
+            check(lib().bbt_stream_sync(_stream))
+        return out
+
+    def fill_bytes(self, value):
+        if self.nbytes:
+            check(lib().bbt_memset(self.ptr, int(value), self.nbytes, _stream))
+        return self
+
+    @property
+    def __cuda_array_interface__(self):
+        return dict(shape=self.shape, typestr=self.dtype.str, data=(self.ptr, False),
+                    version=3, strides=None)
+
+    def __repr__(self):
+        return f"<DeviceArray shape={self.shape} dtype={self.dtype} ptr=0x{self.ptr:x}>"
+
+
+def as_device_array(obj):
+    """DeviceArray view of a DeviceArray or a torch tensor on the GPU."""
+    if isinstance(obj, DeviceArray):
+        return obj
+    if hasattr(obj, 'data_ptr') and hasattr(obj, 'is_contiguous'):   # torch
+        if not obj.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        import torch
+        dt = {torch.complex64: np.complex64, torch.float32: np.float32,
+              torch.complex128: np.complex128, torch.float64: np.float64}[obj.dtype]
+        return DeviceArray(tuple(obj.shape), dt, obj.data_ptr(), obj)
+    raise TypeError(f"cannot interpret {type(obj)} as a device array")
+
+
+def pad_streams_to_even(dev, n_stream):
+    """(n, S) complex64 with odd S -> (n, S+1) with a zero stream appended."""
+    n = dev.size // n_stream
+    out = DeviceArray((n, n_stream + 1), dev.dtype)
+    out.fill_bytes(0)
+    isz = dev.dtype.itemsize
+    if n:
+        check(lib().bbt_memcpy2d(out.ptr, (n_stream + 1) * isz, dev.ptr, n_stream * isz,
+                                 n_stream * isz, n, 2, _stream))
+    return out
+
+
+def strip_stream_pad(dev_padded, n_rows, n_stream, out):
+    """inverse of pad_streams_to_even for rows of (S+1) -> S elements."""
+    isz = dev_padded.dtype.itemsize
+    if n_rows:
+        check(lib().bbt_memcpy2d(out.ptr, n_stream * isz, dev_padded.ptr, (n_stream + 1) * isz,
+                                 n_stream * isz, n_rows, 2, _stream))
+    return out
+
+
+class _Plan:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, '_h', None):
+            getattr(lib(), self._destroy)(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OsmPlan(_Plan):
+    """ifft(fft(block) * response)[valid] for overlap-save blocks."""
+    _destroy = 'bbt_osm_plan_destroy'
+
+    def __init__(self, n_fft, n_stream, response, response_index=None):
+        super().__init__()
+        self.n_fft, self.n_stream = int(n_fft), int(n_stream)
+        if isinstance(response, DeviceArray):
+            resp_ptr, on_dev, n_resp = response.ptr, 1, response.shape[0]
+            assert response.dtype == np.complex64 and response.shape[1] == n_fft
+        else:
+            response = np.ascontiguousarray(response, dtype=np.complex64)
+            assert response.ndim == 2 and response.shape[1] == n_fft
+            resp_ptr, on_dev, n_resp = response.ctypes.data, 0, response.shape[0]
+        idx = None
+        if response_index is not None:
+            idx_arr = np.ascontiguousarray(response_index, dtype=np.int32)
+            assert idx_arr.shape == (n_stream,)
+            idx = idx_arr.ctypes.data_as(_pi32)
+        check(lib().bbt_osm_plan_create(C.byref(self._h), self.n_fft, self.n_stream, n_resp,
+                                        resp_ptr, on_dev, idx))
+
+    def info(self):
+        ws, chunk, n1, n2 = _i64(), _int(), _int(), _int()
+        check(lib().bbt_osm_plan_info(self._h, C.byref(ws), C.byref(chunk), C.byref(n1),
+                                      C.byref(n2)))
+        return dict(workspace_bytes=ws.value, chunk_blocks=chunk.value, n1=n1.value, n2=n2.value)
+
+    def execute(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
+        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
+        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
+        n = in_off.shape[0]
+        assert out_off.shape == valid_start.shape == valid_count.shape == (n,)
+        check(lib().bbt_osm_execute(self._h, in_dev.ptr, out_dev.ptr, n,
+                                    in_off.ctypes.data_as(_pi64), out_off.ctypes.data_as(_pi64),
+                                    valid_start.ctypes.data_as(_pi32),
+                                    valid_count.ctypes.data_as(_pi32), _stream))
+
+    def execute_regular(self, in_dev, out_dev, n_blocks, in_off0, out_off0, hop, valid_start):
+        check(lib().bbt_osm_execute_regular(self._h, in_dev.ptr, out_dev.ptr, int(n_blocks),
+                                            int(in_off0), int(out_off0), int(hop),
+                                            int(valid_start), _stream))
+
+    def timing_enable(self, enable=True):
+        check(lib().bbt_osm_timing_enable(self._h, int(bool(enable))))
+
+    def timing_read(self):
+        ms = (C.c_double * 3)()
+        n = _i64()
+        check(lib().bbt_osm_timing_read(self._h, ms, C.byref(n)))
+        return list(ms), n.value
+
+
+class ChanPlan(_Plan):
+    """FFT over groups of n_chan complete samples."""
+    _destroy = 'bbt_chan_plan_destroy'
+
+    def __init__(self, n_chan, n_stream, direction=-1):
+        super().__init__()
+        self.n_chan, self.n_stream = int(n_chan), int(n_stream)
+        check(lib().bbt_chan_plan_create(C.byref(self._h), self.n_chan, self.n_stream,
+                                         int(direction)))
+
+    def execute(self, in_dev, out_dev, n_spectra):
+        check(lib().bbt_chan_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_spectra), _stream))
+
+
+class PfbPlan(_Plan):
+    """n_tap FIR across blocks followed by the channelizer FFT."""
+    _destroy = 'bbt_pfb_plan_destroy'
+
+    def __init__(self, taps, n_stream):
+        super().__init__()
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        self.n_tap, self.n_chan = taps.shape
+        self.n_stream = int(n_stream)
+        check(lib().bbt_pfb_plan_create(C.byref(self._h), self.n_tap, self.n_chan, self.n_stream,
+                                        taps.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def execute(self, in_dev, out_dev, n_spectra):
+        check(lib().bbt_pfb_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_spectra), _stream))

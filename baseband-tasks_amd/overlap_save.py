@@ -1,0 +1,114 @@
+"""GPU overlap-save tasks of the form  ifft(fft(block) * H)[valid].
+
+Base of `Disperse`/`Dedisperse` (reference dispersion.py:135-139) and
+`Convolve` (convolution.py:116-120): the geometry is `PaddedTaskBase`'s, the
+arithmetic is one `bbt_osm_execute` call for a whole run of frames.
+"""
+import numpy as np
+
+from . import hip
+from .base import PaddedTaskBase
+from .device_task import DeviceTaskMixin, fetch_device
+from .fourier import fft_maker
+
+__all__ = ['SpectralMultiplyTask']
+
+
+def _prod(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
+
+
+class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
+    """Subclasses provide
+
+    ``_spectral_response()`` -> complex64 array ``(N,) + b`` with ``b``
+    broadcastable to the sample shape, in FFT-natural order, unscaled; and
+    set ``_keep_from`` (block index of the first kept sample of a regular
+    frame: ``pad_start`` for dispersion, ``pad_start + pad_end`` for
+    convolution).
+    """
+    _plan = None
+    _keep_from = 0
+
+    def __init__(self, ih, pad_start, pad_end, *, samples_per_frame=None, **kwargs):
+        if not np.dtype(ih.dtype) == np.complex64:
+            raise TypeError("the accelerated path handles complex64 streams; got "
+                            f"{ih.dtype} (real streams: convert with Real2Complex first).")
+        self._FFT = fft_maker.get()
+        super().__init__(ih, pad_start=pad_start, pad_end=pad_end,
+                         samples_per_frame=samples_per_frame,
+                         next_fast_len=self._FFT.next_fast_len, **kwargs)
+        self._n_stream = _prod(self.sample_shape)
+        self._n_stream_even = self._n_stream + (self._n_stream % 2)
+
+    # -- plan ------------------------------------------------------------------
+    def _response_columns(self):
+        """(C, N) response columns and the column index of every stream."""
+        resp = np.asarray(self._spectral_response(), dtype=np.complex64)
+        n = self._ih_samples_per_frame
+        assert resp.shape[0] == n
+        bshape = resp.shape[1:]
+        ncol = _prod(bshape)
+        index = np.broadcast_to(np.arange(ncol).reshape(bshape), self.sample_shape).ravel()
+        columns = np.ascontiguousarray(resp.reshape(n, ncol).T)
+        index = index.astype(np.int32)
+        if self._n_stream_even != self._n_stream:
+            index = np.concatenate([index, index[-1:]])
+        return columns, index
+
+    def _get_plan(self):
+        if self._plan is None:
+            columns, index = self._response_columns()
+            self._plan = hip.OsmPlan(self._ih_samples_per_frame, self._n_stream_even,
+                                     columns, index)
+        return self._plan
+
+    # -- frames ------------------------------------------------------------------
+    def _compute_frames(self, first, last, out):
+        plan = self._get_plan()
+        spf, n = self.samples_per_frame, self._ih_samples_per_frame
+        frames = np.arange(first, last)
+        blocks = [self._block_start(m) for m in frames]
+        starts = np.array([b[0] for b in blocks], dtype=np.int64)
+        skips = np.array([b[1] for b in blocks], dtype=np.int64)
+        in0 = int(starts[0])
+        x = fetch_device(self.ih, in0, int(starts[-1]) + n - in0)
+        counts = np.minimum(spf - skips, self.shape[0] - frames * spf)
+        out_off = frames * spf - first * spf
+        s, se = self._n_stream, self._n_stream_even
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+            padded_out = hip.DeviceArray((out.shape[0], se), np.complex64)
+            target = padded_out
+        else:
+            target = out
+        plan.execute(x, target, starts - in0, out_off, self._keep_from + skips, counts)
+        if se != s:
+            hip.strip_stream_pad(padded_out, out.shape[0], s, out)
+
+    def close(self):
+        super().close()
+        self._drop_cache()
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+
+    def task(self, data):
+        """Process one input block given on the host (the reference's hook,
+        base.py:699-706).  Runs the same kernels on an uploaded copy."""
+        n = self._ih_samples_per_frame
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        assert data.shape == (n,) + tuple(self.sample_shape)
+        x = hip.DeviceArray.from_host(data.reshape(n, self._n_stream))
+        s, se = self._n_stream, self._n_stream_even
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+        spf = self.samples_per_frame
+        y = hip.DeviceArray((spf, se), np.complex64)
+        self._get_plan().execute(x, y, [0], [0], [self._keep_from], [spf])
+        if se != s:
+            y = hip.strip_stream_pad(y, spf, s, hip.DeviceArray((spf, s), np.complex64))
+        return y.to_host().reshape((spf,) + tuple(self.sample_shape))

@@ -1,0 +1,97 @@
+"""Fractional-sample shifting / resampling as a Fourier-domain convolution on
+the GPU (reference baseband_tasks/sampling.py:63-312)."""
+import numpy as np
+
+from . import units as u
+from .base import check_broadcast_to, _stream_rate, _stream_start
+from .convolution import Convolve
+from .units import Time
+
+__all__ = ['to_sample', 'seek_float', 'ShiftAndResample', 'Resample']
+
+
+def to_sample(ih, offset):
+    """Offset in (float) samples: numbers are samples, astropy time
+    quantities are converted with the sample rate (sampling.py:17-20)."""
+    if hasattr(offset, 'to_value'):
+        return offset.to_value('s') * _stream_rate(ih)
+    return np.asanyarray(offset, dtype=float) if np.ndim(offset) else float(offset)
+
+
+def seek_float(ih, offset, whence=0):
+    """Like ``ih.seek`` without rounding; may differ per stream
+    (sampling.py:23-60)."""
+    if u.is_time(offset):
+        offset = (Time(offset) - _stream_start(ih)) * _stream_rate(ih)
+        whence = 0
+    offset = to_sample(ih, offset)
+    check_broadcast_to(offset, ih.shape[1:])
+    if whence == 0 or whence == 'start':
+        return offset
+    elif whence == 1 or whence == 'current':
+        return ih.offset + offset
+    elif whence == 2 or whence == 'end':
+        return ih.shape[0] + offset
+    raise ValueError("invalid 'whence'; should be 0 or 'start', 1 or "
+                     "'current', or 2 or 'end'.")
+
+
+class ShiftAndResample(Convolve):
+    """Shift a stream in time by ``shift`` samples (may differ per stream) and
+    optionally resample it so that a sample falls on ``offset``; ``lo`` adds the
+    phase rotation of a mixed-down signal.  Response: windowed sinc of
+    ``2 * pad + 1`` taps (reference sampling.py:63-227)."""
+
+    def __init__(self, ih, shift, offset=None, whence='start', *, lo=None, pad=64,
+                 samples_per_frame=None):
+        self._shift = to_sample(ih, shift)
+        shift_mean = np.mean(self._shift)
+        if offset is None:
+            d_time = shift_mean
+            self._offset = None
+        else:
+            self._offset = seek_float(ih, offset, whence)
+            d_time = self._offset + np.around(shift_mean - self._offset)
+        sample_shift = np.array(self._shift - d_time, ndmin=ih.ndim - 1, dtype=float)
+        response = self._windowed_sinc(pad, sample_shift)
+        if samples_per_frame is None:
+            samples_per_frame = max(ih.samples_per_frame, pad * 14)
+        super().__init__(ih, response, offset=pad - int(round(float(sample_shift.min()))),
+                         samples_per_frame=samples_per_frame)
+        self._lo = None if lo is None else u.to_hz(lo)
+        self._start_time = self._start_time + float(d_time) / self.sample_rate
+
+    @staticmethod
+    def _windowed_sinc(pad, sample_shift):
+        """sinc(x) cos^2(pi x / (2 pad + 2)) on x = -pad..pad minus the
+        fractional shift, per stream (sampling.py:177-193)."""
+        i_max = int(round(float(sample_shift.max())))
+        i_min = int(round(float(sample_shift.min())))
+        n_result = 2 * pad + 1 + i_max - i_min
+        result = np.zeros((n_result,) + sample_shift.shape)
+        flat = result.reshape(n_result, -1)
+        for k, shift in enumerate(sample_shift.ravel()):
+            i_shift = int(round(float(shift)))
+            x = np.arange(-pad, pad + 1) - (shift - i_shift)
+            flat[i_shift - i_min:i_shift - i_max + n_result, k] = (
+                np.sinc(x) * np.cos(np.pi * x / (2 * pad + 2)) ** 2)
+        return result
+
+    @property
+    def _ft_response(self):
+        base = super()._ft_response
+        if self._lo is None:
+            return base
+        # phase rotation -shift/fs * lo * sideband cycles (sampling.py:211-220)
+        phase = self._shift / self.sample_rate * self._lo * self.sideband
+        return (base * np.exp(-2j * np.pi * phase)).astype(np.complex64)
+
+
+class Resample(ShiftAndResample):
+    """Resample so that a sample falls exactly on ``offset`` and leave the
+    sample pointer there (reference sampling.py:230-312)."""
+
+    def __init__(self, ih, offset, whence='start', *, pad=64, samples_per_frame=None):
+        super().__init__(ih, shift=0., offset=offset, whence=whence, pad=pad,
+                         samples_per_frame=samples_per_frame)
+        self.seek(_stream_start(ih) + float(self._offset) / _stream_rate(ih))
