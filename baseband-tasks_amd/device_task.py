@@ -153,5 +153,12 @@ class DeviceTaskMixin:
         self._cache = self._cache_buffer = None
         self._cache_first = self._cache_last = 0
 
+    def invalidate_cache(self):
+        """Forget cached frames (they will be recomputed) but keep the device
+        buffer, so repeated passes do not reallocate."""
+        self._cache = None
+        self._cache_first = self._cache_last = 0
+        self._frame = self._frame_index = None
+
     def synchronize(self):
         hip.synchronize()
