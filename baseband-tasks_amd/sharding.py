@@ -61,6 +61,7 @@ def share_response(task, torch, dist, device, src=0):
 def gather_frames(local, torch, dist):
     """All-gather equally sized per-rank outputs in rank (= stream) order."""
     world = dist.get_world_size()
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
-    return out.reshape((-1,) + tuple(local.shape[1:]))
+    return out

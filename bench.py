@@ -183,13 +183,14 @@ def main():
     if args.gather and world > 1:
         z = step()
         zt = torch.as_tensor(z, device=dev)
-        out = torch.empty((world,) + tuple(zt.shape), dtype=zt.dtype, device=dev)
+        zt = torch.view_as_real(zt)
+        out = torch.empty((world * zt.shape[0],) + tuple(zt.shape[1:]), dtype=zt.dtype, device=dev)
         fence()
         t0 = time.perf_counter()
         dist.all_gather_into_tensor(out, zt)
         fence()
         dt = time.perf_counter() - t0
-        gather = dict(seconds=dt, GBps_per_rank_in=zt.numel() * 8 * (world - 1) / dt / 1e9)
+        gather = dict(seconds=dt, GBps_per_rank_in=zt.numel() * 4 * (world - 1) / dt / 1e9)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

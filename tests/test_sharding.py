@@ -1,0 +1,75 @@
+"""Multi-rank logic on CPU: frame partitioning and the response broadcast /
+output gather over torch.distributed with the gloo backend, world size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from baseband_tasks_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frame_range_partitions_exactly():
+    for n in (0, 1, 7, 64, 65, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.frame_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import baseband_tasks_amd as bt
+    from baseband_tasks_amd import units as u
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_total = 16 * 4096
+        nh = bt.NoiseGenerator((n_total, 2), '2020-01-01T00:00:00', 1 * u.MHz, 4096, seed=5,
+                               frequency=300 * u.MHz, sideband=np.array([1, -1]))
+        # ranks deliberately disagree about the DM before the broadcast
+        dd = bt.Dedisperse(nh, 5. if rank == 0 else 4.9, samples_per_frame=4096 - 1538)
+        resp, idx = sharding.share_response(dd, torch, dist, torch.device('cpu'))
+        first, last = sharding.frame_range(dd._n_frames(), rank, world)
+        # fake "outputs": the frame indices owned, gathered in stream order
+        local = torch.arange(first, first + 4, dtype=torch.float32).reshape(4, 1)
+        gathered = sharding.gather_frames(local, torch, dist)
+        np.savez(os.path.join(result_dir, f'rank{rank}.npz'), resp=resp.numpy(), idx=idx.numpy(),
+                 span=np.array([first, last]), gathered=gathered.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_share_response_and_gather_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / 'rank0.npz')
+    r1 = np.load(tmp_path / 'rank1.npz')
+    # every rank ends up with rank 0's response (DM 5), bit for bit
+    assert np.array_equal(r0['resp'], r1['resp']) and np.array_equal(r0['idx'], r1['idx'])
+    import baseband_tasks_amd as bt
+    from baseband_tasks_amd import units as u
+    nh = bt.EmptyStreamGenerator((16 * 4096, 2), '2020-01-01T00:00:00', 1 * u.MHz, samples_per_frame=4096,
+                                 frequency=300 * u.MHz, sideband=np.array([1, -1]))
+    want, idx = bt.Dedisperse(nh, 5., samples_per_frame=4096 - 1538)._response_columns()
+    assert np.array_equal(r1['resp'], want) and list(idx) == [0, 1]
+    # spans tile the frames; gather is in rank order
+    assert r0['span'][0] == 0 and r0['span'][1] == r1['span'][0]
+    assert np.array_equal(r0['gathered'], r1['gathered'])
+    assert r0['gathered'][:4, 0].tolist() == [0, 1, 2, 3]
+    assert r0['gathered'][4, 0] == r1['span'][0]
