@@ -15,6 +15,10 @@
 //                     over k1, writes only the valid samples)
 //   k_pfb           PolyphaseFilterBankSamples.ppf + Channelize.task
 //                   (reference pfb.py:91-100, channelize.py:73-74)
+//
+// Registers hold both streams of a pair packed across each other (c2, see
+// fft_core.hpp); the work buffer between the overlap-save passes is stored
+// in that order too (re_A re_B im_A im_B), external arrays are numpy order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fft_core.hpp"
@@ -31,9 +35,6 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
     return base + local;
 }
 
-__device__ __forceinline__ float4 ld4(const float2* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float2* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-
 // ---------------------------------------------------------------------------
 // Batched FFT over contiguous groups of N complete samples.
 //   in/out : (n_fft * N, S) complex64 ; pair index = blockIdx.y
@@ -45,31 +46,26 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
                                                            const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
     constexpr int T = G::T;
-    __shared__ cf lds[FPW * G::LDS_ELEMS];
+    __shared__ v2 lds[FPW * G::LDS_ELEMS];
     const int slot = threadIdx.x / T, tau = threadIdx.x % T;
     const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * FPW + slot;
     const int sp = blockIdx.y;
     const bool active = i < n_fft;
-    cf v[2][16];
+    c2 v[16];
     if (active) {
         const float2* src = in + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float4 x = ld4(src + (long long)T * j * S);
-            v[0][j] = make_float2(x.x, x.y);
-            v[1][j] = make_float2(x.z, x.w);
-        }
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[0][j] = v[1][j] = make_float2(0.f, 0.f);
+        for (int j = 0; j < 16; ++j) v[j] = czero();
     }
-    wg_fft<N, SIGN, 2, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
     if (active) {
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            st4(dst + (long long)T * j * S, make_float4(v[0][j].x * scale, v[0][j].y * scale,
-                                                        v[1][j].x * scale, v[1][j].y * scale));
+            st_ext(dst + (long long)T * j * S, c2{v[j].re * scale, v[j].im * scale});
     }
 }
 
@@ -87,11 +83,13 @@ struct OsmChunk {
     OsmBlock b[BBT_MAX_CHUNK];
 };
 
-// Response multiply for a stream pair: H laid out [C][N1][N2] (k = k1 + N1 k2),
-// already scaled by 1/N.
-struct RespSel {
-    int c0, c1;  // response column used by stream 2*sp and 2*sp+1
-};
+// Response (chirp) of the two streams of pair sp at natural index `idx` of
+// row/column base pointers h0, h1 (already scaled by 1/N).
+__device__ __forceinline__ c2 apply_resp(c2 a, const cf* h0, const cf* h1, bool same, int idx) {
+    if (same) return twmul<-1>(a, h0[idx]);
+    const cf x = h0[idx], y = h1[idx];
+    return cmul2(a, c2{v2{x.x, y.x}, v2{x.y, y.y}});
+}
 
 // Single-kernel path, N <= 4096: one workgroup per (block, pair).
 template <int N>
@@ -103,37 +101,28 @@ __global__ __launch_bounds__(N / 16) void k_osm_small(const float2* __restrict__
                                                        const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
     constexpr int T = G::T;
-    __shared__ cf lds[G::LDS_ELEMS];
+    __shared__ v2 lds[G::LDS_ELEMS];
     const int tau = threadIdx.x, sp = blockIdx.y;
     const OsmBlock blk = ch.b[blockIdx.x];
-    cf v[2][16];
+    c2 v[16];
     const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float4 x = ld4(src + (long long)T * j * S);
-        v[0][j] = make_float2(x.x, x.y);
-        v[1][j] = make_float2(x.z, x.w);
-    }
-    wg_fft<N, -1, 2, false>(v, lds, tau, 0, tw0, tw1);
-    const cf* h0 = resp + (long long)resp_index[2 * sp] * N + tau;
-    const cf* h1 = resp + (long long)resp_index[2 * sp + 1] * N + tau;
+    for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
+    wg_fft<N, -1, false>(v, lds, tau, 0, tw0, tw1);
+    const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
+    const cf* h0 = resp + (long long)c0 * N + tau;
+    const cf* h1 = resp + (long long)c1 * N + tau;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = apply_resp(v[j], h0, h1, c0 == c1, T * j);
+    wg_fft<N, +1, false>(v, lds, tau, 0, tw0, tw1);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        v[0][j] = cmul(v[0][j], h0[T * j]);
-        v[1][j] = cmul(v[1][j], h1[T * j]);
-    }
-    wg_fft<N, +1, 2, false>(v, lds, tau, 0, tw0, tw1);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int n = tau + T * j;
-        const int r = n - blk.valid_start;
-        if (r >= 0 && r < blk.valid_count)
-            st4(out + ((blk.out_off + r) * S + 2 * sp),
-                make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+        const int r = tau + T * j - blk.valid_start;
+        if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
     }
 }
 
-// Column pass, N1 == 16: one thread per float4 column, radix-16 in registers.
+// Column pass, N1 == 16: one thread per 2-stream column, radix-16 in registers.
 //   FIRST: stream -> work (forward).  !FIRST: work -> valid output (inverse).
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in,
@@ -144,82 +133,57 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
     const OsmBlock blk = ch.b[b];
     float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
-    cf v[2][16];
+    c2 v[16];
     if (FIRST) {
         const float2* src = in + ((blk.in_off + n2) * S + 2 * sp);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float4 x = ld4(src + (long long)j * N2 * S);
-            v[0][j] = make_float2(x.x, x.y);
-            v[1][j] = make_float2(x.z, x.w);
-        }
-        radix16<-1>(v[0]);
-        radix16<-1>(v[1]);
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)j * N2 * S);
+        radix16<-1>(v);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            st4(w + (long long)j * N2 * 2, make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+        for (int j = 0; j < 16; ++j) st_int(w + (long long)j * N2 * 2, v[j]);
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float4 x = ld4(w + (long long)j * N2 * 2);
-            v[0][j] = make_float2(x.x, x.y);
-            v[1][j] = make_float2(x.z, x.w);
-        }
-        radix16<+1>(v[0]);
-        radix16<+1>(v[1]);
+        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)j * N2 * 2);
+        radix16<+1>(v);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int r = j * N2 + n2 - blk.valid_start;
-            if (r >= 0 && r < blk.valid_count)
-                st4(out + ((blk.out_off + r) * S + 2 * sp),
-                    make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+            if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
         }
     }
 }
 
-// Column pass, N1 == 256: 256 threads = 16 float4 columns (f, fastest lane
-// index -> 256-byte runs per row) x 16 threads per 256-point transform.
+// Column pass, N1 == 256: 256 threads = 16 two-stream columns (f, fastest
+// lane index -> 256-byte runs per row) x 16 threads per 256-point transform.
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ in,
                                                     float2* __restrict__ out,
                                                     float2* __restrict__ work, OsmChunk ch, int S,
                                                     int N2, const cf* __restrict__ tw0) {
     typedef FftGeo<256> G;
-    __shared__ cf lds[G::LDS_ELEMS * 16];
+    __shared__ v2 lds[G::LDS_ELEMS * 16];
     const int f = threadIdx.x & 15, tau = threadIdx.x >> 4;
     const int n2 = xcd_remap(blockIdx.x, gridDim.x) * 16 + f;
     const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
     const OsmBlock blk = ch.b[b];
-    // work element (k1, n2) of this (block, pair): float4 at ((b*npair+sp)*256 + k1)*N2 + n2
+    // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*256 + k1)*N2 + n2
     float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
-    cf v[2][16];
+    c2 v[16];
     if (FIRST) {
         const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float4 x = ld4(src + (long long)16 * j * N2 * S);
-            v[0][j] = make_float2(x.x, x.y);
-            v[1][j] = make_float2(x.z, x.w);
-        }
-        wg_fft<256, -1, 2, true>(v, lds, tau, f, tw0, nullptr);
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)16 * j * N2 * S);
+        wg_fft<256, -1, true>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            st4(w + (long long)16 * j * N2 * 2,
-                make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+        for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float4 x = ld4(w + (long long)16 * j * N2 * 2);
-            v[0][j] = make_float2(x.x, x.y);
-            v[1][j] = make_float2(x.z, x.w);
-        }
-        wg_fft<256, +1, 2, true>(v, lds, tau, f, tw0, nullptr);
+        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+        wg_fft<256, +1, true>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
-            if (r >= 0 && r < blk.valid_count)
-                st4(out + ((blk.out_off + r) * S + 2 * sp),
-                    make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+            if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
         }
     }
 }
@@ -236,18 +200,14 @@ __global__ __launch_bounds__(N2 / 16) void k_osm_rowpass(float2* __restrict__ wo
                                                          const cf* __restrict__ wroot) {
     typedef FftGeo<N2> G;
     constexpr int T = G::T;
-    __shared__ cf lds[G::LDS_ELEMS];
+    __shared__ v2 lds[G::LDS_ELEMS];
     const int tau = threadIdx.x;
     const int k1 = blockIdx.x;
     const int sp = blockIdx.y % npair;
     float2* row = work + (((long long)blockIdx.y * N1 + k1) * N2 + tau) * 2;
-    cf v[2][16];
+    c2 v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float4 x = ld4(row + (long long)T * j * 2);
-        v[0][j] = make_float2(x.x, x.y);
-        v[1][j] = make_float2(x.z, x.w);
-    }
+    for (int j = 0; j < 16; ++j) v[j] = ld_int(row + (long long)T * j * 2);
     // W_N^{k1 (tau + T j)} = W_N^{k1 tau} * W_{16 N1}^{k1 j},  N = N1 * N2
     cf base;
     {
@@ -260,44 +220,25 @@ __global__ __launch_bounds__(N2 / 16) void k_osm_rowpass(float2* __restrict__ wo
     const int rstride = 4096 / M;
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const cf wj = cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]);
-            v[0][j] = cmul(v[0][j], wj);
-            v[1][j] = cmul(v[1][j], wj);
-        }
+        for (int j = 0; j < 16; ++j)
+            v[j] = twmul<-1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
     }
-    wg_fft<N2, -1, 2, false>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, -1, false>(v, lds, tau, 0, tw0, tw1);
     {
         const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
         const cf* h0 = resp + ((long long)c0 * N1 + k1) * N2 + tau;
-        if (c0 == c1) {
+        const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2 + tau;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const cf h = h0[T * j];
-                v[0][j] = cmul(v[0][j], h);
-                v[1][j] = cmul(v[1][j], h);
-            }
-        } else {
-            const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2 + tau;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                v[0][j] = cmul(v[0][j], h0[T * j]);
-                v[1][j] = cmul(v[1][j], h1[T * j]);
-            }
-        }
+        for (int j = 0; j < 16; ++j) v[j] = apply_resp(v[j], h0, h1, c0 == c1, T * j);
     }
-    wg_fft<N2, +1, 2, false>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, +1, false>(v, lds, tau, 0, tw0, tw1);
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const cf wj = cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]);
-            v[0][j] = cmulc(v[0][j], wj);
-            v[1][j] = cmulc(v[1][j], wj);
-        }
+        for (int j = 0; j < 16; ++j)
+            v[j] = twmul<+1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-        st4(row + (long long)T * j * 2, make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+    for (int j = 0; j < 16; ++j) st_int(row + (long long)T * j * 2, v[j]);
 }
 
 // Response H[c][k] (natural FFT order) -> Hperm[c][k1][k2] * scale, k = k1 + N1 k2.
@@ -325,14 +266,14 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
                                                       const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
     constexpr int T = G::T;
-    __shared__ cf lds[FPW * G::LDS_ELEMS];
+    __shared__ v2 lds[FPW * G::LDS_ELEMS];
     const int slot = threadIdx.x / T, tau = threadIdx.x % T;
     const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * FPW + slot;
     const int sp = blockIdx.y;
     const bool active = i < n_spec;
-    cf v[2][16];
+    c2 v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[0][j] = v[1][j] = make_float2(0.f, 0.f);
+    for (int j = 0; j < 16; ++j) v[j] = czero();
     if (active) {
         const float2* src = in + ((i * N + tau) * S + 2 * sp);
         for (int t = 0; t < n_tap; ++t) {
@@ -340,22 +281,18 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
             const float2* st = src + (long long)t * N * S;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float4 x = ld4(st + (long long)T * j * S);
+                const c2 x = ld_ext(st + (long long)T * j * S);
                 const float h = ht[T * j];
-                v[0][j].x = fmaf(x.x, h, v[0][j].x);
-                v[0][j].y = fmaf(x.y, h, v[0][j].y);
-                v[1][j].x = fmaf(x.z, h, v[1][j].x);
-                v[1][j].y = fmaf(x.w, h, v[1][j].y);
+                v[j].re += x.re * h;
+                v[j].im += x.im * h;
             }
         }
     }
-    wg_fft<N, -1, 2, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    wg_fft<N, -1, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
     if (active) {
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            st4(dst + (long long)T * j * S,
-                make_float4(v[0][j].x, v[0][j].y, v[1][j].x, v[1][j].y));
+        for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, v[j]);
     }
 }
 

@@ -17,50 +17,68 @@
 // The LDS address maps (pitches chosen so every ds_read_b64 / ds_write_b64 is
 // bank-conflict free) are modelled and checked in tools/fft_model.py.
 //
-// No MFMA: this is butterfly arithmetic at ~6 flop/byte of on-chip data, the
-// kernels built on it are HBM-bound.
+// Register format: the two streams of a pair (the two polarisations) are
+// packed ACROSS each other, c2 = {(re_A, re_B), (im_A, im_B)}, so every
+// butterfly add / twiddle multiply is one v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32 on an aligned register pair and the +-i rotations are pure
+// register renaming.  (Packing (re, im) of one stream instead costs a v_mov
+// shuffle for every rotation and cross term: 29 % of the VALU stream.)  The
+// kernels are VALU-issue-bound per wave before they are HBM-bound, so
+// instruction count is what matters.
+//
+// No MFMA: this is butterfly arithmetic at ~6 flop/byte of on-chip data
+// (DESIGN.md).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace bbt {
 
-typedef float2 cf;
+typedef float2 cf;                                        // one complex number (tables)
+typedef float v2 __attribute__((ext_vector_type(2)));     // the same component of streams A, B
+struct c2 {                                               // one complex number per stream
+    v2 re, im;
+};
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c2 cadd(c2 a, c2 b) { return c2{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c2 csub(c2 a, c2 b) { return c2{a.re - b.re, a.im - b.im}; }
+// both streams times the same complex scalar w (tables hold forward twiddles
+// exp(-2 pi i ...); SIGN > 0 multiplies by the conjugate)
+template <int SIGN>
+__device__ __forceinline__ c2 twmul(c2 a, cf w) {
+    if (SIGN < 0) return c2{a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x};
+    return c2{a.re * w.x + a.im * w.y, a.im * w.x - a.re * w.y};
+}
+// per-stream complex multiply
+__device__ __forceinline__ c2 cmul2(c2 a, c2 h) {
+    return c2{a.re * h.re - a.im * h.im, a.re * h.im + a.im * h.re};
+}
 __device__ __forceinline__ cf cmul(cf a, cf b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-// a * conj(b)
-__device__ __forceinline__ cf cmulc(cf a, cf b) {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-// Tables hold forward twiddles exp(-2 pi i ...); SIGN>0 uses the conjugate.
-template <int SIGN>
-__device__ __forceinline__ cf twmul(cf a, cf w) {
-    return SIGN < 0 ? cmul(a, w) : cmulc(a, w);
-}
-// multiply by -i (SIGN<0) or +i (SIGN>0)
-template <int SIGN>
-__device__ __forceinline__ cf mul_mi(cf a) {
-    return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
-}
+__device__ __forceinline__ c2 splat(cf w) { return c2{v2{w.x, w.x}, v2{w.y, w.y}}; }
+__device__ __forceinline__ c2 czero() { return c2{v2{0.f, 0.f}, v2{0.f, 0.f}}; }
 
 template <int SIGN>
-__device__ __forceinline__ void radix2(cf& a, cf& b) {
-    cf t = a;
+__device__ __forceinline__ void radix2(c2& a, c2& b) {
+    c2 t = a;
     a = cadd(t, b);
     b = csub(t, b);
 }
 
-// (a,b,c,d) -> (X0,X1,X2,X3)
+// (a,b,c,d) -> (X0,X1,X2,X3); the -i / +i rotation of (b - d) is folded into
+// the signs of the last four adds.
 template <int SIGN>
-__device__ __forceinline__ void radix4(cf& a, cf& b, cf& c, cf& d) {
-    cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = mul_mi<SIGN>(csub(b, d));
+__device__ __forceinline__ void radix4(c2& a, c2& b, c2& c, c2& d) {
+    const c2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), u = csub(b, d);
     a = cadd(t0, t2);
     c = csub(t0, t2);
-    b = cadd(t1, t3);
-    d = csub(t1, t3);
+    if (SIGN < 0) {
+        b = c2{t1.re + u.im, t1.im - u.re};
+        d = c2{t1.re - u.im, t1.im + u.re};
+    } else {
+        b = c2{t1.re - u.im, t1.im + u.re};
+        d = c2{t1.re + u.im, t1.im - u.re};
+    }
 }
 
 #define BBT_C8 0.70710678118654752440f
@@ -69,26 +87,23 @@ __device__ __forceinline__ void radix4(cf& a, cf& b, cf& c, cf& d) {
 
 // multiply by W_16^K (forward) or its conjugate
 template <int SIGN, int K>
-__device__ __forceinline__ cf mulw16(cf a) {
+__device__ __forceinline__ c2 mulw16(c2 a) {
     constexpr int k = K & 15;
     if constexpr (k == 0) return a;
-    else if constexpr (k == 4) return mul_mi<SIGN>(a);
-    else if constexpr (k == 8) return make_float2(-a.x, -a.y);
-    else if constexpr (k == 12) return mul_mi<-SIGN>(a);
+    else if constexpr (k == 4) return SIGN < 0 ? c2{a.im, -a.re} : c2{-a.im, a.re};
+    else if constexpr (k == 8) return c2{-a.re, -a.im};
+    else if constexpr (k == 12) return SIGN < 0 ? c2{-a.im, a.re} : c2{a.im, -a.re};
     else {
-        // generic constant twiddle
         constexpr float cr[16] = {1.f, BBT_C16, BBT_C8, BBT_S16, 0.f, -BBT_S16, -BBT_C8, -BBT_C16,
                                   -1.f, -BBT_C16, -BBT_C8, -BBT_S16, 0.f, BBT_S16, BBT_C8, BBT_C16};
         // forward W = cos - i sin ; sin(2 pi k/16) = cr[(k+12)&15]
-        constexpr float wr = cr[k];
-        constexpr float wi = -cr[(k + 12) & 15];
-        return twmul<SIGN>(a, make_float2(wr, wi));
+        return twmul<SIGN>(a, make_float2(cr[k], -cr[(k + 12) & 15]));
     }
 }
 
-// In-place radix-8, natural order out.  v[q + 4p] = sum_a v[a] W8^{a (q+4p)}
+// In-place radix-8, natural order out.
 template <int SIGN>
-__device__ __forceinline__ void radix8(cf (&v)[8]) {
+__device__ __forceinline__ void radix8(c2 (&v)[8]) {
     radix4<SIGN>(v[0], v[2], v[4], v[6]);  // r=0: t[0][q] at v[2q]
     radix4<SIGN>(v[1], v[3], v[5], v[7]);  // r=1: t[1][q] at v[1+2q]
     v[3] = mulw16<SIGN, 2>(v[3]);          // W8^1
@@ -98,14 +113,13 @@ __device__ __forceinline__ void radix8(cf (&v)[8]) {
     radix2<SIGN>(v[2], v[3]);              // X[1], X[5]
     radix2<SIGN>(v[4], v[5]);              // X[2], X[6]
     radix2<SIGN>(v[6], v[7]);              // X[3], X[7]
-    // v[2q+p] = X[q+4p]  -> natural
-    cf x1 = v[2], x2 = v[4], x3 = v[6], x4 = v[1], x5 = v[3], x6 = v[5];
+    const c2 x1 = v[2], x2 = v[4], x3 = v[6], x4 = v[1], x5 = v[3], x6 = v[5];
     v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
 }
 
 // In-place radix-16, natural order out.
 template <int SIGN>
-__device__ __forceinline__ void radix16(cf (&v)[16]) {
+__device__ __forceinline__ void radix16(c2 (&v)[16]) {
     // a = r + 4 s ; c = q + 4 p
     radix4<SIGN>(v[0], v[4], v[8], v[12]);   // t[0][q] at v[0+4q]
     radix4<SIGN>(v[1], v[5], v[9], v[13]);
@@ -126,8 +140,8 @@ __device__ __forceinline__ void radix16(cf (&v)[16]) {
     radix4<SIGN>(v[4], v[5], v[6], v[7]);
     radix4<SIGN>(v[8], v[9], v[10], v[11]);
     radix4<SIGN>(v[12], v[13], v[14], v[15]);
-    // transpose 4x4 to natural order
-    cf t;
+    // transpose 4x4 to natural order (register renaming)
+    c2 t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[2]; v[2] = v[8]; v[8] = t;
     t = v[3]; v[3] = v[12]; v[12] = t;
@@ -137,7 +151,7 @@ __device__ __forceinline__ void radix16(cf (&v)[16]) {
 }
 
 template <int SIGN, int R>
-__device__ __forceinline__ void radixR(cf (&v)[R]) {
+__device__ __forceinline__ void radixR(c2 (&v)[R]) {
     if constexpr (R == 2) radix2<SIGN>(v[0], v[1]);
     else if constexpr (R == 4) radix4<SIGN>(v[0], v[1], v[2], v[3]);
     else if constexpr (R == 8) radix8<SIGN>(v);
@@ -160,11 +174,8 @@ struct FftGeo {
         return p;
     }
     static constexpr int PC1 = pc1();
+    // exchange area in 8-byte elements (one v2 per point and component)
     static constexpr int LDS_ELEMS = (16 * PAD0 > 16 * PC1) ? 16 * PAD0 : 16 * PC1;
-    // twiddle tables (device, cf): tw0[c0 * T + tau] = W_N^{tau c0};
-    //                              tw1[c1 * R2 + b1] = W_T^{b1 c1}
-    static constexpr int TW0_ELEMS = 16 * T;
-    static constexpr int TW1_ELEMS = 16 * R2;
 };
 
 // LDS placement of one transform's exchange area.
@@ -175,14 +186,16 @@ __device__ __forceinline__ int lds_idx(int inner, int f) {
     return COLMODE ? inner * 16 + f : inner;
 }
 
-// One workgroup-cooperative FFT over NPL register planes.
-//   v[p][j] : plane p, element tau + T*j of this thread's transform
-//   lds     : exchange area (LDS_ELEMS cf per transform; x16 in COLMODE)
-//   tau     : thread index within the transform (0..T-1)
-//   f       : transform lane within a COLMODE group (0..15), ignored otherwise
+// One workgroup-cooperative FFT of both streams of a pair.
+//   v[j]  : element tau + T*j of this thread's transform (both streams)
+//   lds   : exchange area, LDS_ELEMS v2 per transform (x16 in COLMODE); the
+//           real and the imaginary pairs go through it one after the other
+//   tau   : thread index within the transform (0..T-1)
+//   f     : transform lane within a COLMODE group (0..15), ignored otherwise
+//   tw0   : [16][T] forward twiddles W_N^{tau c0};  tw1: [16][R2] W_T^{b1 c1}
 // All threads of the workgroup must call this together (it uses __syncthreads).
-template <int N, int SIGN, int NPL, bool COLMODE>
-__device__ __forceinline__ void wg_fft(cf (&v)[NPL][16], cf* __restrict__ lds, int tau, int f,
+template <int N, int SIGN, bool COLMODE>
+__device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                        const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
     constexpr int R2 = G::R2, T = G::T;
@@ -190,57 +203,76 @@ __device__ __forceinline__ void wg_fft(cf (&v)[NPL][16], cf* __restrict__ lds, i
     const int b1 = tau % R2;
 
     // ---- stage 0
+    radix16<SIGN>(v);
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) radix16<SIGN>(v[p]);
+    for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], tw0[c * T + tau]);
+    // ---- exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
+    __syncthreads();
 #pragma unroll
-    for (int c = 1; c < 16; ++c) {
-        cf w = tw0[c * T + tau];
+    for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].re;
+    __syncthreads();
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) v[p][c] = twmul<SIGN>(v[p][c], w);
-    }
-    // ---- exchange 0
+    for (int a = 0; a < 16; ++a) v[a].re = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
+    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-        __syncthreads();
+    for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
+    __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[p][c];
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 16; ++a) v[p][a] = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
-    }
+    for (int a = 0; a < 16; ++a) v[a].im = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
     // ---- stage 1
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) radix16<SIGN>(v[p]);
+    radix16<SIGN>(v);
     if constexpr (R2 > 1) {
 #pragma unroll
-        for (int c = 1; c < 16; ++c) {
-            cf w = tw1[c * R2 + b1];
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) v[p][c] = twmul<SIGN>(v[p][c], w);
-        }
-        // ---- exchange 1 + stage 2
+        for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], tw1[c * R2 + b1]);
+        // ---- exchange 1: (c0, c1, b1) -> thread (c0 + 16 g), c1 = g + R2 u ; then stage 2
         constexpr int NU = 16 / R2;
         const int c0r = tau & 15;
         const int g = tau >> 4;
+        c2 t[NU][R2];
+        __syncthreads();
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-            __syncthreads();
+        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].re;
+        __syncthreads();
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[p][c];
-            __syncthreads();
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                cf t[R2];
+            for (int bb = 0; bb < R2; ++bb)
+                t[u][bb].re = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
+        __syncthreads();
 #pragma unroll
-                for (int bb = 0; bb < R2; ++bb)
-                    t[bb] = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
-                radixR<SIGN, R2>(t);
+        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
+        __syncthreads();
 #pragma unroll
-                for (int c2 = 0; c2 < R2; ++c2) v[p][u + NU * c2] = t[c2];
-            }
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int bb = 0; bb < R2; ++bb)
+                t[u][bb].im = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            radixR<SIGN, R2>(t[u]);
+#pragma unroll
+            for (int c2i = 0; c2i < R2; ++c2i) v[u + NU * c2i] = t[u][c2i];
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Memory formats of one complete 2-stream sample (16 bytes):
+//   external (numpy complex64 (n, 2)):   re_A im_A re_B im_B
+//   internal (work buffers):             re_A re_B im_A im_B   (= c2 as stored)
+__device__ __forceinline__ c2 ld_ext(const float2* p) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    return c2{v2{x.x, x.z}, v2{x.y, x.w}};
+}
+__device__ __forceinline__ void st_ext(float2* p, c2 a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.re.x, a.im.x, a.re.y, a.im.y);
+}
+__device__ __forceinline__ c2 ld_int(const float2* p) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    return c2{v2{x.x, x.y}, v2{x.z, x.w}};
+}
+__device__ __forceinline__ void st_int(float2* p, c2 a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.re.x, a.re.y, a.im.x, a.im.y);
 }
 
 }  // namespace bbt

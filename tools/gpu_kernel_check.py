@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = C.CDLL(os.path.join(HERE, '..', 'baseband-tasks_amd', 'lib', 'libbbt_hip.so'))
+LIB = C.CDLL(os.environ.get('BBT_LIB') or os.path.join(HERE, '..', 'baseband-tasks_amd', 'lib', 'libbbt_hip.so'))
 LIB.bbt_last_error.restype = C.c_char_p
 
 
@@ -157,6 +157,10 @@ def check_pfb(n, S, ntap, nspec, rng):
 
 def main():
     big = '--big' in sys.argv
+    if '--perf' in sys.argv:
+        rng = np.random.default_rng(7)
+        check_osm(1 << 20, 2, 32, rng, timing=True)
+        return
     name = C.create_string_buffer(256)
     chk(LIB.bbt_device_name(name, 256))
     print("device:", name.value.decode())
