@@ -83,12 +83,23 @@ struct OsmChunk {
     OsmBlock b[BBT_MAX_CHUNK];
 };
 
-// Response (chirp) of the two streams of pair sp at natural index `idx` of
-// row/column base pointers h0, h1 (already scaled by 1/N).
-__device__ __forceinline__ c2 apply_resp(c2 a, const cf* h0, const cf* h1, bool same, int idx) {
-    if (same) return twmul<-1>(a, h0[idx]);
-    const cf x = h0[idx], y = h1[idx];
-    return cmul2(a, c2{v2{x.x, y.x}, v2{x.y, y.y}});
+// Multiply by the response (chirp), already scaled by 1/N: element j of this
+// thread is at h[STRIDE * j].  The "same column for both streams" test is
+// hoisted out of the loop (a per-element runtime select makes hipcc branch
+// around every load).
+template <int STRIDE>
+__device__ __forceinline__ void apply_resp(c2 (&v)[16], const cf* __restrict__ h0,
+                                           const cf* __restrict__ h1, bool same) {
+    if (same) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], h0[STRIDE * j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const cf x = h0[STRIDE * j], y = h1[STRIDE * j];
+            v[j] = cmul2(v[j], c2{v2{x.x, y.x}, v2{x.y, y.y}});
+        }
+    }
 }
 
 // Single-kernel path, N <= 4096: one workgroup per (block, pair).
@@ -112,8 +123,7 @@ __global__ __launch_bounds__(N / 16) void k_osm_small(const float2* __restrict__
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (long long)c0 * N + tau;
     const cf* h1 = resp + (long long)c1 * N + tau;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = apply_resp(v[j], h0, h1, c0 == c1, T * j);
+    apply_resp<T>(v, h0, h1, c0 == c1);
     wg_fft<N, +1, false>(v, lds, tau, 0, tw0, tw1);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -191,8 +201,14 @@ __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ i
 // Row pass: for row k1 of a (block, pair): four-step twiddle, forward FFT
 // over n2, multiply by the response, inverse FFT over k2, conjugate twiddle.
 //   wroot : W_4096^m, m in [0, 4096)
+#ifndef BBT_ROWPASS_TWO_REGIONS
+#define BBT_ROWPASS_TWO_REGIONS 0
+#endif
+#ifndef BBT_ROWPASS_MINWAVES
+#define BBT_ROWPASS_MINWAVES 1
+#endif
 template <int N2>
-__global__ __launch_bounds__(N2 / 16) void k_osm_rowpass(float2* __restrict__ work, int N1,
+__global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(float2* __restrict__ work, int N1,
                                                          const cf* __restrict__ resp,
                                                          const int* __restrict__ resp_index,
                                                          int npair, const cf* __restrict__ tw0,
@@ -200,7 +216,8 @@ __global__ __launch_bounds__(N2 / 16) void k_osm_rowpass(float2* __restrict__ wo
                                                          const cf* __restrict__ wroot) {
     typedef FftGeo<N2> G;
     constexpr int T = G::T;
-    __shared__ v2 lds[G::LDS_ELEMS];
+    constexpr int IMOFF = BBT_ROWPASS_TWO_REGIONS ? G::LDS_ELEMS : 0;
+    __shared__ v2 lds[G::LDS_ELEMS + IMOFF];
     const int tau = threadIdx.x;
     const int k1 = blockIdx.x;
     const int sp = blockIdx.y % npair;
@@ -220,22 +237,23 @@ __global__ __launch_bounds__(N2 / 16) void k_osm_rowpass(float2* __restrict__ wo
     const int rstride = 4096 / M;
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < 16; ++j) {
             v[j] = twmul<-1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
+        }
     }
-    wg_fft<N2, -1, false>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, -1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
     {
         const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
         const cf* h0 = resp + ((long long)c0 * N1 + k1) * N2 + tau;
         const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2 + tau;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = apply_resp(v[j], h0, h1, c0 == c1, T * j);
+        apply_resp<T>(v, h0, h1, c0 == c1);
     }
-    wg_fft<N2, +1, false>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, +1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < 16; ++j) {
             v[j] = twmul<+1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
+        }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) st_int(row + (long long)T * j * 2, v[j]);

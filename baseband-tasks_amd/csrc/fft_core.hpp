@@ -188,19 +188,22 @@ __device__ __forceinline__ int lds_idx(int inner, int f) {
 
 // One workgroup-cooperative FFT of both streams of a pair.
 //   v[j]  : element tau + T*j of this thread's transform (both streams)
-//   lds   : exchange area, LDS_ELEMS v2 per transform (x16 in COLMODE); the
-//           real and the imaginary pairs go through it one after the other
+//   lds   : exchange area, LDS_ELEMS v2 per transform (x16 in COLMODE).
+//           IMOFF == 0: the real and the imaginary pairs go through it one
+//           after the other (4 barriers per exchange); IMOFF > 0: the
+//           imaginary pairs use lds + IMOFF (2 barriers, twice the LDS).
 //   tau   : thread index within the transform (0..T-1)
 //   f     : transform lane within a COLMODE group (0..15), ignored otherwise
 //   tw0   : [16][T] forward twiddles W_N^{tau c0};  tw1: [16][R2] W_T^{b1 c1}
 // All threads of the workgroup must call this together (it uses __syncthreads).
-template <int N, int SIGN, bool COLMODE>
+template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
 __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                        const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
     constexpr int R2 = G::R2, T = G::T;
     const int c0s = tau / R2;  // stage-1 role
     const int b1 = tau % R2;
+    v2* __restrict__ lds_im = lds + IMOFF;
 
     // ---- stage 0
     radix16<SIGN>(v);
@@ -210,15 +213,21 @@ __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int ta
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].re;
+    if (IMOFF) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lds_im[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
+    }
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a].re = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
-    __syncthreads();
+    if (!IMOFF) {
+        __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
-    __syncthreads();
+        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
+        __syncthreads();
+    }
 #pragma unroll
-    for (int a = 0; a < 16; ++a) v[a].im = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
+    for (int a = 0; a < 16; ++a) v[a].im = lds_im[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
     // ---- stage 1
     radix16<SIGN>(v);
     if constexpr (R2 > 1) {
@@ -232,21 +241,29 @@ __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int ta
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].re;
+        if (IMOFF) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                lds_im[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int bb = 0; bb < R2; ++bb)
                 t[u][bb].re = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
-        __syncthreads();
+        if (!IMOFF) {
+            __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
-        __syncthreads();
+            for (int c = 0; c < 16; ++c)
+                lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int bb = 0; bb < R2; ++bb)
-                t[u][bb].im = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
+                t[u][bb].im = lds_im[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             radixR<SIGN, R2>(t[u]);
