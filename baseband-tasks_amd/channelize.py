@@ -1,6 +1,7 @@
 """Block-FFT channelizer and its inverse on the GPU (reference
 baseband_tasks/channelize.py:12-178)."""
 import operator
+import os
 
 import numpy as np
 
@@ -9,7 +10,14 @@ from .base import TaskBase, getattr_if_none, _stream_rate
 from .device_task import DeviceTaskMixin, fetch_device
 from .fourier import MIN_FFT_LEN, MAX_WG_FFT_LEN
 
-__all__ = ['Channelize', 'Dechannelize']
+__all__ = ['Channelize', 'Dechannelize', 'FUSE_WITH_OVERLAP_SAVE']
+
+#: When the input of a `Channelize` is a GPU overlap-save task (`Dedisperse`,
+#: `Disperse`, `Convolve`, `Resample`) the channelizer FFT is folded into that
+#: task's row pass (libbbt_hip: bbt_osm_execute_channelized) and the
+#: intermediate stream never exists in memory.  Results are the same to
+#: rounding; set to False (or BBT_FUSE=0) to run the two tasks separately.
+FUSE_WITH_OVERLAP_SAVE = os.environ.get('BBT_FUSE', '1') != '0'
 
 
 def _prod(shape):
@@ -94,12 +102,36 @@ class Channelize(_RowFFTTask):
                          samples_per_frame=samples_per_frame, frequency=frequency,
                          sideband=sideband, dtype=np.complex64)
 
+    def _fusable_input(self):
+        """The upstream overlap-save task if its row pass can take over the
+        channelizer FFT, else None."""
+        from .overlap_save import SpectralMultiplyTask
+        dd = self.ih
+        if not (FUSE_WITH_OVERLAP_SAVE and isinstance(dd, SpectralMultiplyTask)) or dd.closed:
+            return None
+        if dd._n_stream != dd._n_stream_even or dd.samples_per_frame < self._n:
+            return None
+        info = dd._get_plan().info()
+        if info['n1'] == 1 or self._n > info['n2'] or info['n2'] % self._n:
+            return None
+        return dd
+
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
         n_spectra = stop - start
-        x = fetch_device(self.ih, start * self._n, n_spectra * self._n)
-        x = x.reshape(n_spectra * self._n, self._n_stream)
-        self._run(x, n_spectra, out.reshape(n_spectra * self._n, self._n_stream))
+        n = self._n
+        flat = out.reshape(n_spectra * n, self._n_stream)
+        dd = self._fusable_input()
+        if dd is not None:
+            spf = dd.samples_per_frame
+            m0, m1 = (start * n) // spf, (stop * n - 1) // spf + 1
+            in0, in_len, starts, out_abs, keep, counts = dd._block_descriptors(m0, m1)
+            x = fetch_device(dd.ih, in0, in_len)
+            dd._get_plan().execute_channelized(x, flat, starts - in0, out_abs, keep, counts, n,
+                                               start, n_spectra)
+            return
+        x = fetch_device(self.ih, start * n, n_spectra * n)
+        self._run(x.reshape(n_spectra * n, self._n_stream), n_spectra, flat)
 
     def task(self, data):
         """Channelize one frame given on the host (reference channelize.py:73-74)."""

@@ -2,6 +2,7 @@
 // Plans, twiddle tables, launch geometry; the kernels are in bbt_kernels.hpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 100
+#define BBT_VERSION 101
 
 // ---------------------------------------------------------------------------
 // errors
@@ -248,6 +249,10 @@ struct bbt_osm_plan {
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     cf* wroot = nullptr;
+    // fused channelizer
+    float2* seam = nullptr;     // [blocks][2][npair][n_chan] float4
+    size_t seam_bytes = 0;
+
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // 4 per chunk launch: t0, tA, tB, tC
@@ -255,11 +260,28 @@ struct bbt_osm_plan {
     int64_t launches = 0;
 };
 
-template <int N2>
-static void launch_rowpass(bbt_osm_plan* p, int nblk, hipStream_t st) {
-    hipLaunchKernelGGL((k_osm_rowpass<N2>), dim3(p->n1, nblk * p->npair), dim3(N2 / 16), 0, st,
-                       p->work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
-                       p->wroot);
+template <int N2, int NCH>
+static void launch_rowpass_t(bbt_osm_plan* p, const OsmChunk& ch, hipStream_t st) {
+    hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>), dim3(p->n1, ch.nblk * p->npair), dim3(N2 / 16), 0,
+                       st, p->work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0,
+                       p->tab2.tw1, p->wroot, ch);
+}
+
+// (row length, channels) -> instantiation; nch == 0 is the plain row pass.
+static int launch_rowpass(bbt_osm_plan* p, const OsmChunk& ch, int nch, hipStream_t st) {
+#define BBT_RP(N2_, NCH_)                               \
+    if (p->n2 == N2_ && nch == NCH_) {                  \
+        launch_rowpass_t<N2_, NCH_>(p, ch, st);         \
+        return 0;                                       \
+    }
+    BBT_RP(256, 0) BBT_RP(512, 0) BBT_RP(1024, 0) BBT_RP(2048, 0) BBT_RP(4096, 0)
+    BBT_RP(256, 256)
+    BBT_RP(512, 256) BBT_RP(512, 512)
+    BBT_RP(1024, 256) BBT_RP(1024, 512) BBT_RP(1024, 1024)
+    BBT_RP(2048, 256) BBT_RP(2048, 512) BBT_RP(2048, 1024) BBT_RP(2048, 2048)
+    BBT_RP(4096, 256) BBT_RP(4096, 512) BBT_RP(4096, 1024) BBT_RP(4096, 2048) BBT_RP(4096, 4096)
+#undef BBT_RP
+    return fail("osm: no row pass for row length %d with %d channels", p->n2, nch);
 }
 
 template <int N>
@@ -285,7 +307,8 @@ static int osm_flush_timing(bbt_osm_plan* p) {
 }
 
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
-                         hipStream_t st) {
+                         const SpecOut& so, hipStream_t st) {
+    const int nch = so.n_chan;   // 0: plain overlap-save output
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (p->timing) {
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&e[i]));
@@ -305,28 +328,31 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             HIP_TRY(hipEventRecord(e[2], st));
         }
     } else {
+        const dim3 g16(p->n2 / 256, ch.nblk, p->npair), g256(p->n2 / 16, ch.nblk, p->npair);
         if (p->n1 == 16)
-            hipLaunchKernelGGL((k_osm_col16<true>), dim3(p->n2 / 256, ch.nblk, p->npair), dim3(256),
-                               0, st, in, out, p->work, ch, p->S, p->n2);
+            hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, p->work, ch,
+                               p->S, p->n2, so);
         else
-            hipLaunchKernelGGL((k_osm_col256<true>), dim3(p->n2 / 16, ch.nblk, p->npair), dim3(256),
-                               0, st, in, out, p->work, ch, p->S, p->n2, p->tab1.tw0);
+            hipLaunchKernelGGL((k_osm_col256<true, false>), g256, dim3(256), 0, st, in, out, p->work,
+                               ch, p->S, p->n2, p->tab1.tw0, so);
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        switch (p->n2) {
-            case 256: launch_rowpass<256>(p, ch.nblk, st); break;
-            case 512: launch_rowpass<512>(p, ch.nblk, st); break;
-            case 1024: launch_rowpass<1024>(p, ch.nblk, st); break;
-            case 2048: launch_rowpass<2048>(p, ch.nblk, st); break;
-            case 4096: launch_rowpass<4096>(p, ch.nblk, st); break;
-            default: return fail("osm: unsupported row length %d", p->n2);
-        }
+        if (launch_rowpass(p, ch, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
-        if (p->n1 == 16)
-            hipLaunchKernelGGL((k_osm_col16<false>), dim3(p->n2 / 256, ch.nblk, p->npair),
-                               dim3(256), 0, st, in, out, p->work, ch, p->S, p->n2);
-        else
-            hipLaunchKernelGGL((k_osm_col256<false>), dim3(p->n2 / 16, ch.nblk, p->npair),
-                               dim3(256), 0, st, in, out, p->work, ch, p->S, p->n2, p->tab1.tw0);
+        if (p->n1 == 16) {
+            if (nch)
+                hipLaunchKernelGGL((k_osm_col16<false, true>), g16, dim3(256), 0, st, in, out,
+                                   p->work, ch, p->S, p->n2, so);
+            else
+                hipLaunchKernelGGL((k_osm_col16<false, false>), g16, dim3(256), 0, st, in, out,
+                                   p->work, ch, p->S, p->n2, so);
+        } else {
+            if (nch)
+                hipLaunchKernelGGL((k_osm_col256<false, true>), g256, dim3(256), 0, st, in, out,
+                                   p->work, ch, p->S, p->n2, p->tab1.tw0, so);
+            else
+                hipLaunchKernelGGL((k_osm_col256<false, false>), g256, dim3(256), 0, st, in, out,
+                                   p->work, ch, p->S, p->n2, p->tab1.tw0, so);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (p->timing) {
@@ -335,6 +361,35 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         if (p->ev.size() >= 4096) return osm_flush_timing(p);
     }
     return 0;
+}
+
+static int osm_check_blocks(const bbt_osm_plan* p, const char* who, int64_t n_blocks,
+                            const int64_t* in_off, const int64_t* out_off,
+                            const int32_t* valid_start, const int32_t* valid_count) {
+    ARG_TRY(n_blocks >= 0, "%s: n_blocks=%lld < 0", who, (long long)n_blocks);
+    ARG_TRY(n_blocks == 0 || (in_off && out_off && valid_start && valid_count),
+            "%s: null descriptor array", who);
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        ARG_TRY(in_off[b] >= 0 && out_off[b] >= 0, "%s: negative offset in block %lld", who,
+                (long long)b);
+        ARG_TRY(valid_start[b] >= 0 && valid_count[b] >= 0 &&
+                    (int64_t)valid_start[b] + valid_count[b] <= p->n,
+                "%s: block %lld keeps [%d, %d) outside [0, %lld)", who, (long long)b,
+                valid_start[b], valid_start[b] + valid_count[b], (long long)p->n);
+    }
+    return 0;
+}
+
+template <int NCH>
+static void launch_seam_fix(bbt_osm_plan* p, float2* out, const std::vector<SeamJob>& jobs,
+                            const FftTables& tab, hipStream_t st) {
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += BBT_SEAM_JOBS_PER_LAUNCH) {
+        SeamJobs batch;
+        const size_t n = std::min(jobs.size() - j0, (size_t)BBT_SEAM_JOBS_PER_LAUNCH);
+        for (size_t i = 0; i < n; ++i) batch.j[i] = jobs[j0 + i];
+        hipLaunchKernelGGL((k_seam_fix<NCH>), dim3((unsigned)n, p->npair), dim3(NCH / 16), 0, st,
+                           p->seam, out, batch, p->S, p->npair, tab.tw0, tab.tw1);
+    }
 }
 
 extern "C" {
@@ -425,6 +480,7 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     if (p->resp) hipFree(p->resp);
     if (p->resp_index) hipFree(p->resp_index);
     if (p->work) hipFree(p->work);
+    if (p->seam) hipFree(p->seam);
     delete p;
     return 0;
 }
@@ -443,18 +499,10 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
                     const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
                     const int32_t* valid_count, bbt_stream stream) {
     ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute: null argument");
-    ARG_TRY(n_blocks >= 0, "bbt_osm_execute: n_blocks=%lld < 0", (long long)n_blocks);
-    ARG_TRY(n_blocks == 0 || (in_off && out_off && valid_start && valid_count),
-            "bbt_osm_execute: null descriptor array");
-    for (int64_t b = 0; b < n_blocks; ++b) {
-        ARG_TRY(in_off[b] >= 0 && out_off[b] >= 0, "bbt_osm_execute: negative offset in block %lld",
-                (long long)b);
-        ARG_TRY(valid_start[b] >= 0 && valid_count[b] >= 0 &&
-                    (int64_t)valid_start[b] + valid_count[b] <= p->n,
-                "bbt_osm_execute: block %lld keeps [%d, %d) outside [0, %lld)", (long long)b,
-                valid_start[b], valid_start[b] + valid_count[b], (long long)p->n);
-    }
+    if (osm_check_blocks(p, "bbt_osm_execute", n_blocks, in_off, out_off, valid_start, valid_count))
+        return 1;
     hipStream_t st = (hipStream_t)stream;
+    SpecOut so = {};
     for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk) {
         OsmChunk ch;
         ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
@@ -463,8 +511,91 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
             ch.b[i].out_off = out_off[b0 + i];
             ch.b[i].valid_start = valid_start[b0 + i];
             ch.b[i].valid_count = valid_count[b0 + i];
+            ch.b[i].shift = 0;
+            ch.b[i].index = (int)(b0 + i);
         }
-        if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, st)) return 1;
+        if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, st)) return 1;
+    }
+    return 0;
+}
+
+int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_dev,
+                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
+                                const int32_t* valid_start, const int32_t* valid_count, int n_chan,
+                                int64_t first_spectrum, int64_t n_spectra, bbt_stream stream) {
+    ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute_channelized: null argument");
+    ARG_TRY(p->n1 > 1, "bbt_osm_execute_channelized: block length %lld is too short to fuse",
+            (long long)p->n);
+    ARG_TRY(fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0,
+            "bbt_osm_execute_channelized: n_chan=%d must be a power of two in [256, %d]", n_chan,
+            p->n2);
+    ARG_TRY(first_spectrum >= 0 && n_spectra >= 0, "bbt_osm_execute_channelized: bad spectrum range");
+    if (osm_check_blocks(p, "bbt_osm_execute_channelized", n_blocks, in_off, out_off, valid_start,
+                         valid_count))
+        return 1;
+    for (int64_t b = 0; b < n_blocks; ++b)
+        ARG_TRY(valid_count[b] >= n_chan,
+                "bbt_osm_execute_channelized: block %lld keeps %d samples < n_chan", (long long)b,
+                valid_count[b]);
+    if (n_blocks == 0 || n_spectra == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    FftTables tabc;
+    if (get_tables(n_chan, &tabc)) return 1;
+    // seam slots and jobs
+    const size_t need = (size_t)n_blocks * 2 * p->npair * n_chan * 16;
+    if (need > p->seam_bytes) {
+        if (p->seam) HIP_TRY(hipFree(p->seam));
+        p->seam = nullptr;
+        p->seam_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&p->seam, need));
+        p->seam_bytes = need;
+    }
+    std::vector<SeamJob> jobs;
+    for (int64_t b = 0; b + 1 < n_blocks; ++b) {
+        const int64_t seam_pos = out_off[b] + valid_count[b];
+        if (out_off[b + 1] != seam_pos || seam_pos % n_chan == 0) continue;   // not adjacent / aligned
+        const int64_t s = seam_pos / n_chan;
+        if (s < first_spectrum || s >= first_spectrum + n_spectra) continue;
+        SeamJob j;
+        j.spectrum = s - first_spectrum;
+        j.first_block = (int)b;
+        j.split = (int)(seam_pos - s * n_chan);
+        jobs.push_back(j);
+    }
+    SpecOut so;
+    so.seam = p->seam;
+    so.s_base = first_spectrum;
+    so.n_out = n_spectra;
+    so.n_chan = n_chan;
+    so.lg_chan = 0;
+    while ((1 << so.lg_chan) < n_chan) ++so.lg_chan;
+    so.n_fft = (int)p->n;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk) {
+        OsmChunk ch;
+        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
+        for (int i = 0; i < ch.nblk; ++i) {
+            const int64_t b = b0 + i;
+            ch.b[i].in_off = in_off[b];
+            ch.b[i].out_off = out_off[b];
+            ch.b[i].valid_start = valid_start[b];
+            ch.b[i].valid_count = valid_count[b];
+            // circular shift that puts spectrum boundaries on multiples of n_chan
+            int64_t o = ((int64_t)valid_start[b] - out_off[b]) % n_chan;
+            if (o < 0) o += n_chan;
+            ch.b[i].shift = (int)o;
+            ch.b[i].index = (int)b;
+        }
+        if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, st)) return 1;
+    }
+    if (!jobs.empty()) {
+        switch (n_chan) {
+            case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, st); break;
+            case 512: launch_seam_fix<512>(p, (float2*)out_dev, jobs, tabc, st); break;
+            case 1024: launch_seam_fix<1024>(p, (float2*)out_dev, jobs, tabc, st); break;
+            case 2048: launch_seam_fix<2048>(p, (float2*)out_dev, jobs, tabc, st); break;
+            case 4096: launch_seam_fix<4096>(p, (float2*)out_dev, jobs, tabc, st); break;
+        }
+        HIP_TRY(hipGetLastError());
     }
     return 0;
 }

@@ -77,7 +77,42 @@ struct OsmBlock {
     long long out_off;  // output complete sample that receives n == valid_start
     int valid_start;    // first block sample kept
     int valid_count;    // number of block samples kept
+    int shift;          // fused channelizer: circular shift o (see k_osm_rowpass), else 0
+    int index;          // fused channelizer: index of the block within the call (seam slots)
 };
+
+// Where the fused channelizer's column pass puts its spectra.
+struct SpecOut {
+    float2* seam;        // [block][head, tail][pair][n_chan] spectra straddling block seams
+    long long s_base;    // spectrum index stored at out[0]
+    long long n_out;     // number of spectra in out
+    int n_chan;
+    int lg_chan;         // log2(n_chan)
+    int n_fft;           // N = N1 * N2
+};
+
+// Fused channelizer output of block-local element (n1, slot) of row length N2:
+// slot = q * n_chan + ch is channel ch of the spectrum whose samples are the
+// (circularly shifted) block samples [n1*N2 + q*n_chan, +n_chan).  n_chan is
+// a power of two (lg_chan), all block-local indices fit 32 bits.
+__device__ __forceinline__ void emit_spectrum(c2 val, float2* __restrict__ out, const SpecOut& so,
+                                              const OsmBlock& blk, int row_start, int slot, int S,
+                                              int sp, int npair) {
+    const int lg = so.lg_chan, nch = 1 << lg;
+    const int ch = slot & (nch - 1);
+    int ystart = row_start + (slot - ch) + blk.shift;     // first sample, unshifted block index
+    if (ystart + nch > so.n_fft) ystart -= so.n_fft;      // the one wrapped group
+    const int rel = ystart - blk.valid_start;              // w.r.t. the first kept sample
+    if (rel >= 0 && rel + nch <= blk.valid_count) {
+        const long long s = ((blk.out_off + rel) >> lg) - so.s_base;
+        if (s >= 0 && s < so.n_out) st_ext(out + (((s << lg) + ch) * S + 2 * sp), val);
+    } else if (rel < 0 && rel + nch > 0) {                 // straddles the block start
+        st_ext(so.seam + (((((long long)blk.index * 2 + 0) * npair + sp) << lg) + ch) * 2, val);
+    } else if (rel < blk.valid_count && rel + nch > blk.valid_count) {  // straddles the block end
+        st_ext(so.seam + (((((long long)blk.index * 2 + 1) * npair + sp) << lg) + ch) * 2, val);
+    }
+}
+
 struct OsmChunk {
     int nblk;
     OsmBlock b[BBT_MAX_CHUNK];
@@ -134,11 +169,11 @@ __global__ __launch_bounds__(N / 16) void k_osm_small(const float2* __restrict__
 
 // Column pass, N1 == 16: one thread per 2-stream column, radix-16 in registers.
 //   FIRST: stream -> work (forward).  !FIRST: work -> valid output (inverse).
-template <bool FIRST>
+template <bool FIRST, bool SPEC = false>
 __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in,
                                                    float2* __restrict__ out,
                                                    float2* __restrict__ work, OsmChunk ch, int S,
-                                                   int N2) {
+                                                   int N2, SpecOut so) {
     const int n2 = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
     const OsmBlock blk = ch.b[b];
@@ -157,19 +192,24 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
         radix16<+1>(v);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int r = j * N2 + n2 - blk.valid_start;
-            if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
+            if (SPEC) {
+                emit_spectrum(v[j], out, so, blk, j * N2, n2, S, sp, npair);
+            } else {
+                const int r = j * N2 + n2 - blk.valid_start;
+                if (r >= 0 && r < blk.valid_count)
+                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
+            }
         }
     }
 }
 
 // Column pass, N1 == 256: 256 threads = 16 two-stream columns (f, fastest
 // lane index -> 256-byte runs per row) x 16 threads per 256-point transform.
-template <bool FIRST>
+template <bool FIRST, bool SPEC = false>
 __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ in,
                                                     float2* __restrict__ out,
                                                     float2* __restrict__ work, OsmChunk ch, int S,
-                                                    int N2, const cf* __restrict__ tw0) {
+                                                    int N2, const cf* __restrict__ tw0, SpecOut so) {
     typedef FftGeo<256> G;
     __shared__ v2 lds[G::LDS_ELEMS * 16];
     const int f = threadIdx.x & 15, tau = threadIdx.x >> 4;
@@ -192,8 +232,13 @@ __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ i
         wg_fft<256, +1, true>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
-            if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
+            if (SPEC) {
+                emit_spectrum(v[j], out, so, blk, (tau + 16 * j) * N2, n2, S, sp, npair);
+            } else {
+                const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
+                if (r >= 0 && r < blk.valid_count)
+                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
+            }
         }
     }
 }
@@ -201,19 +246,27 @@ __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ i
 // Row pass: for row k1 of a (block, pair): four-step twiddle, forward FFT
 // over n2, multiply by the response, inverse FFT over k2, conjugate twiddle.
 //   wroot : W_4096^m, m in [0, 4096)
+//
+// NCH > 0 fuses Channelize.task (reference channelize.py:73-74) into this
+// pass.  The channelizer transforms groups of NCH consecutive dedispersed
+// samples, i.e. acts along n2 inside a row, while the remaining inverse step
+// (column pass) acts along k1: the two commute, so the NCH-point FFT is done
+// here, on registers, and the column pass then emits spectra directly.  To
+// make the groups start at multiples of NCH in n2, the block is circularly
+// shifted by `shift` samples, exactly, by the phase ramp exp(+2 pi i k shift/N)
+// applied with the response.  Spectra that straddle the first / last kept
+// sample of a block are spliced afterwards (k_seam_fix).
 #ifndef BBT_ROWPASS_TWO_REGIONS
 #define BBT_ROWPASS_TWO_REGIONS 0
 #endif
 #ifndef BBT_ROWPASS_MINWAVES
 #define BBT_ROWPASS_MINWAVES 1
 #endif
-template <int N2>
-__global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(float2* __restrict__ work, int N1,
-                                                         const cf* __restrict__ resp,
-                                                         const int* __restrict__ resp_index,
-                                                         int npair, const cf* __restrict__ tw0,
-                                                         const cf* __restrict__ tw1,
-                                                         const cf* __restrict__ wroot) {
+template <int N2, int NCH>
+__global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
+    float2* __restrict__ work, int N1, const cf* __restrict__ resp,
+    const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
+    const cf* __restrict__ tw1, const cf* __restrict__ wroot, OsmChunk ch) {
     typedef FftGeo<N2> G;
     constexpr int T = G::T;
     constexpr int IMOFF = BBT_ROWPASS_TWO_REGIONS ? G::LDS_ELEMS : 0;
@@ -221,10 +274,10 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(f
     const int tau = threadIdx.x;
     const int k1 = blockIdx.x;
     const int sp = blockIdx.y % npair;
-    float2* row = work + (((long long)blockIdx.y * N1 + k1) * N2 + tau) * 2;
+    float2* row = work + (((long long)blockIdx.y * N1 + k1) * N2) * 2;
     c2 v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = ld_int(row + (long long)T * j * 2);
+    for (int j = 0; j < 16; ++j) v[j] = ld_int(row + (long long)(tau + T * j) * 2);
     // W_N^{k1 (tau + T j)} = W_N^{k1 tau} * W_{16 N1}^{k1 j},  N = N1 * N2
     cf base;
     {
@@ -237,9 +290,8 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(f
     const int rstride = 4096 / M;
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 16; ++j)
             v[j] = twmul<-1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
-        }
     }
     wg_fft<N2, -1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
     {
@@ -248,15 +300,116 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(f
         const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2 + tau;
         apply_resp<T>(v, h0, h1, c0 == c1);
     }
+    if constexpr (NCH > 0) {
+        const int shift = ch.b[blockIdx.y / npair].shift;
+        if (shift != 0) {
+            // ramp exp(+2 pi i k shift / N), k = k1 + N1 (tau + T j):
+            //   = exp(2 pi i shift (k1 + N1 tau) / N) * exp(2 pi i shift j / 16)
+            const unsigned n_fft = (unsigned)N1 * (unsigned)N2;
+            const unsigned m = ((unsigned)shift * (unsigned)(k1 + N1 * tau)) & (n_fft - 1u);
+            float s, c;
+            sincospif(2.0f * (float)m / (float)n_fft, &s, &c);
+            const cf r0 = make_float2(c, s);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const cf w = wroot[((shift * j) & 15) * 256];          // W_16^{shift j}, forward
+                v[j] = twmul<-1>(v[j], make_float2(r0.x * w.x + r0.y * w.y, r0.y * w.x - r0.x * w.y));
+            }
+        }
+    }
     wg_fft<N2, +1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 16; ++j)
             v[j] = twmul<+1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
-        }
     }
+    if constexpr (NCH == 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) st_int(row + (long long)T * j * 2, v[j]);
+        for (int j = 0; j < 16; ++j) st_int(row + (long long)(tau + T * j) * 2, v[j]);
+    } else {
+        // channelizer: thread tau holds n2 = tau + T j: group q = j / P, element
+        // m = tau + T (j % P) of the NCH = P * T point transform.
+        constexpr int NG = (NCH > 0) ? N2 / NCH : 1;     // groups per row
+        constexpr int P = 16 / NG;                       // points per thread per group
+        static_assert(NCH == 0 || (NG * NCH == N2 && P * NG == 16), "NCH must divide N2, N2/NCH <= 16");
+        // stage 0: radix-P over the P points of each group, twiddle W_NCH^{tau c} = tw0[(c NG) T + tau]
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if constexpr (P > 1) {
+                c2 t[P];
+#pragma unroll
+                for (int i = 0; i < P; ++i) t[i] = v[q * P + i];
+                radixR<-1, P>(t);
+#pragma unroll
+                for (int i = 0; i < P; ++i) v[q * P + i] = t[i];
+            }
+        }
+#pragma unroll
+        for (int c = 1; c < P; ++c) {
+            const cf w = tw0[(c * NG) * T + tau];
+#pragma unroll
+            for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
+        }
+        // the 16 sequences f = q P + c, one element b = tau each: T-point transforms over b
+        wg_fft_tail<N2, -1, false, IMOFF>(v, lds, tau, 0, tw1);
+        // thread tau2: register u + NU c2 holds k' = (g + R2 u) + 16 c2 of sequence f = tau2 & 15
+        constexpr int R2 = G::R2, NU = 16 / R2;
+        const int f = tau & 15, g = tau >> 4;
+        const int q = f / P, c = f - q * P;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int c2i = 0; c2i < R2; ++c2i) {
+                const int kp = g + R2 * u + 16 * c2i;
+                st_int(row + (long long)(q * NCH + c + P * kp) * 2, v[u + NU * c2i]);
+            }
+    }
+}
+
+// Splice the spectrum that straddles the seam between two consecutive blocks:
+// both blocks computed it from their own (circular) data; inverse-transform
+// both, take samples [0, L) from the earlier block and [L, NCH) from the later
+// one, transform again.  One workgroup per (seam, pair).
+struct SeamJob {
+    long long spectrum;   // output spectrum index (relative to out[0])
+    int first_block;      // call-wide index of the earlier block
+    int split;            // L
+};
+#define BBT_SEAM_JOBS_PER_LAUNCH 64
+struct SeamJobs {         // passed by value: no upload, no synchronisation
+    SeamJob j[BBT_SEAM_JOBS_PER_LAUNCH];
+};
+template <int NCH>
+__global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict__ seam,
+                                                       float2* __restrict__ out, SeamJobs jobs,
+                                                       int S, int npair,
+                                                       const cf* __restrict__ tw0,
+                                                       const cf* __restrict__ tw1) {
+    typedef FftGeo<NCH> G;
+    constexpr int T = G::T;
+    __shared__ v2 lds[G::LDS_ELEMS];
+    const int tau = threadIdx.x, sp = blockIdx.y;
+    const SeamJob job = jobs.j[blockIdx.x];
+    const float2* za = seam + ((((long long)job.first_block * 2 + 1) * npair + sp) * NCH + tau) * 2;
+    const float2* zb = seam + ((((long long)(job.first_block + 1) * 2 + 0) * npair + sp) * NCH + tau) * 2;
+    c2 va[16], vb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) va[j] = ld_ext(za + (long long)T * j * 2);
+    wg_fft<NCH, +1, false>(va, lds, tau, 0, tw0, tw1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vb[j] = ld_ext(zb + (long long)T * j * 2);
+    wg_fft<NCH, +1, false>(vb, lds, tau, 0, tw0, tw1);
+    const float scale = 1.0f / (float)NCH;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool early = tau + T * j < job.split;
+        va[j].re = (early ? va[j].re : vb[j].re) * scale;
+        va[j].im = (early ? va[j].im : vb[j].im) * scale;
+    }
+    wg_fft<NCH, -1, false>(va, lds, tau, 0, tw0, tw1);
+    float2* dst = out + ((job.spectrum * NCH + tau) * S + 2 * sp);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, va[j]);
 }
 
 // Response H[c][k] (natural FFT order) -> Hperm[c][k1][k2] * scale, k = k1 + N1 k2.

@@ -196,19 +196,23 @@ __device__ __forceinline__ int lds_idx(int inner, int f) {
 //   f     : transform lane within a COLMODE group (0..15), ignored otherwise
 //   tw0   : [16][T] forward twiddles W_N^{tau c0};  tw1: [16][R2] W_T^{b1 c1}
 // All threads of the workgroup must call this together (it uses __syncthreads).
+//
+// wg_fft_tail is everything after stage 0: given y[c0][b] (thread b = tau,
+// register c0, already twiddled) it computes the T-point transform over b of
+// each of the 16 sequences c0.  On return thread tau2 holds, in register
+// u + (16/R2) * c2, output k' = c1 + 16 * c2 (c1 = (tau2 >> 4) + R2 * u) of
+// sequence c0 = tau2 & 15 -- for the full transform that is element
+// tau2 + T * register (k = c0 + 16 k').  The fused channelizer enters here
+// with its own stage 0 (fft radix-P per group, see k_osm_rowpass).
 template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
-__device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
-                                       const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
+__device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
+                                            const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
-    constexpr int R2 = G::R2, T = G::T;
+    constexpr int R2 = G::R2;
     const int c0s = tau / R2;  // stage-1 role
     const int b1 = tau % R2;
     v2* __restrict__ lds_im = lds + IMOFF;
 
-    // ---- stage 0
-    radix16<SIGN>(v);
-#pragma unroll
-    for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], tw0[c * T + tau]);
     // ---- exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
     __syncthreads();
 #pragma unroll
@@ -271,6 +275,17 @@ __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int ta
             for (int c2i = 0; c2i < R2; ++c2i) v[u + NU * c2i] = t[u][c2i];
         }
     }
+}
+
+template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
+__device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
+                                       const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
+    constexpr int T = FftGeo<N>::T;
+    // ---- stage 0
+    radix16<SIGN>(v);
+#pragma unroll
+    for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], tw0[c * T + tau]);
+    wg_fft_tail<N, SIGN, COLMODE, IMOFF>(v, lds, tau, f, tw1);
 }
 
 // ---------------------------------------------------------------------------

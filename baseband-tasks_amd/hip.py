@@ -57,6 +57,8 @@ SIGNATURES = {
     'bbt_osm_plan_destroy': [_vp],
     'bbt_osm_plan_info': [_vp, _pi64, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
+    'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
+                                    _i64, _vp],
     'bbt_osm_execute_regular': [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     'bbt_osm_timing_enable': [_vp, _int],
     'bbt_osm_timing_read': [_vp, C.POINTER(C.c_double), _pi64],
@@ -386,6 +388,20 @@ class OsmPlan(_Plan):
                                     in_off.ctypes.data_as(_pi64), out_off.ctypes.data_as(_pi64),
                                     valid_start.ctypes.data_as(_pi32),
                                     valid_count.ctypes.data_as(_pi32), _stream))
+
+    def execute_channelized(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count,
+                            n_chan, first_spectrum, n_spectra):
+        """Fused Channelize: spectra [first_spectrum, +n_spectra) of the stream
+        the blocks would produce (``out_off`` absolute in that stream)."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
+        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
+        check(lib().bbt_osm_execute_channelized(
+            self._h, in_dev.ptr, out_dev.ptr, in_off.shape[0], in_off.ctypes.data_as(_pi64),
+            out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
+            valid_count.ctypes.data_as(_pi32), int(n_chan), int(first_spectrum), int(n_spectra),
+            _stream))
 
     def execute_regular(self, in_dev, out_dev, n_blocks, in_off0, out_off0, hop, valid_start):
         check(lib().bbt_osm_execute_regular(self._h, in_dev.ptr, out_dev.ptr, int(n_blocks),

@@ -67,17 +67,24 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         return self._plan
 
     # -- frames ------------------------------------------------------------------
-    def _compute_frames(self, first, last, out):
-        plan = self._get_plan()
+    def _block_descriptors(self, first, last):
+        """Overlap-save blocks for output frames [first, last): input span
+        (start, length) and per-block arrays (input start, absolute output
+        sample, first kept block sample, kept count)."""
         spf, n = self.samples_per_frame, self._ih_samples_per_frame
         frames = np.arange(first, last)
         blocks = [self._block_start(m) for m in frames]
         starts = np.array([b[0] for b in blocks], dtype=np.int64)
         skips = np.array([b[1] for b in blocks], dtype=np.int64)
-        in0 = int(starts[0])
-        x = fetch_device(self.ih, in0, int(starts[-1]) + n - in0)
         counts = np.minimum(spf - skips, self.shape[0] - frames * spf)
-        out_off = frames * spf - first * spf
+        in0 = int(starts[0])
+        return in0, int(starts[-1]) + n - in0, starts, frames * spf, self._keep_from + skips, counts
+
+    def _compute_frames(self, first, last, out):
+        plan = self._get_plan()
+        in0, in_len, starts, out_abs, keep, counts = self._block_descriptors(first, last)
+        x = fetch_device(self.ih, in0, in_len)
+        out_off = out_abs - first * self.samples_per_frame
         s, se = self._n_stream, self._n_stream_even
         if se != s:
             x = hip.pad_streams_to_even(x, s)
@@ -85,7 +92,7 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             target = padded_out
         else:
             target = out
-        plan.execute(x, target, starts - in0, out_off, self._keep_from + skips, counts)
+        plan.execute(x, target, starts - in0, out_off, keep, counts)
         if se != s:
             hip.strip_stream_pad(padded_out, out.shape[0], s, out)
 

@@ -106,6 +106,20 @@ int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* c
 int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
                     const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
                     const int32_t* valid_count, bbt_stream stream);
+/* Fused Channelize(Dedisperse(...), n_chan): as bbt_osm_execute, but instead
+ * of the dedispersed samples it writes their channelization
+ * (Channelize.task, channelize.py:73-74): spectrum s is the unnormalised FFT
+ * of output complete samples [s*n_chan, (s+1)*n_chan) of the stream the blocks
+ * would have produced.  Spectra first_spectrum .. first_spectrum+n_spectra-1
+ * are stored to out_dev as (n_spectra, n_chan, S); blocks must be consecutive
+ * in the output stream (out_off[b+1] == out_off[b] + valid_count[b]) wherever a
+ * wanted spectrum straddles them.  n_chan: power of two, 256 <= n_chan <=
+ * row length (bbt_osm_plan_info n2), n_fft > 4096, valid_count >= n_chan.
+ * The dedispersed stream itself never exists in memory. */
+int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
+                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
+                                const int32_t* valid_start, const int32_t* valid_count, int n_chan,
+                                int64_t first_spectrum, int64_t n_spectra, bbt_stream stream);
 /* Regular case: block b has in_off = in_off0 + b*hop, out_off = out_off0 +
  * b*hop, the same valid_start and valid_count = hop. */
 int bbt_osm_execute_regular(bbt_osm_plan* plan, const void* in_dev, void* out_dev,

@@ -96,6 +96,43 @@ def test_config2_device_resident_chain_matches_host_chain():
     assert np.array_equal(zd.to_host(), z_host[:128])
 
 
+def test_fused_and_unfused_channelizer_agree(golden, monkeypatch):
+    """Channelize on top of a GPU overlap-save task folds its FFT into that
+    task's row pass; both routes must match the oracle (and each other to
+    rounding), for aligned and unaligned framings, seams included."""
+    from baseband_tasks_amd import channelize as chmod
+    nh = noise(4 * 2**20, (2,), 2**20, frequency=1000 * u.MHz, sideband=1)
+    x = orc.noise_stream(12345, 0, 4 * 2**20, 2**20, (2,))
+    want_y, _ = orc.dedisperse(x, 16e6, 1000., 1, 100., ih_samples_per_frame=2**20)
+    results = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(chmod, 'FUSE_WITH_OVERLAP_SAVE', fuse)
+        for n, spf in ((1024, 512), (4096, 7), (256, 1000)):
+            ch = bt.Channelize(bt.Dedisperse(nh, 100.), n, samples_per_frame=spf)
+            assert (ch._fusable_input() is not None) == fuse
+            z = ch.read()
+            want = orc.channelize(want_y[:z.shape[0] * n], n)
+            assert_parity(z, want, f'fuse={fuse} n={n}')
+            # random access into the middle, across a block seam
+            k = 836100 // n
+            ch.seek(k - 3)
+            assert np.array_equal(ch.read(7), z[k - 3:k + 4])
+            results[fuse, n] = z
+    for n in (1024, 4096, 256):
+        assert rel_l2(results[True, n], results[False, n]) < 3e-7
+    # small geometry: N1 = 16 column pass, two sidebands, Convolve upstream
+    nh = noise(60000, (2,), 20000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,
+               sideband=np.array([1, -1]))
+    xs = orc.noise_stream(11, 0, 60000, 20000, (2,))
+    ys, info = orc.dedisperse(xs, 1e6, 300., np.array([1, -1]), 5., ih_samples_per_frame=20000,
+                              fast_len=HipFFTMaker.next_fast_len)
+    monkeypatch.setattr(chmod, 'FUSE_WITH_OVERLAP_SAVE', True)
+    ch = bt.Channelize(bt.Dedisperse(nh, 5.), 256, samples_per_frame=5)
+    assert ch._fusable_input() is not None and info['ih_spf'] == 32768
+    z = ch.read()
+    assert_parity(z, orc.channelize(ys[:z.shape[0] * 256], 256), 'fused small')
+
+
 # --------------------------------------------------------------------------- config 3
 def test_config3_polyphase_filter_bank(golden):
     nh = noise(2 * 2**20, (2,), 2**20, frequency=1000 * u.MHz, sideband=1)

@@ -134,6 +134,76 @@ def check_osm(N, S, nblk, rng, C_resp=1, timing=False):
     assert e[0] < 1e-6 and e[1] < 1e-5, e
 
 
+def check_fused(N, S, nblk, n_chan, rng, C_resp=1, timing=False, first_spec=0, drop_tail=0):
+    """bbt_osm_execute_channelized against numpy: channelize(overlap_save(x))."""
+    pad = N // 5 + 3
+    hop = N - pad
+    valid_start = pad // 2 + 1
+    L = (nblk - 1) * hop + N
+    x = noise((L, S), rng)
+    H = np.exp(2j * np.pi * rng.uniform(size=(C_resp, N))).astype(np.complex64)
+    resp_index = (np.arange(S) % C_resp).astype(np.int32)
+    plan = C.c_void_p()
+    chk(LIB.bbt_osm_plan_create(C.byref(plan), C.c_int64(N), S, C_resp,
+                                H.ctypes.data_as(C.c_void_p), 0,
+                                resp_index.ctypes.data_as(C.POINTER(C.c_int32))))
+    nspec_all = (nblk * hop) // n_chan
+    nspec = nspec_all - first_spec - drop_tail
+    din = Dev.from_host(x)
+    dout = Dev(nspec * n_chan * S * 8)
+    chk(LIB.bbt_memset(dout.p, 0xff, C.c_size_t(dout.nbytes), None))
+    io = (np.arange(nblk) * hop).astype(np.int64)
+    vs = np.full(nblk, valid_start, np.int32)
+    vc = np.full(nblk, hop, np.int32)
+    p64, p32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+
+    def run():
+        chk(LIB.bbt_osm_execute_channelized(plan, din.p, dout.p, C.c_int64(nblk), io.ctypes.data_as(p64),
+                                            io.ctypes.data_as(p64), vs.ctypes.data_as(p32),
+                                            vc.ctypes.data_as(p32), n_chan, C.c_int64(first_spec),
+                                            C.c_int64(nspec), None))
+    run()
+    chk(LIB.bbt_device_sync())
+    got = dout.to_host((nspec, n_chan, S), np.complex64)
+    if N * nblk <= (1 << 22):
+        y = osm_ref(x, H, N, hop, valid_start, nblk, resp_index)
+        ref = np.fft.fft(y[:nspec_all * n_chan].reshape(nspec_all, n_chan, S), axis=1)
+        ref = ref[first_spec:first_spec + nspec]
+        e = relerr(got, ref)
+        # the spectra straddling block seams, separately
+        seams = [(b * hop) // n_chan - first_spec for b in range(1, nblk) if (b * hop) % n_chan]
+        seams = [s_ for s_ in seams if 0 <= s_ < nspec]
+        es = relerr(got[seams], ref[seams]) if seams else (0., 0.)
+    else:
+        y = osm_ref(x, H, N, hop, valid_start, 2, resp_index)     # first two blocks only
+        k = (2 * hop) // n_chan
+        ref = np.fft.fft(y[:k * n_chan].reshape(k, n_chan, S), axis=1)[first_spec:]
+        e = relerr(got[:k - first_spec], ref)
+        s_ = hop // n_chan - first_spec
+        es = relerr(got[s_:s_ + 1], ref[s_:s_ + 1])
+    print(f"fused N={N} S={S} nblk={nblk} n_chan={n_chan} C={C_resp} first={first_spec}: relL2={e[0]:.2e} "
+          f"max/rms={e[1]:.2e}  seam spectra relL2={es[0]:.2e}")
+    if timing:
+        chk(LIB.bbt_osm_timing_enable(plan, 1))
+        for _ in range(5):
+            run()
+        ms = (C.c_double * 3)()
+        nl = C.c_int64()
+        chk(LIB.bbt_osm_timing_read(plan, ms, C.byref(nl)))
+        print(f"   passes ms (A,B,C) per 5 runs: {ms[0]:.3f} {ms[1]:.3f} {ms[2]:.3f} launches={nl.value}")
+        chk(LIB.bbt_osm_timing_enable(plan, 0))
+        chk(LIB.bbt_device_sync())
+        t0 = time.perf_counter()
+        for _ in range(10):
+            run()
+        chk(LIB.bbt_device_sync())
+        dt = (time.perf_counter() - t0) / 10
+        print(f"   wall {dt * 1e3:.3f} ms per {nblk} blocks -> {nblk * hop / dt / 1e6:.1f} Msamples/s")
+    chk(LIB.bbt_osm_plan_destroy(plan))
+    din.free(), dout.free()
+    assert e[0] < 1e-6 and e[1] < 1e-5 and es[0] < 1e-6, (e, es)
+
+
 def check_pfb(n, S, ntap, nspec, rng):
     x = noise(((nspec + ntap - 1) * n, S), rng)
     taps = rng.normal(size=(ntap, n)).astype(np.float32)
@@ -160,6 +230,20 @@ def main():
     if '--perf' in sys.argv:
         rng = np.random.default_rng(7)
         check_osm(1 << 20, 2, 32, rng, timing=True)
+        check_fused(1 << 20, 2, 32, 1024, rng, timing=True)
+        return
+    if '--fused' in sys.argv:
+        rng = np.random.default_rng(8)
+        for N, ncs in ((1 << 13, (256, 512)), (1 << 14, (256, 1024)), (1 << 16, (256, 2048, 4096)),
+                       (1 << 17, (256, 512)), (1 << 18, (1024,)), (1 << 19, (256, 2048))):
+            for nc in ncs:
+                check_fused(N, 2, 4, nc, rng)
+        check_fused(1 << 15, 4, 3, 512, rng, C_resp=2)
+        check_fused(1 << 17, 4, 3, 512, rng, C_resp=4, first_spec=3, drop_tail=2)
+        check_fused(1 << 20, 2, 3, 1024, rng)
+        check_fused(1 << 20, 2, 3, 4096, rng)
+        check_fused(1 << 20, 2, 32, 1024, rng, timing=True)
+        print("FUSED OK")
         return
     name = C.create_string_buffer(256)
     chk(LIB.bbt_device_name(name, 256))
