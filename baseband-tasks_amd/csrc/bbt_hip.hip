@@ -244,8 +244,16 @@ struct bbt_osm_plan {
     int chunk = 1;
     cf* resp = nullptr;        // [C][N1][N2], scaled 1/N
     int* resp_index = nullptr;  // [S]
-    float2* work = nullptr;     // [chunk][npair][N1][N2] float4
-    size_t work_bytes = 0;
+    float2* work = nullptr;     // [chunk][npair][N1][N2] float4 (lane 0)
+    size_t work_bytes = 0;      // per lane
+    // Chunks alternate between `lanes` internal streams, each with its own
+    // work buffer, so kernels of different chunks overlap: the bandwidth-bound
+    // column passes of one chunk run beside the latency-bound row pass of
+    // another and fill each other's launch tails.
+    int lanes = 1;
+    float2* lane_work[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     cf* wroot = nullptr;
@@ -261,17 +269,18 @@ struct bbt_osm_plan {
 };
 
 template <int N2, int NCH>
-static void launch_rowpass_t(bbt_osm_plan* p, const OsmChunk& ch, hipStream_t st) {
+static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, hipStream_t st) {
     hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>), dim3(p->n1, ch.nblk * p->npair), dim3(N2 / 16), 0,
-                       st, p->work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0,
-                       p->tab2.tw1, p->wroot, ch);
+                       st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
+                       p->wroot, ch);
 }
 
 // (row length, channels) -> instantiation; nch == 0 is the plain row pass.
-static int launch_rowpass(bbt_osm_plan* p, const OsmChunk& ch, int nch, hipStream_t st) {
+static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int nch,
+                          hipStream_t st) {
 #define BBT_RP(N2_, NCH_)                               \
     if (p->n2 == N2_ && nch == NCH_) {                  \
-        launch_rowpass_t<N2_, NCH_>(p, ch, st);         \
+        launch_rowpass_t<N2_, NCH_>(p, work, ch, st);   \
         return 0;                                       \
     }
     BBT_RP(256, 0) BBT_RP(512, 0) BBT_RP(1024, 0) BBT_RP(2048, 0) BBT_RP(4096, 0)
@@ -307,7 +316,7 @@ static int osm_flush_timing(bbt_osm_plan* p) {
 }
 
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
-                         const SpecOut& so, hipStream_t st) {
+                         const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (p->timing) {
@@ -330,28 +339,28 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
     } else {
         const dim3 g16(p->n2 / 256, ch.nblk, p->npair), g256(p->n2 / 16, ch.nblk, p->npair);
         if (p->n1 == 16)
-            hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, p->work, ch,
+            hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
                                p->S, p->n2, so);
         else
-            hipLaunchKernelGGL((k_osm_col256<true, false>), g256, dim3(256), 0, st, in, out, p->work,
+            hipLaunchKernelGGL((k_osm_col256<true, false>), g256, dim3(256), 0, st, in, out, work,
                                ch, p->S, p->n2, p->tab1.tw0, so);
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        if (launch_rowpass(p, ch, nch, st)) return 1;
+        if (launch_rowpass(p, work, ch, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
         if (p->n1 == 16) {
             if (nch)
                 hipLaunchKernelGGL((k_osm_col16<false, true>), g16, dim3(256), 0, st, in, out,
-                                   p->work, ch, p->S, p->n2, so);
+                                   work, ch, p->S, p->n2, so);
             else
                 hipLaunchKernelGGL((k_osm_col16<false, false>), g16, dim3(256), 0, st, in, out,
-                                   p->work, ch, p->S, p->n2, so);
+                                   work, ch, p->S, p->n2, so);
         } else {
             if (nch)
                 hipLaunchKernelGGL((k_osm_col256<false, true>), g256, dim3(256), 0, st, in, out,
-                                   p->work, ch, p->S, p->n2, p->tab1.tw0, so);
+                                   work, ch, p->S, p->n2, p->tab1.tw0, so);
             else
                 hipLaunchKernelGGL((k_osm_col256<false, false>), g256, dim3(256), 0, st, in, out,
-                                   p->work, ch, p->S, p->n2, p->tab1.tw0, so);
+                                   work, ch, p->S, p->n2, p->tab1.tw0, so);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -359,6 +368,34 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         HIP_TRY(hipEventRecord(e[3], st));
         for (int i = 0; i < 4; ++i) p->ev.push_back(e[i]);
         if (p->ev.size() >= 4096) return osm_flush_timing(p);
+    }
+    return 0;
+}
+
+// Run all chunks, alternating lanes; returns with `st` ordered after every lane.
+template <class FillChunk>
+static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n_blocks,
+                       const SpecOut& so, hipStream_t st, FillChunk fill) {
+    const int64_t n_chunks = (n_blocks + p->chunk - 1) / p->chunk;
+    const bool fork = p->lanes > 1 && !p->timing && n_chunks > 1;
+    if (fork) {
+        HIP_TRY(hipEventRecord(p->ev_fork, st));
+        for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
+    }
+    int64_t c = 0;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
+        OsmChunk ch;
+        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
+        for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
+        const int l = fork ? (int)(c % p->lanes) : 0;
+        if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : st))
+            return 1;
+    }
+    if (fork) {
+        for (int l = 0; l < p->lanes; ++l) {
+            HIP_TRY(hipEventRecord(p->ev_join[l], p->lane_stream[l]));
+            HIP_TRY(hipStreamWaitEvent(st, p->ev_join[l], 0));
+        }
     }
     return 0;
 }
@@ -457,18 +494,36 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             hipSuccess)
         return bail(fail("bbt_osm_plan_create: resp_index upload failed"));
 
-    // workspace
+    // workspace: `lanes` work buffers of `chunk` blocks each, 128 MiB in total
+    // (measured best on MI355X: the buffers stay within the 256 MiB Infinity
+    // Cache between passes while each launch still has >= 1024 workgroups)
+    int lanes = 2;
+    if (const char* env = getenv("BBT_OSM_LANES")) lanes = atoi(env);
+    lanes = lanes < 1 ? 1 : (lanes > 4 ? 4 : lanes);
     const size_t per_block = (size_t)p->npair * n_fft * 16;
-    int chunk = (int)((128u << 20) / per_block);
+    int chunk = (int)((128u << 20) / per_block / lanes);
     if (const char* env = getenv("BBT_OSM_CHUNK")) chunk = atoi(env);
     if (chunk < 1) chunk = 1;
     if (chunk > BBT_MAX_CHUNK) chunk = BBT_MAX_CHUNK;
     p->chunk = chunk;
+    p->lanes = lanes;
     if (p->n1 > 1) {
         p->work_bytes = per_block * chunk;
-        if (hipMalloc((void**)&p->work, p->work_bytes) != hipSuccess)
-            return bail(fail("bbt_osm_plan_create: hipMalloc(workspace %zu bytes) failed",
-                             p->work_bytes));
+        for (int l = 0; l < p->lanes; ++l) {
+            if (hipMalloc((void**)&p->lane_work[l], p->work_bytes) != hipSuccess)
+                return bail(fail("bbt_osm_plan_create: hipMalloc(workspace %zu bytes) failed",
+                                 p->work_bytes));
+            if (p->lanes > 1 &&
+                (hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+                 hipEventCreateWithFlags(&p->ev_join[l], hipEventDisableTiming) != hipSuccess))
+                return bail(fail("bbt_osm_plan_create: creating the lane streams failed"));
+        }
+        p->work = p->lane_work[0];
+        if (p->lanes > 1 &&
+            hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess)
+            return bail(fail("bbt_osm_plan_create: creating the fork event failed"));
+    } else {
+        p->lanes = 1;
     }
     *plan = p;
     return 0;
@@ -479,7 +534,15 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     for (auto e : p->ev) hipEventDestroy(e);
     if (p->resp) hipFree(p->resp);
     if (p->resp_index) hipFree(p->resp_index);
-    if (p->work) hipFree(p->work);
+    for (int l = 0; l < 4; ++l) {
+        if (p->lane_stream[l]) {
+            hipStreamSynchronize(p->lane_stream[l]);
+            hipStreamDestroy(p->lane_stream[l]);
+        }
+        if (p->ev_join[l]) hipEventDestroy(p->ev_join[l]);
+        if (p->lane_work[l]) hipFree(p->lane_work[l]);
+    }
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->seam) hipFree(p->seam);
     delete p;
     return 0;
@@ -488,7 +551,7 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
 int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chunk_blocks, int* n1,
                       int* n2) {
     ARG_TRY(p, "bbt_osm_plan_info: null plan");
-    if (workspace_bytes) *workspace_bytes = (int64_t)p->work_bytes;
+    if (workspace_bytes) *workspace_bytes = (int64_t)p->work_bytes * p->lanes;
     if (chunk_blocks) *chunk_blocks = p->chunk;
     if (n1) *n1 = p->n1;
     if (n2) *n2 = p->n2;
@@ -503,20 +566,15 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
         return 1;
     hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
-    for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk) {
-        OsmChunk ch;
-        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
-        for (int i = 0; i < ch.nblk; ++i) {
-            ch.b[i].in_off = in_off[b0 + i];
-            ch.b[i].out_off = out_off[b0 + i];
-            ch.b[i].valid_start = valid_start[b0 + i];
-            ch.b[i].valid_count = valid_count[b0 + i];
-            ch.b[i].shift = 0;
-            ch.b[i].index = (int)(b0 + i);
-        }
-        if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, st)) return 1;
-    }
-    return 0;
+    return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+                       [&](OsmBlock& blk, int64_t b) {
+                           blk.in_off = in_off[b];
+                           blk.out_off = out_off[b];
+                           blk.valid_start = valid_start[b];
+                           blk.valid_count = valid_count[b];
+                           blk.shift = 0;
+                           blk.index = (int)b;
+                       });
 }
 
 int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_dev,
@@ -570,23 +628,19 @@ int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_d
     so.lg_chan = 0;
     while ((1 << so.lg_chan) < n_chan) ++so.lg_chan;
     so.n_fft = (int)p->n;
-    for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk) {
-        OsmChunk ch;
-        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
-        for (int i = 0; i < ch.nblk; ++i) {
-            const int64_t b = b0 + i;
-            ch.b[i].in_off = in_off[b];
-            ch.b[i].out_off = out_off[b];
-            ch.b[i].valid_start = valid_start[b];
-            ch.b[i].valid_count = valid_count[b];
-            // circular shift that puts spectrum boundaries on multiples of n_chan
-            int64_t o = ((int64_t)valid_start[b] - out_off[b]) % n_chan;
-            if (o < 0) o += n_chan;
-            ch.b[i].shift = (int)o;
-            ch.b[i].index = (int)b;
-        }
-        if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, st)) return 1;
-    }
+    if (osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+                    [&](OsmBlock& blk, int64_t b) {
+                        blk.in_off = in_off[b];
+                        blk.out_off = out_off[b];
+                        blk.valid_start = valid_start[b];
+                        blk.valid_count = valid_count[b];
+                        // circular shift that puts spectrum boundaries on multiples of n_chan
+                        int64_t o = ((int64_t)valid_start[b] - out_off[b]) % n_chan;
+                        if (o < 0) o += n_chan;
+                        blk.shift = (int)o;
+                        blk.index = (int)b;
+                    }))
+        return 1;
     if (!jobs.empty()) {
         switch (n_chan) {
             case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, st); break;

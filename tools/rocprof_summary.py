@@ -19,10 +19,10 @@ import shutil
 import sys
 from collections import defaultdict
 
-SHORT = {'k_osm_rowpass': 'osm_rowpass', 'k_osm_col256<true>': 'osm_col_forward',
-         'k_osm_col256<false>': 'osm_col_inverse', 'k_fft_rows': 'channelize_fft_rows',
-         'k_osm_col16<true>': 'osm_col_forward', 'k_osm_col16<false>': 'osm_col_inverse',
-         'k_osm_small': 'osm_small', 'k_pfb': 'pfb'}
+SHORT = {'k_osm_rowpass': 'osm_rowpass', 'k_osm_col256<true': 'osm_col_forward',
+         'k_osm_col256<false': 'osm_col_inverse', 'k_fft_rows': 'channelize_fft_rows',
+         'k_osm_col16<true': 'osm_col_forward', 'k_osm_col16<false': 'osm_col_inverse',
+         'k_osm_small': 'osm_small', 'k_pfb': 'pfb', 'k_seam_fix': 'seam_fix'}
 
 
 def short(name):
