@@ -337,7 +337,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             HIP_TRY(hipEventRecord(e[2], st));
         }
     } else {
-        const dim3 g16(p->n2 / 256, ch.nblk, p->npair), g256(p->n2 / 16, ch.nblk, p->npair);
+        const dim3 g16(p->n2 / 256 * p->npair, ch.nblk), g256(p->n2 / 16 * p->npair, ch.nblk);
         if (p->n1 == 16)
             hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
                                p->S, p->n2, so);
@@ -701,7 +701,7 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
                         float scale, hipStream_t st) {
     constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
     const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
-    hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW>), dim3(gx, p->npair), dim3(FPW * N / 16), 0, st, in,
+    hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW>), dim3(gx * p->npair), dim3(FPW * N / 16), 0, st, in,
                        out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
 }
 
@@ -753,7 +753,7 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
     ARG_TRY(n_spectra >= 0, "bbt_chan_execute: n_spectra < 0");
     if (n_spectra == 0) return 0;
     // keep grid.x within limits: process in slabs
-    const int64_t slab = (int64_t)1 << 22;
+    const int64_t slab = (int64_t)1 << 20;
     const float2* in = (const float2*)in_dev;
     float2* out = (float2*)out_dev;
     for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {
@@ -784,7 +784,7 @@ static void launch_pfb(const bbt_pfb_plan* p, const float2* in, float2* out, int
                        hipStream_t st) {
     constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
     const unsigned gx = (unsigned)((n_spec + FPW - 1) / FPW);
-    hipLaunchKernelGGL((k_pfb<N, FPW>), dim3(gx, p->npair), dim3(FPW * N / 16), 0, st, in, out,
+    hipLaunchKernelGGL((k_pfb<N, FPW>), dim3(gx * p->npair), dim3(FPW * N / 16), 0, st, in, out,
                        (long long)n_spec, p->S, p->n_tap, p->taps, p->tab.tw0, p->tab.tw1);
 }
 
@@ -827,7 +827,7 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
     ARG_TRY(p && in_dev && out_dev, "bbt_pfb_execute: null argument");
     ARG_TRY(n_spectra >= 0, "bbt_pfb_execute: n_spectra < 0");
     if (n_spectra == 0) return 0;
-    const int64_t slab = (int64_t)1 << 22;
+    const int64_t slab = (int64_t)1 << 20;
     const float2* in = (const float2*)in_dev;
     float2* out = (float2*)out_dev;
     for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {

@@ -48,8 +48,12 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
     constexpr int T = G::T;
     __shared__ v2 lds[FPW * G::LDS_ELEMS];
     const int slot = threadIdx.x / T, tau = threadIdx.x % T;
-    const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * FPW + slot;
-    const int sp = blockIdx.y;
+    // pairs of the same samples share cache lines: keep them adjacent in the
+    // XCD-contiguous virtual block order
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const long long i = (long long)(vb / npair) * FPW + slot;
+    const int sp = vb % npair;
     const bool active = i < n_fft;
     c2 v[16];
     if (active) {
@@ -174,8 +178,10 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
                                                    float2* __restrict__ out,
                                                    float2* __restrict__ work, OsmChunk ch, int S,
                                                    int N2, SpecOut so) {
-    const int n2 = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n2 = (vb / npair) * 256 + threadIdx.x;
+    const int b = blockIdx.y, sp = vb % npair;
     const OsmBlock blk = ch.b[b];
     float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
     c2 v[16];
@@ -213,8 +219,10 @@ __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ i
     typedef FftGeo<256> G;
     __shared__ v2 lds[G::LDS_ELEMS * 16];
     const int f = threadIdx.x & 15, tau = threadIdx.x >> 4;
-    const int n2 = xcd_remap(blockIdx.x, gridDim.x) * 16 + f;
-    const int b = blockIdx.y, sp = blockIdx.z, npair = gridDim.z;
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n2 = (vb / npair) * 16 + f;
+    const int b = blockIdx.y, sp = vb % npair;
     const OsmBlock blk = ch.b[b];
     // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*256 + k1)*N2 + n2
     float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
@@ -439,8 +447,10 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
     constexpr int T = G::T;
     __shared__ v2 lds[FPW * G::LDS_ELEMS];
     const int slot = threadIdx.x / T, tau = threadIdx.x % T;
-    const long long i = (long long)xcd_remap(blockIdx.x, gridDim.x) * FPW + slot;
-    const int sp = blockIdx.y;
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const long long i = (long long)(vb / npair) * FPW + slot;
+    const int sp = vb % npair;
     const bool active = i < n_spec;
     c2 v[16];
 #pragma unroll
