@@ -27,10 +27,10 @@ def _prod(shape):
     return n
 
 
-def _check_n(n):
-    if n < MIN_FFT_LEN or n > MAX_WG_FFT_LEN or n & (n - 1):
+def _check_n(n, minimum=2):
+    if n < minimum or n > MAX_WG_FFT_LEN or n & (n - 1):
         raise ValueError(f"the accelerated channelizer supports power-of-two n in "
-                         f"[{MIN_FFT_LEN}, {MAX_WG_FFT_LEN}]; got {n}.")
+                         f"[{minimum}, {MAX_WG_FFT_LEN}]; got {n}.")
 
 
 class _RowFFTTask(DeviceTaskMixin, TaskBase):
@@ -109,7 +109,8 @@ class Channelize(_RowFFTTask):
         dd = self.ih
         if not (FUSE_WITH_OVERLAP_SAVE and isinstance(dd, SpectralMultiplyTask)) or dd.closed:
             return None
-        if dd._n_stream != dd._n_stream_even or dd.samples_per_frame < self._n:
+        if (dd._n_stream != dd._n_stream_even or dd.samples_per_frame < self._n
+                or self._n < MIN_FFT_LEN):
             return None
         info = dd._get_plan().info()
         if info['n1'] == 1 or self._n > info['n2'] or info['n2'] % self._n:

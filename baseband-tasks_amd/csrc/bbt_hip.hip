@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 101
+#define BBT_VERSION 103
 
 // ---------------------------------------------------------------------------
 // errors
@@ -57,7 +57,7 @@ struct FftTables {
 };
 static std::mutex g_tab_mutex;
 static std::map<std::pair<int, int>, FftTables> g_tables;  // (device, N)
-static std::map<int, cf*> g_wroot;                         // device -> W_4096^m
+static std::map<int, cf*> g_wroot;                         // device -> W_4096^m, then W_65536^i (i < 256)
 
 static int upload(cf** dst, const std::vector<cf>& h) {
     HIP_TRY(hipMalloc((void**)dst, h.size() * sizeof(cf)));
@@ -104,8 +104,9 @@ static int get_wroot(cf** out) {
         *out = it->second;
         return 0;
     }
-    std::vector<cf> h(4096);
+    std::vector<cf> h(4096 + 256);
     for (int m = 0; m < 4096; ++m) h[m] = unit_root(m, 4096);
+    for (int m = 0; m < 256; ++m) h[4096 + m] = unit_root(m, 65536);
     cf* d;
     if (upload(&d, h)) return 1;
     g_wroot[dev] = d;
@@ -241,6 +242,7 @@ struct bbt_osm_plan {
     int64_t n = 0;
     int S = 0, npair = 0, C = 0;
     int n1 = 1, n2 = 0;
+    int outer = 1;  // 256 for three-level transforms (N > 2^20): N = outer * n1 * n2
     int chunk = 1;
     cf* resp = nullptr;        // [C][N1][N2], scaled 1/N
     int* resp_index = nullptr;  // [S]
@@ -270,9 +272,10 @@ struct bbt_osm_plan {
 
 template <int N2, int NCH>
 static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, hipStream_t st) {
-    hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>), dim3(p->n1, ch.nblk * p->npair), dim3(N2 / 16), 0,
+    hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>), dim3(p->n1, ch.nblk * p->npair * p->outer),
+                       dim3(N2 / 16), 0,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
-                       p->wroot, ch);
+                       p->wroot, p->wroot + 4096, ch, p->outer);
 }
 
 // (row length, channels) -> instantiation; nch == 0 is the plain row pass.
@@ -336,6 +339,27 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             HIP_TRY(hipEventRecord(e[1], st));
             HIP_TRY(hipEventRecord(e[2], st));
         }
+    } else if (p->outer > 1) {
+        // three levels: outer 256-point column pass over rows of M = 16 * n2, then
+        // the two-level machinery in place on every outer row
+        const int m_len = 16 * p->n2;
+        const dim3 gout(m_len / 16 * p->npair, ch.nblk);
+        const dim3 gmid(p->n2 / 256, ch.nblk * p->npair * 256);
+        hipLaunchKernelGGL((k_osm_col256<true, false>), gout, dim3(256), 0, st, in, out, work, ch,
+                           p->S, m_len, p->tab1.tw0, so);
+        hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
+                           p->wroot, 0);
+        if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+        if (launch_rowpass(p, work, ch, nch, st)) return 1;
+        if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+        hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
+                           p->wroot, nch ? 1 : 0);
+        if (nch)
+            hipLaunchKernelGGL((k_osm_col256<false, true>), gout, dim3(256), 0, st, in, out, work, ch,
+                               p->S, m_len, p->tab1.tw0, so);
+        else
+            hipLaunchKernelGGL((k_osm_col256<false, false>), gout, dim3(256), 0, st, in, out, work,
+                               ch, p->S, m_len, p->tab1.tw0, so);
     } else {
         const dim3 g16(p->n2 / 256 * p->npair, ch.nblk), g256(p->n2 / 16 * p->npair, ch.nblk);
         if (p->n1 == 16)
@@ -435,8 +459,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
                         const void* resp, int resp_on_device, const int32_t* resp_index) {
     ARG_TRY(plan && resp, "bbt_osm_plan_create: null argument");
     *plan = nullptr;
-    ARG_TRY(is_pow2(n_fft) && n_fft >= 256 && n_fft <= (1 << 20),
-            "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^20]",
+    ARG_TRY(is_pow2(n_fft) && n_fft >= 256 && n_fft <= (1 << 24),
+            "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^24]",
             (long long)n_fft);
     ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
             "bbt_osm_plan_create: n_stream=%d must be even and >= 2", n_stream);
@@ -462,12 +486,17 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         p->n1 = 1;
     } else if (n_fft <= (1 << 16)) {
         p->n1 = 16;
-    } else {
+    } else if (n_fft <= (1 << 20)) {
         p->n1 = 256;
+    } else {
+        p->outer = 256;
+        p->n1 = 16;
+        ARG_TRY(n_stream / 2 <= 255,
+                "bbt_osm_plan_create: blocks longer than 2^20 support at most 510 streams");
     }
-    p->n2 = (int)(n_fft / p->n1);
+    p->n2 = (int)(n_fft / p->n1 / p->outer);
     if (get_tables(p->n2, &p->tab2)) return bail(1);
-    if (p->n1 == 256 && get_tables(256, &p->tab1)) return bail(1);
+    if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
     if (get_wroot(&p->wroot)) return bail(1);
 
     // response: upload (if needed), permute to [C][N1][N2], scale by 1/N
@@ -483,7 +512,7 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (hipMalloc((void**)&p->resp, rbytes) != hipSuccess)
         return bail(fail("bbt_osm_plan_create: hipMalloc(response) failed"));
     hipLaunchKernelGGL(k_permute_resp, dim3((unsigned)((n_fft + 255) / 256), n_resp), dim3(256), 0, 0,
-                       nat, p->resp, p->n1, (long long)p->n2, 1.0f / (float)n_fft);
+                       nat, p->resp, p->outer, p->n1, (long long)p->n2, 1.0f / (float)n_fft);
     hipError_t e = hipDeviceSynchronize();
     if (!resp_on_device) hipFree(nat);
     if (e != hipSuccess)
@@ -505,6 +534,10 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (const char* env = getenv("BBT_OSM_CHUNK")) chunk = atoi(env);
     if (chunk < 1) chunk = 1;
     if (chunk > BBT_MAX_CHUNK) chunk = BBT_MAX_CHUNK;
+    if (p->outer > 1) {                       // grid.y = blocks * pairs * 256 must fit
+        while (chunk > 1 && (long long)chunk * p->npair * p->outer > 65535) --chunk;
+        if (chunk * per_block * lanes > (768u << 20)) lanes = 1;
+    }
     p->chunk = chunk;
     p->lanes = lanes;
     if (p->n1 > 1) {
@@ -582,7 +615,7 @@ int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_d
                                 const int32_t* valid_start, const int32_t* valid_count, int n_chan,
                                 int64_t first_spectrum, int64_t n_spectra, bbt_stream stream) {
     ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute_channelized: null argument");
-    ARG_TRY(p->n1 > 1, "bbt_osm_execute_channelized: block length %lld is too short to fuse",
+    ARG_TRY(p->n1 > 1 || p->outer > 1, "bbt_osm_execute_channelized: block length %lld is too short to fuse",
             (long long)p->n);
     ARG_TRY(fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0,
             "bbt_osm_execute_channelized: n_chan=%d must be a power of two in [256, %d]", n_chan,
@@ -694,7 +727,18 @@ int bbt_osm_timing_read(bbt_osm_plan* p, double ms[3], int64_t* launches) {
 struct bbt_chan_plan {
     int n = 0, S = 0, npair = 0, dir = -1;
     FftTables tab;
+    cf* wroot = nullptr;
 };
+
+template <int N, int SIGN>
+static void launch_short(const bbt_chan_plan* p, const float2* in, float2* out, int64_t n_fft,
+                         float scale, hipStream_t st) {
+    constexpr int R = (N <= 16) ? 1 : N / 16;
+    constexpr int FPW = 256 / R;
+    const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
+    hipLaunchKernelGGL((k_fft_short<N, SIGN>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
+                       (long long)n_fft, p->S, scale, p->wroot);
+}
 
 template <int N, int SIGN>
 static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, int64_t n_fft,
@@ -709,6 +753,13 @@ template <int SIGN>
 static int chan_dispatch(const bbt_chan_plan* p, const float2* in, float2* out, int64_t n_fft,
                          float scale, hipStream_t st) {
     switch (p->n) {
+        case 2: launch_short<2, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 4: launch_short<4, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 8: launch_short<8, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 16: launch_short<16, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 32: launch_short<32, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 64: launch_short<64, SIGN>(p, in, out, n_fft, scale, st); break;
+        case 128: launch_short<128, SIGN>(p, in, out, n_fft, scale, st); break;
         case 256: launch_rows<256, SIGN>(p, in, out, n_fft, scale, st); break;
         case 512: launch_rows<512, SIGN>(p, in, out, n_fft, scale, st); break;
         case 1024: launch_rows<1024, SIGN>(p, in, out, n_fft, scale, st); break;
@@ -724,8 +775,8 @@ extern "C" {
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction) {
     ARG_TRY(plan, "bbt_chan_plan_create: null argument");
     *plan = nullptr;
-    ARG_TRY(fft_len_ok(n_chan),
-            "bbt_chan_plan_create: n_chan=%d must be a power of two in [256, 4096]", n_chan);
+    ARG_TRY(is_pow2(n_chan) && n_chan >= 2 && n_chan <= 4096,
+            "bbt_chan_plan_create: n_chan=%d must be a power of two in [2, 4096]", n_chan);
     ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
             "bbt_chan_plan_create: n_stream=%d must be even and >= 2", n_stream);
     ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1 or +1");
@@ -734,7 +785,7 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     p->S = n_stream;
     p->npair = n_stream / 2;
     p->dir = direction;
-    if (get_tables(n_chan, &p->tab)) {
+    if ((n_chan >= 256 && get_tables(n_chan, &p->tab)) || (n_chan < 256 && get_wroot(&p->wroot))) {
         delete p;
         return 1;
     }

@@ -73,6 +73,77 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
     }
 }
 
+// Batched FFT for short groups, N = 2 .. 128 (Channelize with few channels).
+//   N <= 16 : one thread per transform, radix-N in registers.
+//   N = 16 R, R in {2, 4, 8}: R threads per transform; radix-16 over the
+//             elements tau + R j, twiddle W_N^{tau c}, exchange through LDS,
+//             radix-R; output k = c + 16 k'.
+// Accesses are per-thread short runs (N <= 128 samples = 2 KiB per group);
+// neighbouring lanes cover neighbouring groups so the L1/L2 see whole lines.
+template <int N, int SIGN>
+__global__ __launch_bounds__(256) void k_fft_short(const float2* __restrict__ in,
+                                                   float2* __restrict__ out, long long n_fft, int S,
+                                                   float scale, const cf* __restrict__ wroot) {
+    constexpr int R = (N <= 16) ? 1 : N / 16;        // threads per transform
+    constexpr int P = (N <= 16) ? N : 16;            // points per thread
+    constexpr int FPW = 256 / R;                     // transforms per workgroup
+    constexpr int PITCH = R + 1;
+    __shared__ v2 lds[(R > 1) ? FPW * 16 * PITCH : 1];
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int slot = threadIdx.x / R, tau = threadIdx.x % R;
+    const long long i = (long long)(vb / npair) * FPW + slot;
+    const int sp = vb % npair;
+    const bool active = i < n_fft;
+    c2 v[P];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) v[j] = ld_ext(in + ((i * N + tau + R * j) * S + 2 * sp));
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) v[j] = czero();
+    }
+    radixR<SIGN, P>(v);
+    if constexpr (R == 1) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                st_ext(out + ((i * N + j) * S + 2 * sp), c2{v[j].re * scale, v[j].im * scale});
+        }
+    } else {
+        constexpr int NU = 16 / R;
+#pragma unroll
+        for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], wroot[(tau * c) * (4096 / N)]);
+        v2* my = lds + slot * 16 * PITCH;
+        c2 t[NU][R];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) my[c * PITCH + tau] = v[c].re;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int b = 0; b < R; ++b) t[u][b].re = my[(tau + R * u) * PITCH + b];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) my[c * PITCH + tau] = v[c].im;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int b = 0; b < R; ++b) t[u][b].im = my[(tau + R * u) * PITCH + b];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            radixR<SIGN, R>(t[u]);
+            if (active) {
+#pragma unroll
+                for (int kp = 0; kp < R; ++kp)
+                    st_ext(out + ((i * N + (tau + R * u) + 16 * kp) * S + 2 * sp),
+                           c2{t[u][kp].re * scale, t[u][kp].im * scale});
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Overlap-save block descriptors (one launch handles <= BBT_MAX_CHUNK blocks).
 #define BBT_MAX_CHUNK 16
@@ -251,6 +322,41 @@ __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ i
     }
 }
 
+// Middle level of a three-level transform N = 256 * 16 * N2 (N > 2^20), in
+// place on the work buffer.  After the outer 256-point column pass the work
+// buffer holds, per (block, pair), rows k1o of M = 16 * N2 elements indexed
+// m = N2 * a + n2.  FWD: multiply by the outer four-step twiddle W_N^{m k1o}
+// and transform over a (radix-16 in registers); !FWD: the inverse, twiddle
+// conjugated and applied after the butterfly.  One thread per (row, n2).
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_osm_mid16(float2* __restrict__ work, int N2, int n_fft,
+                                                   const cf* __restrict__ wroot, int skip_base) {
+    const int n2 = blockIdx.x * 256 + threadIdx.x;
+    const int k1o = blockIdx.y & 255;
+    float2* w = work + ((long long)blockIdx.y * 16 * N2 + n2) * 2;
+    // W_N^{(N2 a + n2) k1o} = W_N^{n2 k1o} * W_4096^{a k1o}      (N / N2 = 4096)
+    cf base;
+    {
+        float s, c;
+        sincospif(-2.0f * (float)(n2 * k1o) / (float)n_fft, &s, &c);
+        base = skip_base ? make_float2(1.f, 0.f) : make_float2(c, s);   // (fused: done in the row pass)
+    }
+    c2 v[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) v[a] = ld_int(w + (long long)a * N2 * 2);
+    if (FWD) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = twmul<-1>(v[a], cmul(base, wroot[(a * k1o) & 4095]));
+        radix16<-1>(v);
+    } else {
+        radix16<+1>(v);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = twmul<+1>(v[a], cmul(base, wroot[(a * k1o) & 4095]));
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) st_int(w + (long long)a * N2 * 2, v[a]);
+}
+
 // Row pass: for row k1 of a (block, pair): four-step twiddle, forward FFT
 // over n2, multiply by the response, inverse FFT over k2, conjugate twiddle.
 //   wroot : W_4096^m, m in [0, 4096)
@@ -274,14 +380,21 @@ template <int N2, int NCH>
 __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
-    const cf* __restrict__ tw1, const cf* __restrict__ wroot, OsmChunk ch) {
+    const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
+    OsmChunk ch, int outer) {
+    // Three-level transforms (N > 2^20) run this pass once per row k1o of the
+    // outer 256-point level: blockIdx.y = (block * npair + pair) * outer + k1o;
+    // the full frequency index is k = k1o + outer * (k1 + N1 * k2).  outer == 1
+    // is the plain two-level case.
     typedef FftGeo<N2> G;
     constexpr int T = G::T;
     constexpr int IMOFF = BBT_ROWPASS_TWO_REGIONS ? G::LDS_ELEMS : 0;
     __shared__ v2 lds[G::LDS_ELEMS + IMOFF];
     const int tau = threadIdx.x;
     const int k1 = blockIdx.x;
-    const int sp = blockIdx.y % npair;
+    const int k1o = blockIdx.y % outer;
+    const int bp = blockIdx.y / outer;            // block * npair + pair
+    const int sp = bp % npair;
     float2* row = work + (((long long)blockIdx.y * N1 + k1) * N2) * 2;
     c2 v[16];
 #pragma unroll
@@ -304,17 +417,20 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
     wg_fft<N2, -1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
     {
         const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
-        const cf* h0 = resp + ((long long)c0 * N1 + k1) * N2 + tau;
-        const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2 + tau;
+        const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
+        const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
         apply_resp<T>(v, h0, h1, c0 == c1);
     }
     if constexpr (NCH > 0) {
-        const int shift = ch.b[blockIdx.y / npair].shift;
+        const int shift = ch.b[bp / npair].shift;
         if (shift != 0) {
-            // ramp exp(+2 pi i k shift / N), k = k1 + N1 (tau + T j):
-            //   = exp(2 pi i shift (k1 + N1 tau) / N) * exp(2 pi i shift j / 16)
-            const unsigned n_fft = (unsigned)N1 * (unsigned)N2;
-            const unsigned m = ((unsigned)shift * (unsigned)(k1 + N1 * tau)) & (n_fft - 1u);
+            // ramp exp(+2 pi i k shift / N), k = ke + N1e (tau + T j) with
+            // ke = k1o + outer k1, N1e = outer N1, N = N1e N2:
+            //   = exp(2 pi i (shift ke + N1e (shift tau mod N2)) / N) * exp(2 pi i shift j / 16)
+            const unsigned n1e = (unsigned)outer * (unsigned)N1;
+            const unsigned n_fft = n1e * (unsigned)N2;
+            const unsigned a = ((unsigned)shift * (unsigned)tau) & (unsigned)(N2 - 1);
+            const unsigned m = (a * n1e + (unsigned)shift * (unsigned)(k1o + outer * k1)) & (n_fft - 1u);
             float s, c;
             sincospif(2.0f * (float)m / (float)n_fft, &s, &c);
             const cf r0 = make_float2(c, s);
@@ -326,7 +442,22 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
         }
     }
     wg_fft<N2, +1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
-    if (N1 > 1) {
+    if (NCH > 0 && outer > 1) {
+        // Three-level + fused channelizer: the outer four-step twiddle
+        // W_N^{(N2 a + n2) k1o} has a factor that depends on n2; it must act
+        // before the channel FFT, so it is applied here (its a-dependent factor
+        // stays in k_osm_mid16).  W_N^{(tau + T j) k1o} = W_N^{tau k1o} W_65536^{j k1o}.
+        float s, c;
+        sincospif(-2.0f * (float)(tau * k1o) / ((float)outer * (float)N1 * (float)N2), &s, &c);
+        const cf bb = cmul(base, make_float2(c, s));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int x = k1o * j;                          // < 4096
+            const cf wo = cmul(wroot[(x >> 8) * 16], wfine[x & 255]);     // W_65536^x
+            const cf wi = wroot[((k1 * j) & (M - 1)) * rstride];
+            v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
+        }
+    } else if (N1 > 1) {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
             v[j] = twmul<+1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
@@ -420,14 +551,16 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
     for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, va[j]);
 }
 
-// Response H[c][k] (natural FFT order) -> Hperm[c][k1][k2] * scale, k = k1 + N1 k2.
-__global__ void k_permute_resp(const cf* __restrict__ h, cf* __restrict__ hp, int N1, long long N2,
-                               float scale) {
-    const long long n = (long long)N1 * N2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // k1*N2 + k2
+// Response H[c][k] (natural FFT order) -> Hperm[c][k1o][k1][k2] * scale with
+// k = k1o + outer * (k1 + N1 * k2)  (outer == 1: two-level layout [c][k1][k2]).
+__global__ void k_permute_resp(const cf* __restrict__ h, cf* __restrict__ hp, int outer, int N1,
+                               long long N2, float scale) {
+    const long long n = (long long)outer * N1 * N2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const long long k1 = idx / N2, k2 = idx % N2;
-    const cf x = h[(long long)blockIdx.y * n + k1 + N1 * k2];
+    const long long k2 = idx % N2, r = idx / N2;
+    const long long k1 = r % N1, k1o = r / N1;
+    const cf x = h[(long long)blockIdx.y * n + k1o + outer * (k1 + N1 * k2)];
     hp[(long long)blockIdx.y * n + idx] = make_float2(x.x * scale, x.y * scale);
 }
 

@@ -4,8 +4,8 @@ The reference lets tasks pick an FFT engine through the `fft_maker` state
 (baseband_tasks/fourier/base.py:348-466) and asks the engine for
 ``next_fast_len`` when sizing overlap-save blocks (base.py:757-758).  This
 package has a single engine, the hand-written gfx950 FFT inside
-libbbt_hip.so.  Its fast lengths are powers of two; block lengths above
-2^20 are not supported yet.
+libbbt_hip.so.  Its fast lengths are powers of two, up to 2^24 for
+overlap-save blocks.
 """
 import operator
 
@@ -16,7 +16,7 @@ __all__ = ['HipFFTMaker', 'fft_maker', 'FFT_MAKER_CLASSES']
 FFT_MAKER_CLASSES = {}
 
 MIN_FFT_LEN = 256
-MAX_BLOCK_LEN = 1 << 20
+MAX_BLOCK_LEN = 1 << 24
 MAX_WG_FFT_LEN = 4096
 
 

@@ -47,7 +47,7 @@ class PolyphaseFilterBank(_RowFFTTask):
     def __init__(self, ih, response, samples_per_frame=None, frequency=None, sideband=None):
         response = np.asanyarray(response)
         n_tap, n = response.shape
-        _check_n(n)
+        _check_n(n, minimum=256)
         if np.dtype(ih.dtype) != np.complex64:
             raise TypeError("the accelerated filter bank handles complex64 streams; "
                             f"got {ih.dtype}.")

@@ -79,7 +79,8 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  * (convolution.py:116-120).
  *
  *   n_fft       block length N (= PaddedTaskBase._ih_samples_per_frame),
- *               a power of two, 256 <= N <= 2^20
+ *               a power of two, 256 <= N <= 2^24 (one kernel up to 4096,
+ *               two-level four-step up to 2^20, three-level above)
  *   n_stream    S, even
  *   n_resp      number of distinct response columns C
  *   resp        C x N complex64, FFT-natural order, UNSCALED
@@ -136,7 +137,7 @@ int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
  * n_chan consecutive complete samples; in (n_spectra*n_chan, S) ->
  * out (n_spectra, n_chan, S).  direction -1: forward, unnormalised
  * (Channelize); +1: inverse, scaled by 1/n_chan (Dechannelize,
- * channelize.py:164-165).  n_chan a power of two, 256..4096. */
+ * channelize.py:164-165).  n_chan a power of two, 2..4096. */
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction);
 int bbt_chan_plan_destroy(bbt_chan_plan* plan);
 int bbt_chan_execute(bbt_chan_plan* plan, const void* in_dev, void* out_dev, int64_t n_spectra,

@@ -44,7 +44,7 @@ def test_argument_validation_reports_errors():
     resp = np.zeros((1, 300), np.complex64)
     assert lib.bbt_osm_plan_create(C.byref(plan), 300, 2, 1, resp.ctypes.data, 0, None) != 0
     assert b'power of two' in lib.bbt_last_error()
-    assert lib.bbt_osm_plan_create(C.byref(plan), 2**21, 2, 1, resp.ctypes.data, 0, None) != 0
+    assert lib.bbt_osm_plan_create(C.byref(plan), 2**25, 2, 1, resp.ctypes.data, 0, None) != 0
     idx = np.array([0, 5], np.int32)
     resp = np.zeros((1, 256), np.complex64)
     assert lib.bbt_osm_plan_create(C.byref(plan), 256, 2, 1, resp.ctypes.data, 0,

@@ -297,6 +297,47 @@ def test_odd_and_multi_axis_streams(sample_shape):
     assert_parity(z, orc.channelize(x[:20 * 256], 256), f'channelize {sample_shape}')
 
 
+@pytest.mark.parametrize('n', [2, 4, 8, 16, 32, 64, 128])
+def test_short_channelizer(n):
+    nh = noise(5000, (2, 2), 1000, seed=21, fs=1 * u.MHz, frequency=np.array([[300.], [301.]]) * u.MHz,
+               sideband=np.array([[1], [-1]]))
+    x = orc.noise_stream(21, 0, 5000, 1000, (2, 2))
+    ch = bt.Channelize(nh, n, samples_per_frame=7)
+    z = ch.read()
+    k = z.shape[0]
+    assert z.shape == (k, n, 2, 2) and k == (5000 // (7 * n)) * 7
+    assert_parity(z, orc.channelize(x[:k * n], n), f'n={n}')
+    np.testing.assert_allclose(ch.frequency / 1e6, orc.channel_frequency(
+        n, 1e6, np.array([[300.], [301.]]), np.array([[1], [-1]]), sample_ndim=2), rtol=1e-15)
+    ch.seek(0)
+    back = bt.Dechannelize(ch).read()
+    assert np.abs(back - x[:k * n]).max() < 1e-5
+
+
+def test_config4_subband_block_2_24():
+    """Config 4 (SURVEY 8d restatement), ONE sub-band: 6.25 MHz at 403.125 MHz,
+    DM 557, blocks of 2^24 samples (three-level transform), then Channelize(64);
+    plain and fused-capable channel counts."""
+    n_fft, spf = 2**24, 2**24 - 2756522
+    n_in = n_fft + 3 * 2**20              # one full block and a re-aligned final one
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((n_in, 4), dtype=np.float32).view(np.complex64)
+    ds = bt.DeviceStream(x, T0, 6.25 * u.MHz, frequency=403.125 * u.MHz, sideband=1)
+    dd = bt.Dedisperse(ds, 557., samples_per_frame=spf)
+    assert (dd._pad_start, dd._pad_end, dd._ih_samples_per_frame) == (1362235, 1394287, n_fft)
+    y = dd.read()
+    want, info = orc.dedisperse(x, 6.25e6, 403.125, 1, 557., samples_per_frame=spf,
+                                ih_samples_per_frame=2**20, fast_len=HipFFTMaker.next_fast_len)
+    assert info['ih_spf'] == n_fft and y.shape == want.shape
+    assert_parity(y, want, 'config 4 sub-band')
+    for n in (64, 4096):
+        dd.seek(0)
+        ch = bt.Channelize(dd, n, samples_per_frame=16)
+        assert (ch._fusable_input() is not None) == (n == 4096)
+        z = ch.read()
+        assert_parity(z, orc.channelize(want[:z.shape[0] * n], n), f'channelize {n}')
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""

@@ -171,10 +171,10 @@ def test_padded_task_base_blocks_like_the_oracle():
     with pytest.warns(UserWarning, match='inefficient'):
         _HostPadded(nh, 30, 30, samples_per_frame=10)
     # next_fast_len table of the hip engine
-    assert [HipFFTMaker.next_fast_len(n) for n in (1, 256, 257, 19324 + 6401, 2**20)] == \
-        [256, 256, 512, 32768, 2**20]
+    assert [HipFFTMaker.next_fast_len(n) for n in (1, 256, 257, 19324 + 6401, 2**20, 2**20 + 1)] == \
+        [256, 256, 512, 32768, 2**20, 2**21]
     with pytest.raises(ValueError):
-        HipFFTMaker.next_fast_len(2**20 + 1)
+        HipFFTMaker.next_fast_len(2**24 + 1)
 
 
 # --------------------------------------------------------------------------- geometry of the GPU tasks vs the reference
@@ -252,6 +252,9 @@ def test_channelize_pfb_resample_geometry(golden):
                                rtol=1e-15)
     with pytest.raises(ValueError):
         bt.Channelize(nh, 1000)
+    assert bt.Channelize(nh, 64).shape == (2 * 2**20 // 64, 64, 2)     # short transforms are fine
+    with pytest.raises(ValueError):
+        bt.Channelize(nh, 8192)
     with pytest.raises(TypeError):
         bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f4'), 256)
     assert bt.Channelize(noise(2**20, (2,), 2**20), 1024).shape == (1024, 1024, 2)   # no metadata needed

@@ -232,6 +232,18 @@ def main():
         check_osm(1 << 20, 2, 32, rng, timing=True)
         check_fused(1 << 20, 2, 32, 1024, rng, timing=True)
         return
+    if '--large' in sys.argv:
+        rng = np.random.default_rng(9)
+        check_osm(1 << 21, 2, 2, rng)
+        check_osm(1 << 21, 4, 2, rng, C_resp=4)
+        check_fused(1 << 21, 2, 2, 512, rng)
+        check_osm(1 << 22, 2, 2, rng)
+        check_fused(1 << 22, 2, 2, 1024, rng)
+        check_osm(1 << 23, 2, 1, rng)
+        check_osm(1 << 24, 2, 2, rng, timing=True)
+        check_fused(1 << 24, 2, 2, 4096, rng, timing=True)
+        print("LARGE OK")
+        return
     if '--fused' in sys.argv:
         rng = np.random.default_rng(8)
         for N, ncs in ((1 << 13, (256, 512)), (1 << 14, (256, 1024)), (1 << 16, (256, 2048, 4096)),
@@ -249,6 +261,9 @@ def main():
     chk(LIB.bbt_device_name(name, 256))
     print("device:", name.value.decode())
     rng = np.random.default_rng(7)
+    for n in (2, 4, 8, 16, 32, 64, 128):
+        check_chan(n, 2, 1000 + n, -1, rng)
+        check_chan(n, 4, 77, +1, rng)
     for n in (256, 512, 1024, 2048, 4096):
         check_chan(n, 2, 37, -1, rng)
     check_chan(1024, 2, 5, +1, rng)
