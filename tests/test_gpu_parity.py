@@ -338,6 +338,33 @@ def test_config4_subband_block_2_24():
         assert_parity(z, orc.channelize(want[:z.shape[0] * n], n), f'channelize {n}')
 
 
+def test_config5_resample_dedisperse_8_streams():
+    """Config 5: Resample(0.25, pad=64) -> Dedisperse(DM=100), 8 streams, 2^20
+    blocks in both stages (two overlap-save stages, as the reference does it)."""
+    n_in = 3 * 2**20
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n_in, 16), dtype=np.float32).view(np.complex64)
+    ds = bt.DeviceStream(x, T0, 16 * u.MHz, samples_per_frame=2**20, frequency=1000 * u.MHz,
+                         sideband=1)
+    rs = bt.Resample(ds, 0.25, pad=64, samples_per_frame=2**20 - 128)
+    assert rs.tell() == -64 and rs._ih_samples_per_frame == 2**20
+    rs.seek(0)
+    dd = bt.Dedisperse(rs, 100., samples_per_frame=2**20 - 212476)
+    assert (dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame) == \
+        (104963, 107513, 2**20, 836100)
+    assert abs((dd.start_time - ds.start_time) * 16e6 - (64 + 0.25 + 104963)) < 1e-6
+    y = dd.read()
+    r, rinfo = orc.resample(x, 0.25, pad=64, samples_per_frame=2**20 - 128,
+                            ih_samples_per_frame=2**20)
+    want, info = orc.dedisperse(r, 16e6, 1000., 1, 100., samples_per_frame=2**20 - 212476,
+                                ih_samples_per_frame=rinfo['spf'])
+    assert y.shape == want.shape == (n_in - 128 - 212476, 8)
+    assert_parity(y, want, 'config 5')
+    # the resampled stream itself
+    rs.seek(1000)
+    assert_parity(rs.read(5000), r[1000:6000], 'resample')
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""
