@@ -828,7 +828,34 @@ struct bbt_pfb_plan {
     int n = 0, S = 0, npair = 0, n_tap = 0;
     float* taps = nullptr;
     FftTables tab;
+    FftTables tab4096;   // for the sliding-window kernel
+    bool window = false;
 };
+
+template <int N, int NTAP>
+static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* out, int64_t n_spec,
+                              hipStream_t st) {
+    constexpr int NG = 4096 / N;
+    const unsigned gx = (unsigned)((n_spec + NG - 1) / NG);
+    hipLaunchKernelGGL((k_pfb_window<N, NTAP>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
+                       (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+}
+
+// sliding-window variants exist for these (n_chan, n_tap)
+static bool pfb_window_dispatch(const bbt_pfb_plan* p, const float2* in, float2* out,
+                                int64_t n_spec, hipStream_t st, bool probe) {
+#define BBT_PW(N_, T_)                                                  \
+    if (p->n == N_ && p->n_tap == T_) {                                 \
+        if (!probe) launch_pfb_window<N_, T_>(p, in, out, n_spec, st);  \
+        return true;                                                    \
+    }
+    BBT_PW(256, 4) BBT_PW(512, 4) BBT_PW(1024, 4) BBT_PW(2048, 4)
+    BBT_PW(256, 8) BBT_PW(512, 8) BBT_PW(1024, 8) BBT_PW(2048, 8)
+    BBT_PW(256, 12) BBT_PW(512, 12) BBT_PW(1024, 12) BBT_PW(2048, 12)
+    BBT_PW(256, 16) BBT_PW(512, 16) BBT_PW(1024, 16) BBT_PW(2048, 16)
+#undef BBT_PW
+    return false;
+}
 
 template <int N>
 static void launch_pfb(const bbt_pfb_plan* p, const float2* in, float2* out, int64_t n_spec,
@@ -856,7 +883,10 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     p->npair = n_stream / 2;
     p->n_tap = n_tap;
     const size_t tb = (size_t)n_tap * n_chan * sizeof(float);
-    if (get_tables(n_chan, &p->tab) || hipMalloc((void**)&p->taps, tb) != hipSuccess ||
+    const char* env = getenv("BBT_PFB_WINDOW");
+    p->window = (!env || atoi(env) != 0) && pfb_window_dispatch(p, nullptr, nullptr, 0, nullptr, true);
+    if ((p->window && get_tables(4096, &p->tab4096)) ||
+        get_tables(n_chan, &p->tab) || hipMalloc((void**)&p->taps, tb) != hipSuccess ||
         hipMemcpy(p->taps, taps_host, tb, hipMemcpyHostToDevice) != hipSuccess) {
         if (g_err.empty()) fail("bbt_pfb_plan_create: tap upload failed");
         bbt_pfb_plan_destroy(p);
@@ -885,6 +915,11 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
         const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
         const int64_t off = s0 * p->n * p->S;
         hipStream_t st = (hipStream_t)stream;
+        if (p->window) {
+            // input of slab s0 starts at spectrum s0 (same offset as the output)
+            pfb_window_dispatch(p, in + off, out + off, ns, st, false);
+            continue;
+        }
         switch (p->n) {
             case 256: launch_pfb<256>(p, in + off, out + off, ns, st); break;
             case 512: launch_pfb<512>(p, in + off, out + off, ns, st); break;

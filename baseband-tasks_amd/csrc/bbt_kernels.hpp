@@ -610,4 +610,86 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
     }
 }
 
+// Polyphase filter bank, register sliding window.  A 256-thread workgroup
+// computes NG = 4096 / N consecutive spectra of one stream pair: thread t owns
+// columns t + 256 c (c < P = N / 256) of every spectrum, keeps the NTAP * P
+// taps of its columns in registers, and streams the NTAP + NG - 1 input rows
+// through once (each row feeds up to NG accumulators) instead of re-reading
+// NTAP rows per spectrum.  The accumulators are then exactly the register
+// layout of the fused channelizer (NG groups of P points), so the FFT is
+// radix-P + the tail of the 4096-point transform.
+template <int N, int NTAP>
+__global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ in,
+                                                    float2* __restrict__ out, long long n_spec,
+                                                    int S, const float* __restrict__ taps,
+                                                    const cf* __restrict__ tw0,
+                                                    const cf* __restrict__ tw1) {
+    typedef FftGeo<4096> G;
+    constexpr int T = 256;
+    constexpr int NG = 4096 / N;       // spectra per workgroup
+    constexpr int P = 16 / NG;         // columns per thread
+    __shared__ v2 lds[G::LDS_ELEMS];
+    const int tau = threadIdx.x;
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const long long i0 = (long long)(vb / npair) * NG;      // first spectrum of this workgroup
+    const int sp = vb % npair;
+    float h[NTAP][P];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int c = 0; c < P; ++c) h[t][c] = taps[t * N + tau + T * c];
+    c2 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = czero();
+    const long long rows_left = n_spec + NTAP - 1 - i0;     // input rows that exist from i0 on
+    const float2* src = in + ((i0 * N + tau) * S + 2 * sp);
+#pragma unroll
+    for (int r = 0; r < NTAP + NG - 1; ++r) {
+        if (r < rows_left) {
+            c2 x[P];
+#pragma unroll
+            for (int c = 0; c < P; ++c) x[c] = ld_ext(src + ((long long)r * N + T * c) * S);
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const int t = r - q;                          // tap index for spectrum i0 + q
+                if (t >= 0 && t < NTAP) {
+#pragma unroll
+                    for (int c = 0; c < P; ++c) {
+                        v[q * P + c].re += x[c].re * h[t][c];
+                        v[q * P + c].im += x[c].im * h[t][c];
+                    }
+                }
+            }
+        }
+    }
+    // FFT over the columns of each spectrum: radix-P, twiddle W_N^{tau c}, tail
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        if constexpr (P > 1) {
+            c2 t[P];
+#pragma unroll
+            for (int c = 0; c < P; ++c) t[c] = v[q * P + c];
+            radixR<-1, P>(t);
+#pragma unroll
+            for (int c = 0; c < P; ++c) v[q * P + c] = t[c];
+        }
+    }
+#pragma unroll
+    for (int c = 1; c < P; ++c) {
+        const cf w = tw0[(c * NG) * T + tau];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
+    }
+    wg_fft_tail<4096, -1, false>(v, lds, tau, 0, tw1);
+    const int f = tau & 15, g = tau >> 4;
+    const int q = f / P, c = f - q * P;
+    if (i0 + q < n_spec) {
+        float2* dst = out + (((i0 + q) * N + c) * S + 2 * sp);
+#pragma unroll
+        for (int c2i = 0; c2i < 16; ++c2i)
+            st_ext(dst + (long long)(P * (g + 16 * c2i)) * S, v[c2i]);
+    }
+}
+
 }  // namespace bbt

@@ -279,6 +279,11 @@ def main():
     check_osm(1 << 17, 4, 3, rng, C_resp=4)
     check_pfb(1024, 2, 12, 21, rng)
     check_pfb(256, 4, 4, 50, rng)
+    check_pfb(512, 2, 8, 13, rng)
+    check_pfb(2048, 2, 16, 7, rng)
+    check_pfb(2048, 2, 12, 5, rng)
+    check_pfb(4096, 2, 12, 3, rng)
+    check_pfb(1024, 6, 5, 9, rng)
     if big:
         check_osm(1 << 20, 2, 3, rng)
         check_osm(1 << 20, 2, 32, rng, timing=True)
