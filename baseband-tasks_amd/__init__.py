@@ -1,7 +1,8 @@
 """baseband_tasks_amd: MI355X-native coherent dedispersion and channelization
 behind the stream-reader interface of mhvk/baseband-tasks.
 
-Only the dedispersion -> channelizer hot path is provided;
+The dedispersion -> channelizer hot path and its immediate neighbours
+(detection, integration) are provided;
 every task here runs hand-written gfx950 kernels through libbbt_hip.so and
 raises if that library is missing -- there is no CPU fallback.
 """
@@ -17,6 +18,8 @@ from .convolution import Convolve
 from .sampling import ShiftAndResample, Resample
 from .channelize import Channelize, Dechannelize
 from .pfb import sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples
+from .functions import Square, Power
+from .integration import Integrate
 from . import hip
 
 __version__ = '0.1.0'

@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 103
+#define BBT_VERSION 104
 
 // ---------------------------------------------------------------------------
 // errors
@@ -934,3 +934,32 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// detection + integration
+extern "C" int bbt_detect_integrate(const void* in_dev, void* out_dev, int64_t n_out, int64_t step,
+                                    int64_t n_elem, int mode, int average, bbt_stream stream) {
+    ARG_TRY(in_dev && out_dev, "bbt_detect_integrate: null argument");
+    ARG_TRY(n_out >= 0 && step >= 1 && n_elem >= 1, "bbt_detect_integrate: bad sizes");
+    ARG_TRY(mode >= 0 && mode <= 2, "bbt_detect_integrate: mode must be 0 (square), 1 (power) or 2 (sum)");
+    ARG_TRY(mode != 1 || n_elem % 2 == 0,
+            "bbt_detect_integrate: power needs (X, Y) pairs, n_elem=%lld is odd", (long long)n_elem);
+    if (n_out == 0) return 0;
+    const long long q = mode == 1 ? n_elem / 2 : n_elem;
+    const long long tiles = (q + 255) / 256;
+    ARG_TRY(n_out * tiles < (1ll << 31), "bbt_detect_integrate: too many output elements for one call");
+    const float scale = average ? 1.0f / (float)step : 1.0f;
+    const dim3 grid((unsigned)(n_out * tiles)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0)
+        hipLaunchKernelGGL((k_detect_integrate<0>), grid, block, 0, st, in_dev, out_dev,
+                           (long long)n_out, (long long)step, q, scale);
+    else if (mode == 1)
+        hipLaunchKernelGGL((k_detect_integrate<1>), grid, block, 0, st, in_dev, out_dev,
+                           (long long)n_out, (long long)step, q, scale);
+    else
+        hipLaunchKernelGGL((k_detect_integrate<2>), grid, block, 0, st, in_dev, out_dev,
+                           (long long)n_out, (long long)step, q, scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -692,4 +692,52 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
     }
 }
 
+// ---------------------------------------------------------------------------
+// Detection + integration (reference functions.py:15-16, 131-143 and
+// integration.py:252-303 for an integer step): out[i] = scale * sum over the
+// `step` input samples [i*step, (i+1)*step) of
+//   MODE 0  |z|^2 per complex element            (Square)   float2 -> float
+//   MODE 1  |X|^2, |Y|^2, Re X Y*, Im X Y*        (Power)    float4 (X, Y) -> float4
+//   MODE 2  the element itself                    (Integrate of a real stream) float -> float
+// `q` = elements per complete sample in units of the mode's input type.  The
+// sum runs sequentially in time, in float32, like np.add.reduceat along axis 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_detect_integrate(const void* __restrict__ in_,
+                                                          void* __restrict__ out_, long long n_out,
+                                                          long long step, long long q, float scale) {
+    const long long tiles = (q + 255) / 256;
+    const long long tile = (long long)blockIdx.x;
+    const long long i = tile / tiles;
+    const long long e = (tile - i * tiles) * 256 + threadIdx.x;
+    if (i >= n_out || e >= q) return;
+    const long long first = i * step * q + e;
+    if (MODE == 0) {
+        const float2* in = (const float2*)in_ + first;
+        float acc = 0.f;
+        for (long long s = 0; s < step; ++s) {
+            const float2 z = in[s * q];
+            acc += z.x * z.x + z.y * z.y;
+        }
+        ((float*)out_)[i * q + e] = acc * scale;
+    } else if (MODE == 1) {
+        const float4* in = (const float4*)in_ + first;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (long long s = 0; s < step; ++s) {
+            const float4 z = in[s * q];              // X = (x, y), Y = (z, w)
+            acc.x += z.x * z.x + z.y * z.y;
+            acc.y += z.z * z.z + z.w * z.w;
+            acc.z += z.x * z.z + z.y * z.w;
+            acc.w += z.y * z.z - z.x * z.w;
+        }
+        ((float4*)out_)[i * q + e] =
+            make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
+    } else {
+        const float* in = (const float*)in_ + first;
+        float acc = 0.f;
+        for (long long s = 0; s < step; ++s) acc += in[s * q];
+        ((float*)out_)[i * q + e] = acc * scale;
+    }
+}
+
 }  // namespace bbt

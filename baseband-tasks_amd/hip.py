@@ -68,6 +68,7 @@ SIGNATURES = {
     'bbt_pfb_plan_create': [_pvp, _int, _int, _int, C.POINTER(C.c_float)],
     'bbt_pfb_plan_destroy': [_vp],
     'bbt_pfb_execute': [_vp, _vp, _vp, _i64, _vp],
+    'bbt_detect_integrate': [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp],
 }
 
 _lib = None
@@ -329,6 +330,12 @@ def strip_stream_pad(dev_padded, n_rows, n_stream, out):
         check(lib().bbt_memcpy2d(out.ptr, n_stream * isz, dev_padded.ptr, (n_stream + 1) * isz,
                                  n_stream * isz, n_rows, 2, _stream))
     return out
+
+
+def detect_integrate(in_dev, out_dev, n_out, step, n_elem, mode, average=True):
+    """Square (mode 0) / Power (1) / plain sum (2) over ``step`` samples."""
+    check(lib().bbt_detect_integrate(in_dev.ptr, out_dev.ptr, int(n_out), int(step), int(n_elem),
+                                     int(mode), int(bool(average)), _stream))
 
 
 class _Plan:

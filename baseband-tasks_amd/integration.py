@@ -1,0 +1,93 @@
+"""Stepwise integration on the GPU (reference baseband_tasks/integration.py:
+52-303, the integer-``step`` case)."""
+import operator
+
+import numpy as np
+
+from . import hip, units as u
+from .base import BaseTaskBase, _stream_rate, _stream_start
+from .device_task import DeviceTaskMixin, fetch_device
+from .functions import _DetectTask
+
+__all__ = ['Integrate']
+
+
+def _prod(shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n
+
+
+class Integrate(DeviceTaskMixin, BaseTaskBase):
+    """Integrate a stream over ``step`` consecutive samples.
+
+    Parameters
+    ----------
+    ih : stream
+        float32 (e.g. the output of `Square` / `Power`) or complex64.
+    step : int, optional
+        Input samples per output sample; default: everything from ``start``.
+        (Integration in time or pulse-phase units, i.e. non-integer steps and
+        the ``phase`` callable of the reference, is outside the accelerated
+        path.)
+    start : int or `~baseband_tasks_amd.units.Time`
+        Offset (or time, rounded to the nearest sample) of the first sample.
+    average : bool
+        Only averaging is supported here (the reference's ``average=False``
+        returns a structured array of sums and counts).
+    samples_per_frame : int
+        Output samples per frame (framing only).
+    dtype : optional, must equal the input dtype.
+
+    When ``ih`` is a GPU `Square` or `Power`, detection and integration run as
+    one kernel on the undetected stream (the detected stream is never stored).
+    """
+    max_frames_per_call = 1 << 16
+
+    def __init__(self, ih, step=None, phase=None, *, start=0, average=True,
+                 samples_per_frame=1, dtype=None):
+        if phase is not None:
+            raise NotImplementedError("integration in pulse phase is outside the accelerated path.")
+        if not average:
+            raise NotImplementedError("only average=True is accelerated.")
+        ih_start = ih.seek(start)
+        ih_n = ih.shape[0] - ih_start
+        if ih_start < 0 or ih_n < 0:
+            raise ValueError("'start' is not within the underlying stream.")
+        if step is None:
+            step = ih_n
+        try:
+            step = operator.index(step)
+        except TypeError:
+            raise NotImplementedError("integration over time intervals (non-integer step) is "
+                                      "outside the accelerated path.") from None
+        in_dtype = np.dtype(ih.dtype)
+        if in_dtype not in (np.dtype(np.float32), np.dtype(np.complex64)):
+            raise TypeError(f"the accelerated Integrate handles float32/complex64; got {in_dtype}.")
+        if dtype is not None and np.dtype(dtype) != in_dtype:
+            raise TypeError("the accelerated Integrate keeps the input dtype.")
+        n_out = int(ih_n / step + 0.5 / step)
+        assert n_out >= 1, "time per frame larger than total time in stream"
+        rate = _stream_rate(ih)
+        self._step, self._ih_start = step, ih_start
+        self.average = average
+        super().__init__(ih, shape=(n_out,) + tuple(ih.shape[1:]), sample_rate=rate / step,
+                         samples_per_frame=samples_per_frame,
+                         start_time=_stream_start(ih) + ih_start / rate, dtype=in_dtype)
+
+    def _compute_frames(self, first, last, out):
+        a, b = self._frame_span(first, last)
+        n_out, step = b - a, self._step
+        src = self.ih
+        if isinstance(src, _DetectTask) and not src.closed:
+            x = fetch_device(src.ih, self._ih_start + a * step, n_out * step)
+            src._detect(x, n_out, step, out, self.average)
+            return
+        x = fetch_device(src, self._ih_start + a * step, n_out * step)
+        n_float = _prod(self.sample_shape) * (2 if self.dtype.kind == 'c' else 1)
+        hip.detect_integrate(x, out, n_out, step, n_float, 2, self.average)
+
+    def close(self):
+        super().close()
+        self._drop_cache()

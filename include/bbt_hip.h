@@ -154,6 +154,18 @@ int bbt_pfb_plan_destroy(bbt_pfb_plan* plan);
 int bbt_pfb_execute(bbt_pfb_plan* plan, const void* in_dev, void* out_dev, int64_t n_spectra,
                     bbt_stream stream);
 
+/* ---- detection and integration -------------------------------------------
+ * Replaces Square.task / Power.task (functions.py:15-16, 131-143) and, for an
+ * integer step, Integrate._read_frame (integration.py:252-303), in one pass:
+ * out[i] = (average ? 1/step : 1) * sum_{s<step} f(in[i*step + s]).
+ *   mode 0  f = |z|^2 per complex element: in (n_out*step, n_elem) complex64,
+ *           out (n_out, n_elem) float32
+ *   mode 1  f = |X|^2, |Y|^2, Re(X Y*), Im(X Y*) for consecutive (X, Y) element
+ *           pairs: out (n_out, n_elem/2, 4) float32
+ *   mode 2  f = identity on float32 elements: in (n_out*step, n_elem) float32 */
+int bbt_detect_integrate(const void* in_dev, void* out_dev, int64_t n_out, int64_t step,
+                         int64_t n_elem, int mode, int average, bbt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

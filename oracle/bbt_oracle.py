@@ -466,3 +466,41 @@ def resample(x, offset, pad=64, samples_per_frame=None,
     info['start_shift_samples'] = geo['pad_start'] + float(d_time)
     info['pointer'] = int(round(offset - info['start_shift_samples']))
     return y, info
+
+
+# --------------------------------------------------------------------------
+# functions.py:15-56, 59-143 ; integration.py:52-303 (integer step only)
+def square(x):
+    """Square.task (functions.py:15-16, 38-44): re^2 + im^2 for complex input
+    (output real dtype), x^2 for real input."""
+    if x.dtype.kind == 'c':
+        return np.square(x.real) + np.square(x.imag)
+    return np.square(x)
+
+
+def power(x, axis=-1):
+    """Power.task (functions.py:131-143): along the polarization axis (length
+    2 -> 4): |X|^2, |Y|^2, Re(X Y*), Im(X Y*)."""
+    xin = np.moveaxis(x, axis, 0)
+    out = np.empty((4,) + xin.shape[1:], x.real.dtype)
+    out[0] = square(xin[0])
+    out[1] = square(xin[1])
+    c = xin[0] * xin[1].conj()
+    out[2] = c.real
+    out[3] = c.imag
+    return np.moveaxis(out, 0, axis)
+
+
+def integrate(x, step, start=0, average=True):
+    """Integrate(ih, step, start=start).read() for integer ``step``
+    (integration.py:116-130, 252-303): bins of ``step`` consecutive samples
+    from ``start``; a trailing partial bin is dropped; sums are accumulated in
+    the input dtype, divided by the count if ``average``."""
+    n_out = int((x.shape[0] - start) / step + 0.5 / step)
+    seg = x[start:start + n_out * step].reshape((n_out, step) + x.shape[1:])
+    acc = np.zeros((n_out,) + x.shape[1:], x.dtype)
+    for k in range(step):            # sequential accumulation, as np.add.reduceat along axis 0
+        acc += seg[:, k]
+    if average:
+        acc /= step
+    return acc

@@ -35,6 +35,8 @@ from baseband_tasks.pfb import (sinc_hamming, PolyphaseFilterBank,  # noqa: E402
                                 PolyphaseFilterBankSamples)
 from baseband_tasks.convolution import Convolve                   # noqa: E402
 from baseband_tasks.sampling import Resample                      # noqa: E402
+from baseband_tasks.functions import Square, Power               # noqa: E402
+from baseband_tasks.integration import Integrate                 # noqa: E402
 
 fft_maker.set('numpy')
 T0 = Time('2020-01-01T00:00:00', precision=9)
@@ -46,6 +48,11 @@ def noise(shape, fs, spf, frequency=None, sideband=None, seed=SEED):
     if frequency is not None:
         kw = dict(frequency=frequency, sideband=sideband)
     return NoiseGenerator(shape, T0, fs, spf, dtype=np.complex64, seed=seed, **kw)
+
+
+def SetPol(nh):
+    from baseband_tasks.base import SetAttribute
+    return SetAttribute(nh, polarization=np.array(['X', 'Y']))
 
 
 def stats(a):
@@ -240,6 +247,27 @@ def main():
     g, shift = geometry(dd, rs)
     out['sj_geo'] = g
     out['sj_out'] = dd.read()
+
+    # ---- detection and integration (functions.py, integration.py), small complete outputs
+    nh = noise((40 * 256, 2), 1. * u.MHz, 2560, 300. * u.MHz, 1, seed=17)
+    nh = SetPol(nh)
+    ch = Channelize(nh, 256, samples_per_frame=4)
+    sq = Square(ch)
+    out['sk_square'] = sq.read()
+    out['sk_square_pol'] = np.array([str(p) for p in sq.polarization.ravel()])
+    ch.seek(0)
+    pw = Power(ch)
+    out['sk_power'] = pw.read()
+    out['sk_power_pol'] = np.array([str(p) for p in pw.polarization.ravel()])
+    for tag, kw in (('a', dict(step=8)), ('b', dict(step=5, start=3)), ('c', dict())):
+        pw.seek(0)
+        it = Integrate(pw, **kw)
+        out['sk_int_%s' % tag] = it.read()
+        out['sk_int_%s_meta' % tag] = np.array([it.shape[0], it.sample_rate.to_value(u.Hz),
+                                               ((it.start_time - nh.start_time)
+                                                * nh.sample_rate).to_value(u.one)])
+    sq.seek(0)
+    out['sk_int_sq'] = Integrate(sq, 4, samples_per_frame=3).read()
 
     # ---- config 5 geometry: Resample + Dedisperse, 8 streams
     nh = noise((8 * 2**20, 8), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)

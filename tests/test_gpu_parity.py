@@ -365,6 +365,62 @@ def test_config5_resample_dedisperse_8_streams():
     assert_parity(rs.read(5000), r[1000:6000], 'resample')
 
 
+def _close(got, want, rtol=2e-6):
+    """float32 detection/integration vs the float32 oracle: relative to the
+    typical magnitude (cross terms pass through zero)."""
+    assert got.shape == want.shape and got.dtype == want.dtype == np.float32
+    scale = np.sqrt(np.mean(want.astype(np.float64) ** 2))
+    assert np.abs(got.astype(np.float64) - want).max() <= rtol * scale * 8, \
+        np.abs(got.astype(np.float64) - want).max() / scale
+
+
+def test_square_power_integrate_golden(golden):
+    nh = noise(40 * 256, (2,), 2560, seed=17, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1,
+               polarization=['X', 'Y'])
+    ch = bt.Channelize(nh, 256, samples_per_frame=4)
+    sq = bt.Square(ch)
+    assert list(sq.polarization) == list(golden['sk_square_pol'])
+    _close(sq.read(), golden['sk_square'])
+    ch.seek(0)
+    pw = bt.Power(ch)
+    assert list(pw.polarization) == list(golden['sk_power_pol']) and pw.shape == (40, 256, 4)
+    _close(pw.read(), golden['sk_power'])
+    for tag, kw in (('a', dict(step=8)), ('b', dict(step=5, start=3)), ('c', dict())):
+        it = bt.Integrate(pw, **kw)
+        meta = golden['sk_int_%s_meta' % tag]
+        assert it.shape[0] == meta[0] and abs(it.sample_rate - meta[1]) < 1e-9
+        assert abs((it.start_time - nh.start_time) * 1e6 - meta[2]) < 1e-3
+        _close(it.read(), golden['sk_int_%s' % tag], rtol=1e-5)
+    _close(bt.Integrate(sq, 4, samples_per_frame=3).read(), golden['sk_int_sq'], rtol=1e-5)
+    # un-fused route (Integrate of an already detected float stream) agrees
+    pw.seek(0)
+    det = bt.DeviceStream(pw.read(), T0, pw.sample_rate)
+    _close(bt.Integrate(det, 8).read(), golden['sk_int_a'], rtol=1e-5)
+    # complex input is integrated as it is
+    nh.seek(0)
+    got = bt.Integrate(nh, 10).read()
+    x = orc.noise_stream(17, 0, 40 * 256, 2560, (2,))
+    assert np.abs(got - orc.integrate(x, 10)).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        bt.Integrate(pw, 0.1 * u.s)
+    with pytest.raises(ValueError):
+        bt.Power(nh, polarization=['a', 'b', 'c', 'c'])
+
+
+def test_metric_pipeline_with_detection():
+    """Dedisperse -> Channelize -> Power -> Integrate at config-2 geometry."""
+    nh = noise(3 * 2**20, (2,), 2**20, frequency=1000 * u.MHz, sideband=1, polarization=['X', 'Y'])
+    ds = bt.DeviceStream(nh, T0, 16 * u.MHz)
+    it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds, 100.), 1024, 64)), 16, samples_per_frame=8)
+    got = it.read()
+    x = orc.noise_stream(12345, 0, 3 * 2**20, 2**20, (2,))
+    y, _ = orc.dedisperse(x, 16e6, 1000., 1, 100., ih_samples_per_frame=2**20)
+    z = orc.channelize(y[:(y.shape[0] // (1024 * 64)) * 1024 * 64], 1024)
+    want = orc.integrate(orc.power(z), 16)
+    assert got.shape == want.shape == (z.shape[0] // 16, 1024, 4)
+    _close(got, want, rtol=1e-5)
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""

@@ -246,3 +246,25 @@ def test_config5_geometry(golden):
     assert [g['pad_start'], g['pad_end'], geo['ih_spf'], geo['spf'], geo['n_out'], 0] == \
         list(golden['c5_dd_geo'])
     assert abs(64 + 0.25 + g['pad_start'] - golden['c5_dd_shift'][0]) < 1e-3
+
+
+def test_square_power_integrate(golden):
+    """functions.py / integration.py known answers from the reference."""
+    x = orc.noise_stream(17, 0, 40 * 256, 2560, (2,))
+    z = orc.channelize(x, 256)
+    assert np.allclose(orc.square(z), golden['sk_square'], rtol=3e-6, atol=1e-4)
+    pw = orc.power(z)
+    assert pw.shape == golden['sk_power'].shape and pw.dtype == np.float32
+    assert np.allclose(pw, golden['sk_power'], rtol=3e-6, atol=1e-3)
+    for tag, kw, n_out, rate, shift in (('a', dict(step=8), 5, 1e6 / 256 / 8, 0.),
+                                        ('b', dict(step=5, start=3), 7, 1e6 / 256 / 5, 768.),
+                                        ('c', dict(step=40), 1, 1e6 / 256 / 40, 0.)):
+        got = orc.integrate(pw, **kw)
+        want = golden['sk_int_%s' % tag]
+        assert got.shape == want.shape and got.shape[0] == n_out
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-3), tag
+        meta = golden['sk_int_%s_meta' % tag]
+        assert meta[0] == n_out and abs(meta[1] - rate) < 1e-9 and abs(meta[2] - shift) < 1e-3
+    assert np.allclose(orc.integrate(orc.square(z), 4), golden['sk_int_sq'], rtol=1e-5, atol=1e-3)
+    assert list(golden['sk_power_pol']) == ['XX', 'YY', 'XY', 'YX']
+    assert list(golden['sk_square_pol']) == ['XX', 'YY']
