@@ -414,13 +414,11 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
         for (int j = 0; j < 16; ++j)
             v[j] = twmul<-1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
     }
+    const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
+    const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
+    const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
     wg_fft<N2, -1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
-    {
-        const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
-        const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
-        const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
-        apply_resp<T>(v, h0, h1, c0 == c1);
-    }
+    apply_resp<T>(v, h0, h1, c0 == c1);
     if constexpr (NCH > 0) {
         const int shift = ch.b[bp / npair].shift;
         if (shift != 0) {

@@ -186,7 +186,9 @@ __device__ __forceinline__ int lds_idx(int inner, int f) {
     return COLMODE ? inner * 16 + f : inner;
 }
 
-// One workgroup-cooperative FFT of both streams of a pair.
+// One workgroup-cooperative FFT of both streams of a pair, as building blocks
+// (so a kernel can issue the table loads of a later stage before the LDS
+// exchange of an earlier one) and composed as wg_fft / wg_fft_tail.
 //   v[j]  : element tau + T*j of this thread's transform (both streams)
 //   lds   : exchange area, LDS_ELEMS v2 per transform (x16 in COLMODE).
 //           IMOFF == 0: the real and the imaginary pairs go through it one
@@ -195,25 +197,34 @@ __device__ __forceinline__ int lds_idx(int inner, int f) {
 //   tau   : thread index within the transform (0..T-1)
 //   f     : transform lane within a COLMODE group (0..15), ignored otherwise
 //   tw0   : [16][T] forward twiddles W_N^{tau c0};  tw1: [16][R2] W_T^{b1 c1}
-// All threads of the workgroup must call this together (it uses __syncthreads).
-//
-// wg_fft_tail is everything after stage 0: given y[c0][b] (thread b = tau,
-// register c0, already twiddled) it computes the T-point transform over b of
-// each of the 16 sequences c0.  On return thread tau2 holds, in register
-// u + (16/R2) * c2, output k' = c1 + 16 * c2 (c1 = (tau2 >> 4) + R2 * u) of
-// sequence c0 = tau2 & 15 -- for the full transform that is element
-// tau2 + T * register (k = c0 + 16 k').  The fused channelizer enters here
-// with its own stage 0 (fft radix-P per group, see k_osm_rowpass).
-template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
-__device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
-                                            const cf* __restrict__ tw1) {
+// All threads of the workgroup must call the exchanges together (__syncthreads).
+
+// twiddles of stage 0 (index c-1 holds W_N^{tau c}) and stage 1 (W_T^{b1 c})
+template <int N>
+__device__ __forceinline__ void fft_load_tw0(cf (&w)[15], const cf* __restrict__ tw0, int tau) {
+#pragma unroll
+    for (int c = 1; c < 16; ++c) w[c - 1] = tw0[c * FftGeo<N>::T + tau];
+}
+template <int N>
+__device__ __forceinline__ void fft_load_tw1(cf (&w)[15], const cf* __restrict__ tw1, int tau) {
+    constexpr int R2 = FftGeo<N>::R2;
+#pragma unroll
+    for (int c = 1; c < 16; ++c) w[c - 1] = (R2 > 1) ? tw1[c * R2 + tau % R2] : make_float2(1.f, 0.f);
+}
+template <int SIGN>
+__device__ __forceinline__ void fft_butterfly_twiddle(c2 (&v)[16], const cf (&w)[15]) {
+    radix16<SIGN>(v);
+#pragma unroll
+    for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], w[c - 1]);
+}
+
+// exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
+template <int N, bool COLMODE, int IMOFF>
+__device__ __forceinline__ void fft_exchange0(c2 (&v)[16], v2* __restrict__ lds, int tau, int f) {
     typedef FftGeo<N> G;
     constexpr int R2 = G::R2;
-    const int c0s = tau / R2;  // stage-1 role
-    const int b1 = tau % R2;
+    const int c0s = tau / R2, b1 = tau % R2;
     v2* __restrict__ lds_im = lds + IMOFF;
-
-    // ---- exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].re;
@@ -232,15 +243,19 @@ __device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, i
     }
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a].im = lds_im[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
-    // ---- stage 1
-    radix16<SIGN>(v);
+}
+
+// exchange 1: (c0, c1, b1) -> thread (c0 + 16 g), c1 = g + R2 u ; then the
+// radix-R2 stage.  No-op for N == 256.
+template <int N, int SIGN, bool COLMODE, int IMOFF>
+__device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict__ lds, int tau, int f) {
+    typedef FftGeo<N> G;
+    constexpr int R2 = G::R2;
     if constexpr (R2 > 1) {
-#pragma unroll
-        for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], tw1[c * R2 + b1]);
-        // ---- exchange 1: (c0, c1, b1) -> thread (c0 + 16 g), c1 = g + R2 u ; then stage 2
         constexpr int NU = 16 / R2;
-        const int c0r = tau & 15;
-        const int g = tau >> 4;
+        const int c0s = tau / R2, b1 = tau % R2;
+        const int c0r = tau & 15, g = tau >> 4;
+        v2* __restrict__ lds_im = lds + IMOFF;
         c2 t[NU][R2];
         __syncthreads();
 #pragma unroll
@@ -277,14 +292,33 @@ __device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, i
     }
 }
 
+// wg_fft_tail is everything after stage 0: given y[c0][b] (thread b = tau,
+// register c0, already twiddled) it computes the T-point transform over b of
+// each of the 16 sequences c0.  On return thread tau2 holds, in register
+// u + (16/R2) * c2, output k' = c1 + 16 * c2 (c1 = (tau2 >> 4) + R2 * u) of
+// sequence c0 = tau2 & 15 -- for the full transform that is element
+// tau2 + T * register (k = c0 + 16 k').  The fused channelizer and the PFB
+// enter here with their own stage 0.
+template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
+__device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
+                                            const cf* __restrict__ tw1) {
+    fft_exchange0<N, COLMODE, IMOFF>(v, lds, tau, f);
+    if constexpr (FftGeo<N>::R2 > 1) {
+        cf w1[15];
+        fft_load_tw1<N>(w1, tw1, tau);
+        fft_butterfly_twiddle<SIGN>(v, w1);
+    } else {
+        radix16<SIGN>(v);
+    }
+    fft_exchange1_stage2<N, SIGN, COLMODE, IMOFF>(v, lds, tau, f);
+}
+
 template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
 __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                        const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
-    constexpr int T = FftGeo<N>::T;
-    // ---- stage 0
-    radix16<SIGN>(v);
-#pragma unroll
-    for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], tw0[c * T + tau]);
+    cf w0[15];
+    fft_load_tw0<N>(w0, tw0, tau);
+    fft_butterfly_twiddle<SIGN>(v, w0);
     wg_fft_tail<N, SIGN, COLMODE, IMOFF>(v, lds, tau, f, tw1);
 }
 
