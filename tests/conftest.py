@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # libbbt_hip.so is built in-tree (git-ignored): build it if this checkout
+    # does not have it yet and hipcc is around.  Never a substitute path: if the
+    # build is impossible the tests that need the library fail.
+    lib = os.path.join(ROOT, 'baseband-tasks_amd', 'lib', 'libbbt_hip.so')
+    if not os.path.exists(lib) and os.path.exists('/opt/rocm/bin/hipcc'):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope='session')
