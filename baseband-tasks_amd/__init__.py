@@ -13,9 +13,9 @@ from .generators import (StreamGenerator, EmptyStreamGenerator, Noise, NoiseGene
                          DeviceStream)
 from .dm import DispersionMeasure
 from .fourier import fft_maker, HipFFTMaker
-from .dispersion import Disperse, Dedisperse
+from .dispersion import Disperse, Dedisperse, DisperseSamples, DedisperseSamples
 from .convolution import Convolve
-from .sampling import ShiftAndResample, Resample
+from .sampling import ShiftAndResample, Resample, ShiftSamples
 from .channelize import Channelize, Dechannelize
 from .pfb import sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples
 from .functions import Square, Power

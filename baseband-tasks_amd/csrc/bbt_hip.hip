@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 104
+#define BBT_VERSION 105
 
 // ---------------------------------------------------------------------------
 // errors
@@ -960,6 +960,63 @@ extern "C" int bbt_detect_integrate(const void* in_dev, void* out_dev, int64_t n
     else
         hipLaunchKernelGGL((k_detect_integrate<2>), grid, block, 0, st, in_dev, out_dev,
                            (long long)n_out, (long long)step, q, scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// integer sample shifts
+struct bbt_shift_plan {
+    int n_elem = 0, elem_bytes = 0;
+    int* offset = nullptr;
+};
+
+extern "C" int bbt_shift_plan_create(bbt_shift_plan** plan, int n_elem, int elem_bytes,
+                                     const int32_t* offsets_host) {
+    ARG_TRY(plan && offsets_host, "bbt_shift_plan_create: null argument");
+    *plan = nullptr;
+    ARG_TRY(n_elem >= 1, "bbt_shift_plan_create: n_elem=%d must be >= 1", n_elem);
+    ARG_TRY(elem_bytes == 4 || elem_bytes == 8, "bbt_shift_plan_create: elem_bytes must be 4 or 8");
+    for (int e = 0; e < n_elem; ++e)
+        ARG_TRY(offsets_host[e] >= 0, "bbt_shift_plan_create: offset[%d]=%d is negative", e,
+                offsets_host[e]);
+    bbt_shift_plan* p = new bbt_shift_plan;
+    p->n_elem = n_elem;
+    p->elem_bytes = elem_bytes;
+    if (hipMalloc((void**)&p->offset, n_elem * sizeof(int)) != hipSuccess ||
+        hipMemcpy(p->offset, offsets_host, n_elem * sizeof(int), hipMemcpyHostToDevice) !=
+            hipSuccess) {
+        fail("bbt_shift_plan_create: uploading the offsets failed");
+        if (p->offset) hipFree(p->offset);
+        delete p;
+        return 1;
+    }
+    *plan = p;
+    return 0;
+}
+
+extern "C" int bbt_shift_plan_destroy(bbt_shift_plan* p) {
+    if (!p) return 0;
+    if (p->offset) hipFree(p->offset);
+    delete p;
+    return 0;
+}
+
+extern "C" int bbt_shift_execute(bbt_shift_plan* p, const void* in_dev, void* out_dev,
+                                 int64_t n_out, bbt_stream stream) {
+    ARG_TRY(p && in_dev && out_dev, "bbt_shift_execute: null argument");
+    ARG_TRY(n_out >= 0, "bbt_shift_execute: n_out < 0");
+    const long long total = (long long)n_out * p->n_elem;
+    if (total == 0) return 0;
+    ARG_TRY((total + 255) / 256 < (1ll << 31), "bbt_shift_execute: too many elements for one call");
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (p->elem_bytes == 8)
+        hipLaunchKernelGGL((k_shift_samples<float2>), grid, block, 0, st, (const float2*)in_dev,
+                           (float2*)out_dev, total, p->n_elem, p->offset);
+    else
+        hipLaunchKernelGGL((k_shift_samples<float>), grid, block, 0, st, (const float*)in_dev,
+                           (float*)out_dev, total, p->n_elem, p->offset);
     HIP_TRY(hipGetLastError());
     return 0;
 }

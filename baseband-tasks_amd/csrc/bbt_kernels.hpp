@@ -738,4 +738,19 @@ __global__ __launch_bounds__(256) void k_detect_integrate(const void* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Per-stream integer sample shifts (reference sampling.py:380-425,
+// ShiftSamples.task: data[self._indices]): out[i, e] = in[i + offset[e], e]
+// for the E elements of a complete sample, offset[e] = shift.max() - shift[e].
+// Element size 4 or 8 bytes; lanes run along the flattened (i, e) index.
+template <typename T>
+__global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in, T* __restrict__ out,
+                                                       long long n_total, int n_elem,
+                                                       const int* __restrict__ offset) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_total) return;
+    const int e = (int)(t % n_elem);
+    out[t] = in[t + (long long)offset[e] * n_elem];
+}
+
 }  // namespace bbt

@@ -11,8 +11,9 @@ from . import units as u
 from .base import getattr_if_none, _stream_rate, _stream_start
 from .dm import DispersionMeasure
 from .overlap_save import SpectralMultiplyTask
+from .sampling import ShiftSamples
 
-__all__ = ['Disperse', 'Dedisperse']
+__all__ = ['Disperse', 'Dedisperse', 'DisperseSamples', 'DedisperseSamples']
 
 
 class Disperse(SpectralMultiplyTask):
@@ -112,6 +113,49 @@ class Disperse(SpectralMultiplyTask):
 class Dedisperse(Disperse):
     """Coherently dedisperse a time stream (reference dispersion.py:149-190);
     parameters as for `Disperse`, with ``dm`` the DM to remove."""
+
+    def __init__(self, ih, dm, *, reference_frequency=None, samples_per_frame=None,
+                 frequency=None, sideband=None):
+        super().__init__(ih, -DispersionMeasure(dm), reference_frequency=reference_frequency,
+                         samples_per_frame=samples_per_frame, frequency=frequency,
+                         sideband=sideband)
+
+    @property
+    def dm(self):
+        return -self._dm
+
+
+class DisperseSamples(ShiftSamples):
+    """Incoherent dispersion: shift every stream by the dispersive delay at its
+    mid-channel frequency, rounded to whole samples (no in-channel smearing;
+    reference dispersion.py:193-250).  Parameters as for `Disperse`."""
+
+    def __init__(self, ih, dm, *, reference_frequency=None, samples_per_frame=None,
+                 frequency=None, sideband=None):
+        if frequency is not None or sideband is not None:
+            from .base import SetAttribute
+            ih = SetAttribute(ih, frequency=frequency, sideband=sideband)
+        frequency = ih.frequency
+        if np.dtype(ih.dtype).kind != 'c':
+            # mid-channel frequency of a real stream
+            frequency = frequency + ih.sideband * _stream_rate(ih) / 2.
+        if reference_frequency is None:
+            reference_frequency = np.mean(frequency)
+        else:
+            reference_frequency = u.to_hz(reference_frequency)
+        dm = DispersionMeasure(dm)
+        delay = dm.time_delay(frequency, reference_frequency)          # seconds
+        super().__init__(ih, delay * _stream_rate(ih), samples_per_frame=samples_per_frame)
+        self.reference_frequency = reference_frequency
+        self._dm = dm
+
+    @property
+    def dm(self):
+        return self._dm
+
+
+class DedisperseSamples(DisperseSamples):
+    """Incoherent dedispersion (reference dispersion.py:253-298)."""
 
     def __init__(self, ih, dm, *, reference_frequency=None, samples_per_frame=None,
                  frequency=None, sideband=None):

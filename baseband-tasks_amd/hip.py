@@ -69,6 +69,9 @@ SIGNATURES = {
     'bbt_pfb_plan_destroy': [_vp],
     'bbt_pfb_execute': [_vp, _vp, _vp, _i64, _vp],
     'bbt_detect_integrate': [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp],
+    'bbt_shift_plan_create': [_pvp, _int, _int, _pi32],
+    'bbt_shift_plan_destroy': [_vp],
+    'bbt_shift_execute': [_vp, _vp, _vp, _i64, _vp],
 }
 
 _lib = None
@@ -453,3 +456,17 @@ class PfbPlan(_Plan):
 
     def execute(self, in_dev, out_dev, n_spectra):
         check(lib().bbt_pfb_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_spectra), _stream))
+
+
+class ShiftPlan(_Plan):
+    """out[i, e] = in[i + offsets[e], e] (per-element integer sample shifts)."""
+    _destroy = 'bbt_shift_plan_destroy'
+
+    def __init__(self, offsets, elem_bytes):
+        super().__init__()
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32).ravel()
+        check(lib().bbt_shift_plan_create(C.byref(self._h), offsets.shape[0], int(elem_bytes),
+                                          offsets.ctypes.data_as(_pi32)))
+
+    def execute(self, in_dev, out_dev, n_out):
+        check(lib().bbt_shift_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_out), _stream))

@@ -3,11 +3,13 @@ the GPU (reference baseband_tasks/sampling.py:63-312)."""
 import numpy as np
 
 from . import units as u
-from .base import check_broadcast_to, _stream_rate, _stream_start
+from . import hip
+from .base import PaddedTaskBase, check_broadcast_to, _stream_rate, _stream_start
+from .device_task import DeviceTaskMixin, fetch_device
 from .convolution import Convolve
 from .units import Time
 
-__all__ = ['to_sample', 'seek_float', 'ShiftAndResample', 'Resample']
+__all__ = ['to_sample', 'seek_float', 'ShiftAndResample', 'Resample', 'ShiftSamples']
 
 
 def to_sample(ih, offset):
@@ -95,3 +97,46 @@ class Resample(ShiftAndResample):
         super().__init__(ih, shift=0., offset=offset, whence=whence, pad=pad,
                          samples_per_frame=samples_per_frame)
         self.seek(_stream_start(ih) + float(self._offset) / _stream_rate(ih))
+
+
+class ShiftSamples(DeviceTaskMixin, PaddedTaskBase):
+    """Shift streams by integer numbers of samples (no resampling): positive
+    shifts delay a stream.  ``shift`` (samples, rounded; or an astropy time
+    quantity) broadcasts to the sample shape; the output starts
+    ``shift.max()`` samples after the input and is ``ptp(shift)`` samples
+    shorter (reference sampling.py:380-425).  float32 or complex64 streams."""
+
+    def __init__(self, ih, shift, *, samples_per_frame=None):
+        shift = self._shift = np.round(to_sample(ih, shift)).astype(int)
+        check_broadcast_to(shift, ih.shape[1:])
+        if np.dtype(ih.dtype).itemsize not in (4, 8):
+            raise TypeError(f"the accelerated ShiftSamples handles 4- and 8-byte samples; got {ih.dtype}.")
+        start_time = _stream_start(ih) + int(shift.max()) / _stream_rate(ih)
+        super().__init__(ih, pad_start=0, pad_end=int(np.ptp(shift)),
+                         samples_per_frame=samples_per_frame, start_time=start_time)
+        # element e of a complete output sample comes from input sample i + offsets[e]
+        self._offsets = np.broadcast_to(shift.max() - shift, self.sample_shape).ravel()
+        self._plan = None
+
+    def _compute_frames(self, first, last, out):
+        if self._plan is None:
+            self._plan = hip.ShiftPlan(self._offsets, self.dtype.itemsize)
+        start, stop = self._frame_span(first, last)
+        x = fetch_device(self.ih, start, stop - start + self._pad_end)
+        self._plan.execute(x, out, stop - start)
+
+    def task(self, data):
+        n_out = data.shape[0] - self._pad_end
+        if self._plan is None:
+            self._plan = hip.ShiftPlan(self._offsets, self.dtype.itemsize)
+        out = hip.DeviceArray((n_out,) + tuple(self.sample_shape), self.dtype)
+        self._plan.execute(hip.DeviceArray.from_host(np.ascontiguousarray(data, dtype=self.dtype)),
+                           out, n_out)
+        return out.to_host()
+
+    def close(self):
+        super().close()
+        self._drop_cache()
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None

@@ -42,6 +42,7 @@ typedef void* bbt_event;  /* hipEvent_t  */
 typedef struct bbt_osm_plan bbt_osm_plan;
 typedef struct bbt_chan_plan bbt_chan_plan;
 typedef struct bbt_pfb_plan bbt_pfb_plan;
+typedef struct bbt_shift_plan bbt_shift_plan;
 
 /* ---- library / device ------------------------------------------------- */
 const char* bbt_last_error(void);
@@ -165,6 +166,18 @@ int bbt_pfb_execute(bbt_pfb_plan* plan, const void* in_dev, void* out_dev, int64
  *   mode 2  f = identity on float32 elements: in (n_out*step, n_elem) float32 */
 int bbt_detect_integrate(const void* in_dev, void* out_dev, int64_t n_out, int64_t step,
                          int64_t n_elem, int mode, int average, bbt_stream stream);
+
+/* ---- integer sample shifts -------------------------------------------------
+ * Replaces ShiftSamples.task (sampling.py:424-425, data[self._indices]), the
+ * base of DisperseSamples / DedisperseSamples (dispersion.py:193-298):
+ * out[i, e] = in[i + offsets[e], e] for the n_elem elements (4 or 8 bytes each)
+ * of a complete sample, offsets[e] = shift.max() - shift[e] >= 0.  `in` must
+ * hold n_out + max(offsets) complete samples. */
+int bbt_shift_plan_create(bbt_shift_plan** plan, int n_elem, int elem_bytes,
+                          const int32_t* offsets_host);
+int bbt_shift_plan_destroy(bbt_shift_plan* plan);
+int bbt_shift_execute(bbt_shift_plan* plan, const void* in_dev, void* out_dev, int64_t n_out,
+                      bbt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -504,3 +504,27 @@ def integrate(x, step, start=0, average=True):
     if average:
         acc /= step
     return acc
+
+
+# --------------------------------------------------------------------------
+# sampling.py:380-425 ; dispersion.py:193-298
+def shift_samples(x, shift):
+    """ShiftSamples(ih, shift).read(): out[i, ...] = x[i + shift.max() - shift, ...]
+    (sampling.py:407-425); returns (y, start shift in samples)."""
+    shift = np.round(np.asanyarray(shift, dtype=float)).astype(int)
+    full = np.broadcast_to(shift, x.shape[1:])
+    n_out = x.shape[0] - int(np.ptp(shift))
+    idx = np.ix_(np.arange(n_out), *[np.arange(s) for s in x.shape[1:]])
+    return x[(shift.max() - full + idx[0],) + idx[1:]], int(shift.max())
+
+
+def disperse_samples_shift(sample_rate_hz, frequency_mhz, sideband, dm, complex_data=True,
+                           reference_frequency_mhz=None):
+    """Integer shifts DisperseSamples applies (dispersion.py:229-246)."""
+    frequency = np.asanyarray(frequency_mhz, dtype=float)
+    if not complex_data:
+        frequency = frequency + np.asanyarray(sideband) * sample_rate_hz / 1e6 / 2.
+    if reference_frequency_mhz is None:
+        reference_frequency_mhz = frequency.mean()
+    delay = time_delay(dm, frequency, reference_frequency_mhz)
+    return np.round(delay * sample_rate_hz).astype(int)

@@ -34,7 +34,8 @@ from baseband_tasks.channelize import Channelize, Dechannelize    # noqa: E402
 from baseband_tasks.pfb import (sinc_hamming, PolyphaseFilterBank,  # noqa: E402
                                 PolyphaseFilterBankSamples)
 from baseband_tasks.convolution import Convolve                   # noqa: E402
-from baseband_tasks.sampling import Resample                      # noqa: E402
+from baseband_tasks.sampling import Resample, ShiftSamples        # noqa: E402
+from baseband_tasks.dispersion import DisperseSamples, DedisperseSamples  # noqa: E402
 from baseband_tasks.functions import Square, Power               # noqa: E402
 from baseband_tasks.integration import Integrate                 # noqa: E402
 
@@ -268,6 +269,21 @@ def main():
                                                 * nh.sample_rate).to_value(u.one)])
     sq.seek(0)
     out['sk_int_sq'] = Integrate(sq, 4, samples_per_frame=3).read()
+
+    # ---- integer shifts (sampling.py:380-425, dispersion.py:193-298)
+    nh = noise((3000, 3, 2), 1. * u.kHz, 1000, np.array([[300.], [300.4], [301.]]) * u.MHz,
+               np.array([[1], [1], [-1]]), seed=18)
+    sh = ShiftSamples(nh, np.array([[-2], [0], [3]]), samples_per_frame=700)
+    out['sl_shift'] = sh.read()
+    out['sl_shift_meta'] = np.array([sh.shape[0], sh._pad_end,
+                                     ((sh.start_time - nh.start_time) * nh.sample_rate).to_value(u.one)])
+    nh.seek(0)
+    ds_ = DisperseSamples(nh, 50., samples_per_frame=500)
+    out['sl_disp_shift'] = ds_._shift
+    out['sl_disp'] = ds_.read()
+    out['sl_disp_meta'] = np.array([ds_.shape[0], ds_._pad_end,
+                                    ((ds_.start_time - nh.start_time) * nh.sample_rate).to_value(u.one),
+                                    ds_.reference_frequency.to_value(u.MHz)])
 
     # ---- config 5 geometry: Resample + Dedisperse, 8 streams
     nh = noise((8 * 2**20, 8), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)

@@ -421,6 +421,53 @@ def test_metric_pipeline_with_detection():
     _close(got, want, rtol=1e-5)
 
 
+def test_shift_samples_and_incoherent_dedispersion(golden):
+    freq = np.array([[300.], [300.4], [301.]]) * u.MHz
+    nh = noise(3000, (3, 2), 1000, seed=18, fs=1 * u.kHz, frequency=freq,
+               sideband=np.array([[1], [1], [-1]]))
+    sh = bt.ShiftSamples(nh, np.array([[-2], [0], [3]]), samples_per_frame=700)
+    m = golden['sl_shift_meta']
+    assert [sh.shape[0], sh._pad_end] == [m[0], m[1]]
+    assert abs((sh.start_time - nh.start_time) * 1e3 - m[2]) < 1e-6
+    assert np.array_equal(sh.read(), golden['sl_shift'])             # bit exact: pure data movement
+    sh.seek(690)
+    assert np.array_equal(sh.read(30), golden['sl_shift'][690:720])
+    ds_ = bt.DisperseSamples(nh, 50., samples_per_frame=500)
+    assert np.array_equal(ds_._shift, golden['sl_disp_shift'])
+    m = golden['sl_disp_meta']
+    assert [ds_.shape[0], ds_._pad_end] == [m[0], m[1]]
+    assert abs((ds_.start_time - nh.start_time) * 1e3 - m[2]) < 1e-6
+    assert abs(ds_.reference_frequency / 1e6 - m[3]) < 1e-9
+    assert np.array_equal(ds_.read(), golden['sl_disp'])
+    # round trip is exact (reference tests/test_dispersion.py:342-358)
+    dd = bt.DedisperseSamples(ds_, 50., reference_frequency=ds_.reference_frequency)
+    assert dd.dm == 50. and dd._dm == -50.
+    x = orc.noise_stream(18, 0, 3000, 1000, (3, 2))
+    back = dd.read()
+    lag = int(round((dd.start_time - nh.start_time) * 1e3))
+    assert np.array_equal(back, x[lag:lag + back.shape[0]])
+    # float32 streams and fractional shifts (reference tests/test_sampling.py:621-707)
+    def ramp(fh):
+        t = np.arange(fh.tell(), fh.tell() + fh.samples_per_frame, dtype=np.float32)
+        return np.broadcast_to(t.reshape(-1, 1, 1), (fh.samples_per_frame, 5, 3)).copy()
+    ih = bt.StreamGenerator(ramp, (1000, 5, 3), '2010-11-12', 1 * u.Hz, samples_per_frame=100,
+                            dtype=np.float32)
+    shifter = bt.ShiftSamples(ih, np.array([1., 2., 3.25]))
+    assert np.array_equal(shifter._shift, [1, 2, 3]) and shifter.start_time - ih.start_time == 3.
+    got = shifter.read()
+    for i, sf in enumerate(3 - np.array([1, 2, 3])):
+        assert np.array_equal(got[:, :, i], np.arange(sf, sf + 998, dtype=np.float32)[:, None] * np.ones(5))
+    back_shift = np.arange(-4, 1).reshape(-1, 1)
+    sb = bt.ShiftSamples(ih, back_shift, samples_per_frame=100)
+    assert sb.start_time == ih.start_time
+    sb.seek(90)
+    got = sb.read(20)
+    for i, sf in enumerate(-back_shift.ravel()):
+        assert np.array_equal(got[:, i, 0], np.arange(90 + sf, 110 + sf, dtype=np.float32))
+    with pytest.raises(ValueError, match='broadcast to sample shape'):
+        bt.ShiftSamples(ih, np.array([[1], [2]]))
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""

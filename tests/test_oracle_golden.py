@@ -268,3 +268,19 @@ def test_square_power_integrate(golden):
     assert np.allclose(orc.integrate(orc.square(z), 4), golden['sk_int_sq'], rtol=1e-5, atol=1e-3)
     assert list(golden['sk_power_pol']) == ['XX', 'YY', 'XY', 'YX']
     assert list(golden['sk_square_pol']) == ['XX', 'YY']
+
+
+def test_shift_and_disperse_samples(golden):
+    x = orc.noise_stream(18, 0, 3000, 1000, (3, 2))
+    y, shift = orc.shift_samples(x, np.array([[-2], [0], [3]]))
+    assert np.array_equal(y, golden['sl_shift'])
+    m = golden['sl_shift_meta']          # (the shift carries astropy's own 1e-9 time rounding)
+    assert [y.shape[0], 5] == [m[0], m[1]] and abs(shift - m[2]) < 1e-6
+    freq = np.array([[300.], [300.4], [301.]])
+    sh = orc.disperse_samples_shift(1e3, freq, np.array([[1], [1], [-1]]), 50.)
+    assert np.array_equal(sh, golden['sl_disp_shift'])
+    y, shift = orc.shift_samples(x, sh)
+    assert np.array_equal(y, golden['sl_disp'])
+    m = golden['sl_disp_meta']
+    assert [y.shape[0], int(np.ptp(sh))] == [m[0], m[1]] and abs(shift - m[2]) < 1e-6
+    assert abs(freq.mean() - m[3]) < 1e-12
