@@ -87,18 +87,22 @@ class Channelize(_RowFFTTask):
     def __init__(self, ih, n, samples_per_frame=1, *, frequency=None, sideband=None):
         n = operator.index(n)
         samples_per_frame = operator.index(samples_per_frame)
-        if np.dtype(ih.dtype) != np.complex64:
-            raise TypeError("the accelerated channelizer handles complex64 streams; "
+        if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the accelerated channelizer handles complex64 and float32 streams; "
                             f"got {ih.dtype}.")
         _check_n(n)
+        # real streams: n // 2 + 1 channels (rfft); computed as the complex
+        # transform of the zero-extended stream, upper half dropped
+        self._real = np.dtype(ih.dtype).kind == 'f'
+        n_out = n // 2 + 1 if self._real else n
         rate = _stream_rate(ih)
         frequency = getattr_if_none(ih, 'frequency', frequency, required=False)
         sideband = getattr_if_none(ih, 'sideband', sideband, required=False)
         if frequency is not None:
-            fft_freq = np.fft.fftfreq(n, d=1. / rate).reshape((n,) + (1,) * (ih.ndim - 1))
-            frequency = frequency + fft_freq * sideband
+            fft_freq = (np.fft.rfftfreq if self._real else np.fft.fftfreq)(n, d=1. / rate)
+            frequency = frequency + fft_freq.reshape((n_out,) + (1,) * (ih.ndim - 1)) * sideband
         self._setup_streams(n, _prod(ih.shape[1:]))
-        super().__init__(ih, shape=(-1, n) + tuple(ih.shape[1:]), sample_rate=rate / n,
+        super().__init__(ih, shape=(-1, n_out) + tuple(ih.shape[1:]), sample_rate=rate / n,
                          samples_per_frame=samples_per_frame, frequency=frequency,
                          sideband=sideband, dtype=np.complex64)
 
@@ -108,6 +112,8 @@ class Channelize(_RowFFTTask):
         from .overlap_save import SpectralMultiplyTask
         dd = self.ih
         if not (FUSE_WITH_OVERLAP_SAVE and isinstance(dd, SpectralMultiplyTask)) or dd.closed:
+            return None
+        if self._real or dd._real:
             return None
         if (dd._n_stream != dd._n_stream_even or dd.samples_per_frame < self._n
                 or self._n < MIN_FFT_LEN):
@@ -121,7 +127,7 @@ class Channelize(_RowFFTTask):
         start, stop = self._frame_span(first, last)
         n_spectra = stop - start
         n = self._n
-        flat = out.reshape(n_spectra * n, self._n_stream)
+        flat = None if self._real else out.reshape(n_spectra * n, self._n_stream)
         dd = self._fusable_input()
         if dd is not None:
             spf = dd.samples_per_frame
@@ -131,21 +137,27 @@ class Channelize(_RowFFTTask):
             dd._get_plan().execute_channelized(x, flat, starts - in0, out_abs, keep, counts, n,
                                                start, n_spectra)
             return
-        x = fetch_device(self.ih, start * n, n_spectra * n)
-        self._run(x.reshape(n_spectra * n, self._n_stream), n_spectra, flat)
+        x = fetch_device(self.ih, start * n, n_spectra * n).reshape(n_spectra * n, self._n_stream)
+        if self._real:
+            full = hip.DeviceArray((n_spectra * n, self._n_stream), np.complex64)
+            self._run(hip.real_to_complex(x), n_spectra, full)
+            hip.keep_half_spectrum(full, n, self._n_stream, out)
+            return
+        self._run(x, n_spectra, flat)
 
     def task(self, data):
         """Channelize one frame given on the host (reference channelize.py:73-74)."""
-        data = np.ascontiguousarray(data, dtype=np.complex64)
+        data = np.ascontiguousarray(data, dtype=np.complex64)       # real input: zero imaginary part
         n_spectra = data.shape[0] // self._n
         x = hip.DeviceArray.from_host(data.reshape(n_spectra * self._n, self._n_stream))
         y = hip.DeviceArray(x.shape, np.complex64)
         self._run(x, n_spectra, y)
-        return y.to_host().reshape((n_spectra, self._n) + tuple(self.sample_shape[1:]))
+        y = y.to_host().reshape((n_spectra, self._n) + tuple(self.sample_shape[1:]))
+        return np.ascontiguousarray(y[:, :self._n // 2 + 1]) if self._real else y
 
     def inverse(self, ih):
         """`Dechannelize` that undoes this channelization."""
-        return Dechannelize(ih, n=self._n)
+        return Dechannelize(ih, n=self._n, dtype=np.float32 if self._real else None)
 
 
 class Dechannelize(_RowFFTTask):
@@ -156,13 +168,17 @@ class Dechannelize(_RowFFTTask):
     def __init__(self, ih, n=None, samples_per_frame=None, *, dtype=None, frequency=None,
                  sideband=None):
         assert np.dtype(ih.dtype).kind == 'c', "Dechannelization needs complex spectra."
-        if dtype is not None and np.dtype(dtype) != np.complex64:
-            raise TypeError("the accelerated dechannelizer produces complex64 only.")
+        dtype = np.dtype(np.complex64 if dtype is None else dtype)
+        if dtype not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the accelerated dechannelizer produces complex64 or float32.")
+        self._real = dtype.kind == 'f'
         if n is None:
+            if self._real:
+                raise ValueError("need explicit 'n' for real transform.")
             n = ih.shape[1]
         n = operator.index(n)
-        if n != ih.shape[1]:
-            raise ValueError("for complex output n must equal the number of channels.")
+        if ih.shape[1] != (n // 2 + 1 if self._real else n):
+            raise ValueError(f"{ih.shape[1]} channels do not match n={n} for {dtype} output.")
         _check_n(n)
         if samples_per_frame is None:
             ih_spf = ih.samples_per_frame
@@ -174,22 +190,30 @@ class Dechannelize(_RowFFTTask):
         self._setup_streams(n, _prod(ih.shape[2:]))
         super().__init__(ih, shape=(-1,) + tuple(ih.shape[2:]),
                          sample_rate=_stream_rate(ih) * n, ih_samples_per_frame=ih_spf,
-                         frequency=frequency, sideband=sideband, dtype=np.complex64)
+                         frequency=frequency, sideband=sideband, dtype=dtype)
+
+    def _spectra_to_stream(self, x, n_spectra, out):
+        n, s = self._n, self._n_stream
+        if self._real:
+            full = hip.half_to_full_spectrum(x, n, s).reshape(n_spectra * n, s)
+            tmp = hip.DeviceArray((n_spectra * n, s), np.complex64)
+            self._run(full, n_spectra, tmp)
+            hip.real_part(tmp, out)
+        else:
+            self._run(x.reshape(n_spectra * n, s), n_spectra, out.reshape(n_spectra * n, s))
 
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
         n_spectra = (stop - start) // self._n
         x = fetch_device(self.ih, start // self._n, n_spectra)
-        x = x.reshape(n_spectra * self._n, self._n_stream)
-        self._run(x, n_spectra, out.reshape(n_spectra * self._n, self._n_stream))
+        self._spectra_to_stream(x, n_spectra, out)
 
     def task(self, data):
         data = np.ascontiguousarray(data, dtype=np.complex64)
         n_spectra = data.shape[0]
-        x = hip.DeviceArray.from_host(data.reshape(n_spectra * self._n, self._n_stream))
-        y = hip.DeviceArray(x.shape, np.complex64)
-        self._run(x, n_spectra, y)
-        return y.to_host().reshape((n_spectra * self._n,) + tuple(self.sample_shape))
+        out = hip.DeviceArray((n_spectra * self._n,) + tuple(self.sample_shape), self.dtype)
+        self._spectra_to_stream(hip.DeviceArray.from_host(data), n_spectra, out)
+        return out.to_host()
 
     def inverse(self, ih):
         return Channelize(ih, n=self._n)

@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 105
+#define BBT_VERSION 106
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1017,6 +1017,29 @@ extern "C" int bbt_shift_execute(bbt_shift_plan* p, const void* in_dev, void* ou
     else
         hipLaunchKernelGGL((k_shift_samples<float>), grid, block, 0, st, (const float*)in_dev,
                            (float*)out_dev, total, p->n_elem, p->offset);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// real-stream glue
+extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
+                           int n_stream, bbt_stream stream) {
+    ARG_TRY(in_dev && out_dev, "bbt_real_op: null argument");
+    ARG_TRY(op >= 0 && op <= 3, "bbt_real_op: op must be 0..3");
+    ARG_TRY(n_total >= 0, "bbt_real_op: n_total < 0");
+    ARG_TRY(op != 2 || (n_chan >= 2 && n_chan % 2 == 0 && n_stream >= 1),
+            "bbt_real_op: half-to-full needs an even n_chan and n_stream >= 1");
+    if (n_total == 0) return 0;
+    ARG_TRY((n_total + 255) / 256 < (1ll << 31), "bbt_real_op: too many elements for one call");
+    const dim3 grid((unsigned)((n_total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (op) {
+        case 0: hipLaunchKernelGGL((k_real_ops<0>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        case 1: hipLaunchKernelGGL((k_real_ops<1>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        case 2: hipLaunchKernelGGL((k_real_ops<2>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        default: hipLaunchKernelGGL((k_real_ops<3>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

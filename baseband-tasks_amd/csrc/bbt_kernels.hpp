@@ -753,4 +753,46 @@ __global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in,
     out[t] = in[t + (long long)offset[e] * n_elem];
 }
 
+// ---------------------------------------------------------------------------
+// Glue for real-valued (float32) streams, which run through the complex
+// kernels (reference: the rfft/irfft engine paths, fourier/numpy.py:41-49).
+//   MODE 0  real -> complex (zero imaginary part)            out[t] = (in[t], 0)
+//   MODE 1  complex -> real part                             out[t] = in[t].x
+//   MODE 2  half spectrum (n/2+1 channels) -> Hermitian full spectrum of n
+//           channels, as irfft interprets it (imaginary parts of the DC and
+//           Nyquist channels ignored); rows = spectra, `s` streams innermost
+//   MODE 3  x -> x^2 (Square of a real stream)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_real_ops(const void* __restrict__ in_,
+                                                  void* __restrict__ out_, long long n_total, int n,
+                                                  int s) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_total) return;
+    if (MODE == 0) {
+        ((float2*)out_)[t] = make_float2(((const float*)in_)[t], 0.f);
+    } else if (MODE == 1) {
+        ((float*)out_)[t] = ((const float2*)in_)[t].x;
+    } else if (MODE == 3) {
+        const float x = ((const float*)in_)[t];
+        ((float*)out_)[t] = x * x;
+    } else {
+        // t indexes out (spectrum, k, stream)
+        const int st = (int)(t % s);
+        const long long r = t / s;
+        const int k = (int)(r % n);
+        const long long spec = r / n;
+        const int half = n / 2 + 1;
+        const float2* row = (const float2*)in_ + spec * half * s;
+        float2 z;
+        if (k <= n / 2) {
+            z = row[(long long)k * s + st];
+            if (k == 0 || 2 * k == n) z.y = 0.f;
+        } else {
+            z = row[(long long)(n - k) * s + st];
+            z.y = -z.y;
+        }
+        ((float2*)out_)[t] = z;
+    }
+}
+
 }  // namespace bbt

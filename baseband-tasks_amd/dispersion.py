@@ -85,11 +85,15 @@ class Disperse(SpectralMultiplyTask):
     @property
     def phase_factor(self):
         """exp(2 pi i phase) per FFT bin, float64 arithmetic cast to complex64
-        (dispersion.py:115-129); shape ``(N,) +`` broadcastable sample shape."""
+        (dispersion.py:115-129); shape ``(N,) +`` broadcastable sample shape
+        (``N // 2 + 1`` frequencies for a real stream)."""
         if self._phase_factor is None:
             n = self._ih_samples_per_frame
-            fft_freq = np.fft.fftfreq(n, d=1. / self.sample_rate)
-            fft_freq = fft_freq.reshape((n,) + (1,) * len(self.sample_shape))
+            if self._real:       # non-negative frequencies only, as for rfft (fourier/base.py:150-153)
+                fft_freq = np.fft.rfftfreq(n, d=1. / self.sample_rate)
+            else:
+                fft_freq = np.fft.fftfreq(n, d=1. / self.sample_rate)
+            fft_freq = fft_freq.reshape(fft_freq.shape + (1,) * len(self.sample_shape))
             frequency = self.frequency + fft_freq * self.sideband
             phase = self._dm.phase_delay(frequency, self.reference_frequency)
             phase = phase * self.sideband

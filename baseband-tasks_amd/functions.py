@@ -18,10 +18,20 @@ def _prod(shape):
 
 class _DetectTask(DeviceTaskMixin, TaskBase):
     _mode = 0
+    _real = False
 
     def _detect(self, x, n_out, step, out, average=True):
         """x: input complete samples on the device; fills ``out``."""
-        hip.detect_integrate(x, out, n_out, step, _prod(self.ih.shape[1:]), self._mode, average)
+        n_elem = _prod(self.ih.shape[1:])
+        if self._real:           # x^2, then (if asked) a plain sum
+            if step == 1:
+                hip.square_real(x, out)
+            else:
+                tmp = hip.DeviceArray((n_out * step, n_elem), np.float32)
+                hip.square_real(x, tmp)
+                hip.detect_integrate(tmp, out, n_out, step, n_elem, 2, average)
+            return
+        hip.detect_integrate(x, out, n_out, step, n_elem, self._mode, average)
 
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
@@ -29,7 +39,7 @@ class _DetectTask(DeviceTaskMixin, TaskBase):
         self._detect(x, stop - start, 1, out)
 
     def task(self, data):
-        data = np.ascontiguousarray(data, dtype=np.complex64)
+        data = np.ascontiguousarray(data, dtype=np.float32 if self._real else np.complex64)
         out = hip.DeviceArray((data.shape[0],) + tuple(self.sample_shape), self.dtype)
         self._detect(hip.DeviceArray.from_host(data), data.shape[0], 1, out)
         return out.to_host()
@@ -42,9 +52,10 @@ class Square(_DetectTask):
     _mode = 0
 
     def __init__(self, ih, polarization=None):
-        if np.dtype(ih.dtype) != np.complex64:
-            raise TypeError("the accelerated Square handles complex64 streams; got "
+        if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the accelerated Square handles complex64 and float32 streams; got "
                             f"{ih.dtype}.")
+        self._real = np.dtype(ih.dtype).kind == 'f'
         if polarization is None and getattr(ih, 'polarization', None) is not None:
             polarization = np.char.add(ih.polarization, ih.polarization)
         super().__init__(ih, dtype=np.float32, polarization=polarization)

@@ -72,6 +72,7 @@ SIGNATURES = {
     'bbt_shift_plan_create': [_pvp, _int, _int, _pi32],
     'bbt_shift_plan_destroy': [_vp],
     'bbt_shift_execute': [_vp, _vp, _vp, _i64, _vp],
+    'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
 }
 
 _lib = None
@@ -339,6 +340,44 @@ def detect_integrate(in_dev, out_dev, n_out, step, n_elem, mode, average=True):
     """Square (mode 0) / Power (1) / plain sum (2) over ``step`` samples."""
     check(lib().bbt_detect_integrate(in_dev.ptr, out_dev.ptr, int(n_out), int(step), int(n_elem),
                                      int(mode), int(bool(average)), _stream))
+
+
+def real_to_complex(x):
+    """float32 DeviceArray -> complex64 with zero imaginary part (same shape)."""
+    out = DeviceArray(x.shape, np.complex64)
+    check(lib().bbt_real_op(x.ptr, out.ptr, 0, out.size, 0, 0, _stream))
+    return out
+
+
+def real_part(z, out=None):
+    """complex64 DeviceArray -> its real part (float32)."""
+    if out is None:
+        out = DeviceArray(z.shape, np.float32)
+    check(lib().bbt_real_op(z.ptr, out.ptr, 1, out.size, 0, 0, _stream))
+    return out
+
+
+def half_to_full_spectrum(z, n_chan, n_stream):
+    """(n_spec, n_chan/2+1, n_stream) complex64 -> Hermitian (n_spec, n_chan, n_stream)."""
+    n_spec = z.size // ((n_chan // 2 + 1) * n_stream)
+    out = DeviceArray((n_spec, n_chan, n_stream), np.complex64)
+    check(lib().bbt_real_op(z.ptr, out.ptr, 2, out.size, int(n_chan), int(n_stream), _stream))
+    return out
+
+
+def keep_half_spectrum(z, n_chan, n_stream, out):
+    """(n_spec, n_chan, n_stream) -> first n_chan/2+1 channels of every spectrum."""
+    n_spec = z.size // (n_chan * n_stream)
+    half = n_chan // 2 + 1
+    if n_spec:
+        check(lib().bbt_memcpy2d(out.ptr, half * n_stream * 8, z.ptr, n_chan * n_stream * 8,
+                                 half * n_stream * 8, n_spec, 2, _stream))
+    return out
+
+
+def square_real(x, out):
+    check(lib().bbt_real_op(x.ptr, out.ptr, 3, out.size, 0, 0, _stream))
+    return out
 
 
 class _Plan:

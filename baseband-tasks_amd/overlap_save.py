@@ -34,9 +34,13 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
     _keep_from = 0
 
     def __init__(self, ih, pad_start, pad_end, *, samples_per_frame=None, **kwargs):
-        if not np.dtype(ih.dtype) == np.complex64:
-            raise TypeError("the accelerated path handles complex64 streams; got "
-                            f"{ih.dtype} (real streams: convert with Real2Complex first).")
+        if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the accelerated path handles complex64 and float32 streams; got "
+                            f"{ih.dtype}.")
+        # float32 streams run through the same complex kernels: zero imaginary
+        # part on the way in, Hermitian response, real part on the way out
+        # (what rfft -> multiply -> irfft computes in the reference).
+        self._real = np.dtype(ih.dtype).kind == 'f'
         self._FFT = fft_maker.get()
         super().__init__(ih, pad_start=pad_start, pad_end=pad_end,
                          samples_per_frame=samples_per_frame,
@@ -49,6 +53,13 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         """(C, N) response columns and the column index of every stream."""
         resp = np.asarray(self._spectral_response(), dtype=np.complex64)
         n = self._ih_samples_per_frame
+        if self._real:
+            # keep the non-negative frequencies (all irfft looks at) and extend
+            half = resp[:n // 2 + 1].copy()
+            half[0] = half[0].real
+            if n % 2 == 0:
+                half[-1] = half[-1].real
+            resp = np.concatenate([half, half[-2 if n % 2 == 0 else -1:0:-1].conj()])
         assert resp.shape[0] == n
         bshape = resp.shape[1:]
         ncol = _prod(bshape)
@@ -86,15 +97,21 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         x = fetch_device(self.ih, in0, in_len)
         out_off = out_abs - first * self.samples_per_frame
         s, se = self._n_stream, self._n_stream_even
+        n_out = out.shape[0]
+        if self._real:
+            x = hip.real_to_complex(x.reshape(in_len, s))
+            final, out = out, hip.DeviceArray((n_out, s), np.complex64)
         if se != s:
             x = hip.pad_streams_to_even(x, s)
-            padded_out = hip.DeviceArray((out.shape[0], se), np.complex64)
+            padded_out = hip.DeviceArray((n_out, se), np.complex64)
             target = padded_out
         else:
             target = out
         plan.execute(x, target, starts - in0, out_off, keep, counts)
         if se != s:
-            hip.strip_stream_pad(padded_out, out.shape[0], s, out)
+            hip.strip_stream_pad(padded_out, n_out, s, out)
+        if self._real:
+            hip.real_part(out, final)
 
     def close(self):
         super().close()
@@ -107,8 +124,8 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         """Process one input block given on the host (the reference's hook,
         base.py:699-706).  Runs the same kernels on an uploaded copy."""
         n = self._ih_samples_per_frame
-        data = np.ascontiguousarray(data, dtype=np.complex64)
         assert data.shape == (n,) + tuple(self.sample_shape)
+        data = np.ascontiguousarray(data, dtype=np.complex64)       # real input: zero imaginary part
         x = hip.DeviceArray.from_host(data.reshape(n, self._n_stream))
         s, se = self._n_stream, self._n_stream_even
         if se != s:
@@ -118,4 +135,5 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         self._get_plan().execute(x, y, [0], [0], [self._keep_from], [spf])
         if se != s:
             y = hip.strip_stream_pad(y, spf, s, hip.DeviceArray((spf, s), np.complex64))
-        return y.to_host().reshape((spf,) + tuple(self.sample_shape))
+        y = y.to_host().reshape((spf,) + tuple(self.sample_shape))
+        return np.ascontiguousarray(y.real) if self._real else y

@@ -48,9 +48,11 @@ class PolyphaseFilterBank(_RowFFTTask):
         response = np.asanyarray(response)
         n_tap, n = response.shape
         _check_n(n, minimum=256)
-        if np.dtype(ih.dtype) != np.complex64:
-            raise TypeError("the accelerated filter bank handles complex64 streams; "
+        if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the accelerated filter bank handles complex64 and float32 streams; "
                             f"got {ih.dtype}.")
+        self._real = np.dtype(ih.dtype).kind == 'f'
+        n_out = n // 2 + 1 if self._real else n
         pad = (n_tap - 1) * n
         assert pad % 2 == 0
         if samples_per_frame is not None:
@@ -67,11 +69,11 @@ class PolyphaseFilterBank(_RowFFTTask):
         frequency = getattr_if_none(ih, 'frequency', frequency, required=False)
         sideband = getattr_if_none(ih, 'sideband', sideband, required=False)
         if frequency is not None:
-            fft_freq = np.fft.fftfreq(n, d=1. / rate).reshape((n,) + (1,) * (ih.ndim - 1))
-            frequency = frequency + fft_freq * sideband
+            fft_freq = (np.fft.rfftfreq if self._real else np.fft.fftfreq)(n, d=1. / rate)
+            frequency = frequency + fft_freq.reshape((n_out,) + (1,) * (ih.ndim - 1)) * sideband
         self._setup_streams(n, _prod(ih.shape[1:]))
         self._reshape = (self.padded._ih_samples_per_frame // n, n) + tuple(ih.shape[1:])
-        super().__init__(self.padded, shape=(-1, n) + tuple(ih.shape[1:]),
+        super().__init__(self.padded, shape=(-1, n_out) + tuple(ih.shape[1:]),
                          sample_rate=rate / n,
                          samples_per_frame=self.padded.samples_per_frame // n,
                          frequency=frequency, sideband=sideband, dtype=np.complex64)
@@ -88,6 +90,9 @@ class PolyphaseFilterBank(_RowFFTTask):
         x = fetch_device(self._source, start * n, (n_spectra + n_tap - 1) * n)
         x = x.reshape((n_spectra + n_tap - 1) * n, self._n_stream)
         s, se = self._n_stream, self._n_stream_even
+        if self._real:
+            x = hip.real_to_complex(x)
+            final, out = out, hip.DeviceArray((n_spectra * n, s), np.complex64)
         flat = out.reshape(n_spectra * n, s)
         if se != s:
             x = hip.pad_streams_to_even(x, s)
@@ -96,6 +101,8 @@ class PolyphaseFilterBank(_RowFFTTask):
             hip.strip_stream_pad(tmp, n_spectra * n, s, flat)
         else:
             self._get_plan().execute(x, flat, n_spectra)
+        if self._real:
+            hip.keep_half_spectrum(flat, n, s, final)
 
     def ppf(self, data):
         raise NotImplementedError("the filter and the FFT are one GPU kernel here; "

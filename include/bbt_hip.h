@@ -179,6 +179,19 @@ int bbt_shift_plan_destroy(bbt_shift_plan* plan);
 int bbt_shift_execute(bbt_shift_plan* plan, const void* in_dev, void* out_dev, int64_t n_out,
                       bbt_stream stream);
 
+/* ---- real-valued streams ------------------------------------------------------
+ * float32 streams run through the complex kernels (the reference's rfft/irfft
+ * engine paths, fourier/numpy.py:41-49).  Element-wise glue, n_total = number
+ * of OUTPUT elements:
+ *   op 0  real -> complex (zero imaginary part)
+ *   op 1  complex -> real part
+ *   op 2  half spectrum (n_total/(n_chan*n_stream) spectra of n_chan/2+1
+ *         channels, n_stream streams innermost) -> Hermitian full spectrum of
+ *         n_chan channels as irfft interprets it
+ *   op 3  x -> x*x */
+int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
+                int n_stream, bbt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

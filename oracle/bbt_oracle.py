@@ -216,7 +216,7 @@ def fft_frequency(n, sample_rate, ndim_after=0, real=False):
 
 def chirp(n, sample_rate_hz, frequency_mhz, sideband, dm,
           reference_frequency_mhz, sample_offset=0, sample_ndim=1,
-          dtype=np.complex64):
+          dtype=np.complex64, real=False):
     """Disperse.phase_factor (dispersion.py:115-129), shape (n,)+broadcast.
 
     frequency = f0 + fftfreq * sideband; phase = phase_delay * sideband
@@ -225,7 +225,7 @@ def chirp(n, sample_rate_hz, frequency_mhz, sideband, dm,
     """
     frequency_mhz = np.asanyarray(frequency_mhz, dtype=float)
     sideband = np.asanyarray(sideband)
-    ff = fft_frequency(n, sample_rate_hz / 1e6, sample_ndim)     # MHz
+    ff = fft_frequency(n, sample_rate_hz / 1e6, sample_ndim, real=real)     # MHz
     freq = frequency_mhz + ff * sideband
     ph = phase_delay(dm, freq, reference_frequency_mhz)
     ph = ph * sideband
@@ -250,11 +250,27 @@ def _ifft(a, axis, fft64):
     return np.fft.ifft(a, axis=axis).astype(a.dtype, copy=False)
 
 
+def _rfft(a, axis):
+    """fourier/numpy.py:41-43 (real input; float64 inside, cast to complex64)."""
+    return np.fft.rfft(a.astype(np.float64), axis=axis).astype(np.complex64)
+
+
+def _irfft(a, n, axis):
+    """fourier/numpy.py:46-49."""
+    return np.fft.irfft(a.astype(np.complex128), n=n, axis=axis).astype(np.float32)
+
+
 def disperse_block(x, phase_factor, pad_start, spf, fft64=True):
-    """Disperse.task (dispersion.py:135-139)."""
-    ft = _fft(x, 0, fft64)
-    ft *= phase_factor
-    result = _ifft(ft, 0, fft64)
+    """Disperse.task (dispersion.py:135-139); real streams go through
+    rfft / irfft."""
+    if x.dtype.kind == 'f':
+        ft = _rfft(x, 0)
+        ft *= phase_factor
+        result = _irfft(ft, x.shape[0], 0)
+    else:
+        ft = _fft(x, 0, fft64)
+        ft *= phase_factor
+        result = _ifft(ft, 0, fft64)
     return result[pad_start:pad_start + spf]
 
 
@@ -283,7 +299,7 @@ def dedisperse(x, sample_rate_hz, frequency_mhz, sideband, dm,
                           g['pad_end'], samples_per_frame, fast_len)
     h = chirp(geo['ih_spf'], sample_rate_hz, frequency_mhz, sideband, -dm,
               g['reference_frequency'], g['sample_offset'],
-              sample_ndim=x.ndim - 1, dtype=x.dtype)
+              sample_ndim=x.ndim - 1, dtype=np.complex64, real=x.dtype.kind == 'f')
     y = overlap_save(x, geo, lambda blk: disperse_block(
         blk, h, geo['pad_start'], geo['spf'], fft64))
     info = dict(g)
@@ -300,18 +316,20 @@ def channelize(x, n, fft64=True):
     partial group is dropped (base.py:684-687)."""
     nspec = x.shape[0] // n
     blocks = x[:nspec * n].reshape((nspec, n) + x.shape[1:])
+    if x.dtype.kind == 'f':
+        return _rfft(blocks, 1)
     return _fft(blocks, 1, fft64)
 
 
-def dechannelize(z, fft64=True):
-    """Dechannelize.task (channelize.py:164-165), complex output."""
-    r = _ifft(z, 1, fft64)
+def dechannelize(z, fft64=True, n=None):
+    """Dechannelize.task (channelize.py:164-165); pass ``n`` for real output."""
+    r = _ifft(z, 1, fft64) if n is None else _irfft(z, n, 1)
     return r.reshape((-1,) + z.shape[2:])
 
 
-def channel_frequency(n, sample_rate_hz, frequency_mhz, sideband, sample_ndim=1):
+def channel_frequency(n, sample_rate_hz, frequency_mhz, sideband, sample_ndim=1, real=False):
     """channelize.py:60-64: frequency + fft.frequency * sideband (MHz)."""
-    ff = fft_frequency(n, sample_rate_hz / 1e6, sample_ndim)
+    ff = fft_frequency(n, sample_rate_hz / 1e6, sample_ndim, real=real)
     return np.asanyarray(frequency_mhz, float) + ff * np.asanyarray(sideband)
 
 
@@ -359,10 +377,15 @@ def ppf_fourier(data, response, fft64=True):
     long_response = np.zeros(blk.shape[:2], data.dtype)
     long_response[:n_tap] = response
     long_response = long_response.reshape(long_response.shape + (1,) * (data.ndim - 1))
-    ft_resp_conj = _fft(long_response, 0, fft64).conj()
-    ft = _fft(blk, 0, fft64)
-    ft *= ft_resp_conj
-    result = _ifft(ft, 0, fft64)
+    if data.dtype.kind == 'f':
+        ft = _rfft(blk, 0)
+        ft *= _rfft(long_response, 0).conj()
+        result = _irfft(ft, blk.shape[0], 0)
+    else:
+        ft_resp_conj = _fft(long_response, 0, fft64).conj()
+        ft = _fft(blk, 0, fft64)
+        ft *= ft_resp_conj
+        result = _ifft(ft, 0, fft64)
     result = result[:result.shape[0] + 1 - n_tap]
     return result.reshape((-1,) + result.shape[2:])
 

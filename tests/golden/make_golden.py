@@ -285,6 +285,31 @@ def main():
                                     ((ds_.start_time - nh.start_time) * nh.sample_rate).to_value(u.one),
                                     ds_.reference_frequency.to_value(u.MHz)])
 
+    # ---- real-valued streams (rfft paths: fourier/numpy.py:41-49, dispersion.py:58-61, channelize.py)
+    nr = NoiseGenerator((12000, 2), T0, 1. * u.MHz, 4000, dtype=np.float32, seed=19,
+                        frequency=300. * u.MHz, sideband=np.array([1, -1]))
+    chr_ = Channelize(nr, 256, samples_per_frame=3)
+    out['sr_chan'] = chr_.read()
+    out['sr_chan_freq'] = chr_.frequency.to_value(u.MHz)
+    chr_.seek(0)
+    out['sr_dechan'] = Dechannelize(chr_, n=256, dtype=np.dtype('f4')).read()
+    nr.seek(0)
+    ddr = Dedisperse(nr, 5., samples_per_frame=4096 - 767 - 771)
+    g, shift = geometry(ddr, nr)
+    out['sr_dd_geo'] = g
+    out['sr_dd_shift'] = shift
+    out['sr_dd'] = ddr.read()
+    out['sr_dd_chirp'] = ddr.phase_factor[[0, 1, 1000, 2047, 2048]]
+    nr.seek(0)
+    ddr2 = Disperse(nr, 5., reference_frequency=300.2 * u.MHz, samples_per_frame=4096 - 767 - 771)
+    g, shift = geometry(ddr2, nr)
+    out['sr_dd2_geo'] = g
+    out['sr_dd2'] = ddr2.read()
+    nr1 = NoiseGenerator((40 * 256,), T0, 1. * u.MHz, 2560, dtype=np.float32, seed=20)
+    out['sr_pfb'] = PolyphaseFilterBank(nr1, sinc_hamming(4, 256), samples_per_frame=8).read()
+    nr.seek(0)
+    out['sr_square'] = Square(nr).read(1000)
+
     # ---- config 5 geometry: Resample + Dedisperse, 8 streams
     nh = noise((8 * 2**20, 8), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)
     rs = Resample(nh, 0.25, pad=64, samples_per_frame=2**20 - 128)

@@ -468,6 +468,51 @@ def test_shift_samples_and_incoherent_dedispersion(golden):
         bt.ShiftSamples(ih, np.array([[1], [2]]))
 
 
+def test_real_valued_streams_golden(golden):
+    """float32 streams (the reference's rfft/irfft paths) against reference vectors."""
+    sb = np.array([1, -1])
+    nr = bt.NoiseGenerator((12000, 2), T0, 1 * u.MHz, 4000, dtype=np.float32, seed=19,
+                           frequency=300 * u.MHz, sideband=sb)
+    ch = bt.Channelize(nr, 256, samples_per_frame=3)
+    z = ch.read()
+    assert z.shape == (45, 129, 2) and z.dtype == np.complex64
+    assert_parity(z, golden['sr_chan'], 'real channelize')
+    np.testing.assert_allclose(ch.frequency / 1e6, golden['sr_chan_freq'], rtol=1e-15)
+    ch.seek(0)
+    back = ch.inverse(ch).read()
+    assert back.dtype == np.float32 and back.shape == golden['sr_dechan'].shape
+    assert np.abs(back - golden['sr_dechan']).max() < 1e-5
+    nr.seek(0)
+    dd = bt.Dedisperse(nr, 5., samples_per_frame=4096 - 767 - 771)
+    assert [dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame,
+            dd.shape[0], dd._sample_offset] == list(golden['sr_dd_geo'])
+    assert np.abs(dd.phase_factor[[0, 1, 1000, 2047, 2048]] - golden['sr_dd_chirp']).max() < 3e-7
+    y = dd.read()
+    assert y.dtype == np.float32
+    rms = np.sqrt(np.mean(golden['sr_dd'].astype(float) ** 2))
+    assert np.abs(y - golden['sr_dd']).max() < MAX_TOL * rms
+    assert np.linalg.norm(y - golden['sr_dd']) / np.linalg.norm(golden['sr_dd']) < REL_L2_TOL
+    d2 = bt.Disperse(nr, 5., reference_frequency=300.2 * u.MHz, samples_per_frame=4096 - 767 - 771)
+    assert [d2._pad_start, d2._pad_end, d2._ih_samples_per_frame, d2.samples_per_frame,
+            d2.shape[0], d2._sample_offset] == list(golden['sr_dd2_geo'])
+    y2 = d2.read()
+    assert np.linalg.norm(y2 - golden['sr_dd2']) / np.linalg.norm(golden['sr_dd2']) < REL_L2_TOL
+    nr.seek(0)
+    blk = nr.read(4096)
+    assert np.array_equal(d2.task(blk), y2[:4096 - 767 - 771])       # the host-data hook
+    nr1 = bt.NoiseGenerator((40 * 256,), T0, 1 * u.MHz, 2560, dtype=np.float32, seed=20)
+    zp = bt.PolyphaseFilterBank(nr1, bt.sinc_hamming(4, 256), samples_per_frame=8).read()
+    assert_parity(zp, golden['sr_pfb'], 'real pfb')
+    nr.seek(0)
+    sq = bt.Square(nr)
+    assert sq.dtype == np.float32 and np.allclose(sq.read(1000), golden['sr_square'], rtol=1e-6)
+    nr.seek(0)
+    x = orc.noise_stream(19, 0, 12000, 4000, (2,), dtype=np.float32)
+    assert np.allclose(bt.Integrate(sq, 10).read(), orc.integrate(orc.square(x), 10), rtol=1e-5)
+    with pytest.raises(ValueError):
+        bt.Power(nr, polarization=['XX', 'YY', 'XY', 'YX'])
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""

@@ -256,7 +256,9 @@ def test_channelize_pfb_resample_geometry(golden):
     with pytest.raises(ValueError):
         bt.Channelize(nh, 8192)
     with pytest.raises(TypeError):
-        bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f4'), 256)
+        bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f8'), 256)
+    real = bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f4'), 256)
+    assert real.shape == (16, 129) and real.dtype == np.complex64       # rfft: n // 2 + 1 channels
     assert bt.Channelize(noise(2**20, (2,), 2**20), 1024).shape == (1024, 1024, 2)   # no metadata needed
     pfb = bt.PolyphaseFilterBank(nh, bt.sinc_hamming(12, 1024))
     assert [pfb.padded._pad_start, pfb.padded._pad_end, pfb.padded._ih_samples_per_frame,

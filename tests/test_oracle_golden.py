@@ -284,3 +284,36 @@ def test_shift_and_disperse_samples(golden):
     m = golden['sl_disp_meta']
     assert [y.shape[0], int(np.ptp(sh))] == [m[0], m[1]] and abs(shift - m[2]) < 1e-6
     assert abs(freq.mean() - m[3]) < 1e-12
+
+
+def test_real_valued_streams(golden):
+    """rfft paths of the reference (fourier/numpy.py:41-49) on float32 noise."""
+    x = orc.noise_stream(19, 0, 12000, 4000, (2,), dtype=np.float32)
+    assert x.dtype == np.float32
+    sb = np.array([1, -1])
+    z = orc.channelize(x[:45 * 256], 256)
+    assert z.shape == (45, 129, 2) and rel_l2(z, golden['sr_chan']) < TIGHT
+    np.testing.assert_allclose(orc.channel_frequency(256, 1e6, 300., sb, real=True),
+                               golden['sr_chan_freq'], rtol=1e-15)
+    back = orc.dechannelize(z, n=256)
+    assert back.dtype == np.float32 and np.abs(back - golden['sr_dechan']).max() < 2e-6
+    y, info = orc.dedisperse(x, 1e6, 300., sb, 5., samples_per_frame=4096 - 767 - 771,
+                             ih_samples_per_frame=4000)
+    assert [info['pad_start'], info['pad_end'], info['ih_spf'], info['spf'], info['n_out'], 0] == \
+        list(golden['sr_dd_geo'])
+    assert y.dtype == np.float32 and np.abs(y - golden['sr_dd']).max() < 3e-6
+    g = orc.disperse_geometry(1e6, 300., sb, -5., complex_data=False)
+    h = orc.chirp(4096, 1e6, 300., sb, -5., g['reference_frequency'], real=True)
+    assert h.shape == (2049, 2) and np.abs(h[[0, 1, 1000, 2047, 2048]] - golden['sr_dd_chirp']).max() < 3e-7
+    g2 = orc.disperse_geometry(1e6, 300., sb, 5., complex_data=False, reference_frequency_mhz=300.2)
+    geo2 = orc.padded_geometry(12000, 4000, g2['pad_start'], g2['pad_end'], 4096 - 767 - 771,
+                               orc.next_fast_len)
+    assert [g2['pad_start'], g2['pad_end'], geo2['ih_spf'], geo2['spf'], geo2['n_out'],
+            g2['sample_offset']] == list(golden['sr_dd2_geo'])
+    h2 = orc.chirp(4096, 1e6, 300., sb, 5., 300.2, real=True)
+    y2 = orc.overlap_save(x, geo2, lambda b: orc.disperse_block(b, h2, geo2['pad_start'], geo2['spf']))
+    assert np.abs(y2 - golden['sr_dd2']).max() < 3e-6
+    x1 = orc.noise_stream(20, 0, 40 * 256, 2560, (), dtype=np.float32)
+    zp, _ = orc.polyphase_filter_bank(x1, orc.sinc_hamming(4, 256), 2560, 8)
+    assert zp.shape == (32, 129) and rel_l2(zp, golden['sr_pfb']) < TIGHT
+    assert np.allclose(orc.square(x[:1000]), golden['sr_square'], rtol=1e-6)
