@@ -220,7 +220,7 @@ def main():
             metric='Msamples/s through Dedisperse(DM=100)+Channelize(1k ch), 2-pol c64',
             value=round(value, 1), unit='Msamples/s', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
-            higher_is_better=True, scaling='weak', vs_baseline=None, dtype='c64 (f32 arithmetic)',
+            higher_is_better=True, scaling='weak', vs_baseline=None, dtype='c64',
             data='synthetic',
             config=dict(workload='configs[1]+metric pipeline: Dedisperse DM=100, 16 MHz BW at 1000 MHz, '
                                  '2^20-sample overlap-save blocks (836100 valid) -> Channelize(1024), '
