@@ -133,10 +133,11 @@ class Channelize(_RowFFTTask):
             spf = dd.samples_per_frame
             m0, m1 = (start * n) // spf, (stop * n - 1) // spf + 1
             in0, in_len, starts, out_abs, keep, counts = dd._block_descriptors(m0, m1)
-            x = fetch_device(dd.ih, in0, in_len)
-            dd._get_plan().execute_channelized(x, flat, starts - in0, out_abs, keep, counts, n,
-                                               start, n_spectra)
-            return
+            if np.all(counts >= n):      # (a short final frame cannot host a whole spectrum)
+                x = fetch_device(dd.ih, in0, in_len)
+                dd._get_plan().execute_channelized(x, flat, starts - in0, out_abs, keep, counts, n,
+                                                   start, n_spectra)
+                return
         x = fetch_device(self.ih, start * n, n_spectra * n).reshape(n_spectra * n, self._n_stream)
         if self._real:
             full = hip.DeviceArray((n_spectra * n, self._n_stream), np.complex64)

@@ -82,6 +82,25 @@ def test_config2_dedisperse_and_metric_pipeline(golden):
     assert_parity(z[-2:], golden['c2ch_tail'], 'golden tail')
 
 
+def test_fused_channelizer_short_final_frame():
+    """The last dedispersion frame keeps fewer samples than one spectrum: that
+    call takes the unfused route, everything else stays fused."""
+    n_fft, pad = 2**14, 767 + 771
+    spf = n_fft - pad
+    n_in = 3 * spf + pad + 100                      # dedispersed length 3 * spf + 100
+    nh = noise(n_in, (2,), 5000, seed=31, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
+    x = orc.noise_stream(31, 0, n_in, 5000, (2,))
+    dd = bt.Dedisperse(nh, 5., samples_per_frame=spf)
+    assert dd.shape[0] == 3 * spf + 100 and dd._ih_samples_per_frame == n_fft
+    ch = bt.Channelize(dd, 256, samples_per_frame=1)
+    assert ch._fusable_input() is dd
+    z = ch.read()
+    y, _ = orc.dedisperse(x, 1e6, 300., 1, 5., samples_per_frame=spf, ih_samples_per_frame=5000,
+                          fast_len=HipFFTMaker.next_fast_len)
+    assert z.shape[0] == (3 * spf + 100) // 256
+    assert_parity(z, orc.channelize(y[:z.shape[0] * 256], 256), 'short final frame')
+
+
 def test_config2_device_resident_chain_matches_host_chain():
     nh = noise(3 * 2**20, (2,), 2**20, frequency=1000 * u.MHz, sideband=1)
     ds = bt.DeviceStream(nh, T0, 16 * u.MHz)
