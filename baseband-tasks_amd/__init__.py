@@ -17,7 +17,8 @@ from .dispersion import Disperse, Dedisperse, DisperseSamples, DedisperseSamples
 from .convolution import Convolve
 from .sampling import ShiftAndResample, Resample, ShiftSamples
 from .channelize import Channelize, Dechannelize
-from .pfb import sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples
+from .pfb import (sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples,
+                  InversePolyphaseFilterBank)
 from .functions import Square, Power
 from .integration import Integrate
 from . import hip

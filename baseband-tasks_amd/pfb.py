@@ -3,10 +3,12 @@ import numpy as np
 
 from . import hip
 from .base import PaddedTaskBase, getattr_if_none, _stream_rate
-from .channelize import _RowFFTTask, _check_n, _prod
-from .device_task import fetch_device
+from .channelize import Dechannelize, _RowFFTTask, _check_n, _prod
+from .device_task import DeviceTaskMixin, fetch_device
+from .fourier import fft_maker
 
-__all__ = ['sinc_hamming', 'PolyphaseFilterBank', 'PolyphaseFilterBankSamples']
+__all__ = ['sinc_hamming', 'PolyphaseFilterBank', 'PolyphaseFilterBankSamples',
+           'InversePolyphaseFilterBank']
 
 
 def sinc_hamming(n_tap, n_sample, sinc_scale=1.):
@@ -116,3 +118,112 @@ class PolyphaseFilterBank(_RowFFTTask):
 #: The GPU evaluates the time-domain definition directly, so both reference
 #: classes map to the same task.
 PolyphaseFilterBankSamples = PolyphaseFilterBank
+
+
+class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
+    """Undo a polyphase filter bank by Wiener deconvolution (reference
+    pfb.py:157-269): dechannelize, then, frame by frame, FFT along the block
+    axis, multiply by ``conj(R) / (|R|^2 + 1/sn^2) * (1 + 1/sn^2)`` with ``R``
+    the transform of the zero-extended response, inverse FFT.
+
+    On the GPU this is the overlap-save spectral-multiply plan run along the
+    block axis with ``n * prod(sample_shape)`` streams (one response column per
+    polyphase phase); complex output only.
+
+    Parameters
+    ----------
+    ih : stream of spectra, shape (n_spec, n, ...)
+    response : array (n_tap, n)
+    sn : float
+        Effective signal-to-noise ratio of the Wiener filter.
+    pad_start, pad_end : int
+        Extra blocks of padding on each side of a frame (default 128).
+    samples_per_frame : int, optional
+        Output samples per frame (a multiple of n).
+    frequency, sideband, dtype : as for `Dechannelize`.
+    """
+    _plan = None
+
+    def __init__(self, ih, response, sn, pad_start=128, pad_end=128, samples_per_frame=None,
+                 frequency=None, sideband=None, dtype=None):
+        response = np.asanyarray(response)
+        n_tap, n = response.shape
+        if dtype is not None and np.dtype(dtype) != np.complex64:
+            raise NotImplementedError("the accelerated inverse filter bank produces complex64.")
+        self.dechannelized = Dechannelize(ih, n=n, frequency=frequency, sideband=sideband)
+        self._response = response
+        self._n = n
+        pad_minimum = (n_tap - 1) * n
+        assert pad_minimum % 2 == 0
+        self._FFT = fft_maker.get()
+        super().__init__(self.dechannelized, pad_start=pad_start * n + pad_minimum // 2,
+                         pad_end=pad_end * n + pad_minimum // 2,
+                         samples_per_frame=samples_per_frame, next_fast_len=self.next_fast_len)
+        if self._ih_samples_per_frame % n or self.samples_per_frame % n:
+            raise ValueError(f"frames must hold whole blocks of n={n} samples.")
+        self._reshape = (self._ih_samples_per_frame // n, n) + tuple(self.sample_shape)
+        self._inv_sn2 = 1. / (sn * sn)
+        self._n_stream = _prod(self.sample_shape)
+        self._ft_inverse_cache = None
+
+    def next_fast_len(self, m):
+        """A block count the engine transforms (power of two >= 256) times n."""
+        return max(self._FFT.next_fast_len(m), 256 * self._n)
+
+    @property
+    def _ft_inverse_response(self):
+        """Wiener deconvolution filter, shape (n_block, n, 1, ...) (pfb.py:234-246);
+        float64 arithmetic, cast to complex64."""
+        if self._ft_inverse_cache is None:
+            long_response = np.zeros(self._reshape[:2], np.complex128)
+            long_response[:self._response.shape[0]] = self._response
+            ft_response = np.fft.fft(long_response, axis=0).conj()
+            inverse = (ft_response.conj() / (ft_response.real ** 2 + ft_response.imag ** 2
+                                             + self._inv_sn2)) * (1 + self._inv_sn2)
+            self._ft_inverse_cache = inverse.astype(np.complex64).reshape(
+                inverse.shape + (1,) * len(self.sample_shape))
+        return self._ft_inverse_cache
+
+    def _get_plan(self):
+        if self._plan is None:
+            n, s = self._n, self._n_stream
+            columns = np.ascontiguousarray(self._ft_inverse_response.reshape(-1, n).T)
+            self._plan = hip.OsmPlan(self._reshape[0], n * s, columns,
+                                     np.repeat(np.arange(n, dtype=np.int32), s))
+        return self._plan
+
+    def _compute_frames(self, first, last, out):
+        plan = self._get_plan()
+        n, s, spf, n_in = self._n, self._n_stream, self.samples_per_frame, self._ih_samples_per_frame
+        frames = np.arange(first, last)
+        blocks = [self._block_start(m) for m in frames]
+        starts = np.array([b[0] for b in blocks], dtype=np.int64)
+        skips = np.array([b[1] for b in blocks], dtype=np.int64)
+        counts = np.minimum(spf - skips, self.shape[0] - frames * spf)       # samples kept per frame
+        keep = self._pad_start + skips                                        # first kept sample
+        off = int(keep[0] % n)                         # same for all frames (skips are whole blocks)
+        assert np.all(keep % n == off) and np.all(starts % n == 0)
+        n_blk = -(-(off + counts) // n)                                       # blocks computed per frame
+        tmp_off = np.concatenate([[0], np.cumsum(n_blk)[:-1]])
+        in0 = int(starts[0])
+        x = fetch_device(self.dechannelized, in0, int(starts[-1]) + n_in - in0)
+        x = x.reshape(x.shape[0] // n, n * s)
+        tmp = hip.DeviceArray((int(n_blk.sum()), n * s), np.complex64)
+        plan.execute(x, tmp, (starts - in0) // n, tmp_off, keep // n, n_blk)
+        tmp = tmp.reshape(int(n_blk.sum()) * n, s)
+        flat = out.reshape(out.shape[0], s)
+        base = first * spf
+        for m, t0, cnt in zip(frames, tmp_off, counts):
+            o = int(m * spf - base)
+            flat[o:o + int(cnt)].copy_from_device(tmp[int(t0) * n + off:int(t0) * n + off + int(cnt)])
+
+    def task(self, data):
+        raise NotImplementedError("frames are deconvolved on the GPU; use read().")
+
+    def close(self):
+        super().close()
+        self._drop_cache()
+        self._ft_inverse_cache = None
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None

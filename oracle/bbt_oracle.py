@@ -551,3 +551,43 @@ def disperse_samples_shift(sample_rate_hz, frequency_mhz, sideband, dm, complex_
         reference_frequency_mhz = frequency.mean()
     delay = time_delay(dm, frequency, reference_frequency_mhz)
     return np.round(delay * sample_rate_hz).astype(int)
+
+
+# --------------------------------------------------------------------------
+# pfb.py:157-269
+def inverse_pfb(z, response, sn, pad_start=128, pad_end=128, samples_per_frame=None,
+                ih_samples_per_frame=1, fast_len=next_fast_len, fft64=True):
+    """InversePolyphaseFilterBank(ih, response, sn, pad_start, pad_end).read()
+    for spectra ``z`` of shape (n_spec, n, ...): dechannelize, then per frame
+    FFT along the block axis, multiply by the Wiener inverse of the response,
+    inverse FFT, flatten, drop the padding.  Returns (y, geometry)."""
+    n_tap, n = response.shape
+    x = dechannelize(z, fft64)
+    pad_minimum = (n_tap - 1) * n
+    assert pad_minimum % 2 == 0
+    ps = pad_start * n + pad_minimum // 2
+    pe = pad_end * n + pad_minimum // 2
+
+    def nfl(m):                                   # pfb.py:227-232
+        m = fast_len(m)
+        res = m % n
+        return m - res + n if res else m
+    geo = padded_geometry(x.shape[0], ih_samples_per_frame * n, ps, pe, samples_per_frame, nfl)
+    nblk = geo['ih_spf'] // n
+    long_response = np.zeros((nblk, n), x.dtype)
+    long_response[:n_tap] = response
+    long_response = long_response.reshape(long_response.shape + (1,) * (x.ndim - 1))
+    ft_response = _fft(long_response, 0, fft64).conj()
+    inv_sn2 = 1. / (sn * sn)
+    inverse = (ft_response.conj() / (ft_response.real ** 2 + ft_response.imag ** 2 + inv_sn2)
+               * (1 + inv_sn2))
+
+    def task(data):
+        blk = data.reshape((nblk, n) + data.shape[1:])
+        ft = _fft(blk, 0, fft64)
+        ft *= inverse
+        result = _ifft(ft, 0, fft64)
+        result = result.reshape((-1,) + result.shape[2:])
+        return result[ps:result.shape[0] - pe]
+    geo['inverse_response'] = inverse
+    return overlap_save(x, geo, task), geo

@@ -32,7 +32,7 @@ from baseband_tasks.dispersion import Disperse, Dedisperse        # noqa: E402
 from baseband_tasks.dm import DispersionMeasure                   # noqa: E402
 from baseband_tasks.channelize import Channelize, Dechannelize    # noqa: E402
 from baseband_tasks.pfb import (sinc_hamming, PolyphaseFilterBank,  # noqa: E402
-                                PolyphaseFilterBankSamples)
+                                PolyphaseFilterBankSamples, InversePolyphaseFilterBank)
 from baseband_tasks.convolution import Convolve                   # noqa: E402
 from baseband_tasks.sampling import Resample, ShiftSamples        # noqa: E402
 from baseband_tasks.dispersion import DisperseSamples, DedisperseSamples  # noqa: E402
@@ -309,6 +309,20 @@ def main():
     out['sr_pfb'] = PolyphaseFilterBank(nr1, sinc_hamming(4, 256), samples_per_frame=8).read()
     nr.seek(0)
     out['sr_square'] = Square(nr).read(1000)
+
+    # ---- inverse polyphase filter bank (pfb.py:157-269), Wiener deconvolution along blocks
+    resp = sinc_hamming(4, 32)
+    nh = noise((25000, 2), 1. * u.MHz, 5000, 300. * u.MHz, 1, seed=22)
+    pfb = PolyphaseFilterBank(nh, resp, samples_per_frame=100)
+    out['sm_pfb_shape'] = np.array(pfb.shape)
+    ipfb = InversePolyphaseFilterBank(pfb, resp, sn=10., pad_start=16, pad_end=16,
+                                      samples_per_frame=8192 - 32 * 32 - 96)
+    g, shift = geometry(ipfb, pfb)
+    out['sm_ipfb_geo'] = g
+    out['sm_ipfb_shift'] = np.array([((ipfb.start_time - nh.start_time) * nh.sample_rate).to_value(u.one)])
+    out['sm_ipfb_rate'] = np.array([ipfb.sample_rate.to_value(u.Hz)])
+    out['sm_ipfb'] = ipfb.read()
+    out['sm_ipfb_resp'] = ipfb._ft_inverse_response[[0, 1, 100, 255], :, 0][:, [0, 5, 31]]
 
     # ---- config 5 geometry: Resample + Dedisperse, 8 streams
     nh = noise((8 * 2**20, 8), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)

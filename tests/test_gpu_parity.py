@@ -532,6 +532,27 @@ def test_real_valued_streams_golden(golden):
         bt.Power(nr, polarization=['XX', 'YY', 'XY', 'YX'])
 
 
+def test_inverse_polyphase_filter_bank_golden(golden):
+    """pfb.py:157-269 on the GPU: 64 streams (32 phases x 2 pol), one Wiener
+    response column per phase, half-block output offset."""
+    x = orc.noise_stream(22, 0, 25000, 5000, (2,))
+    resp = orc.sinc_hamming(4, 32)
+    z, _ = orc.polyphase_filter_bank(x, resp, ih_samples_per_frame=5000, samples_per_frame=100)
+    src = bt.StreamGenerator(lambda fh: z[fh.tell():fh.tell() + fh.samples_per_frame], z.shape, T0,
+                             1e6 / 32, samples_per_frame=100, frequency=300 * u.MHz, sideband=1)
+    ipfb = bt.InversePolyphaseFilterBank(src, resp, sn=10., pad_start=16, pad_end=16,
+                                         samples_per_frame=8192 - 32 * 32 - 96)
+    assert [ipfb._pad_start, ipfb._pad_end, ipfb._ih_samples_per_frame, ipfb.samples_per_frame,
+            ipfb.shape[0]] == list(golden['sm_ipfb_geo'][:5])
+    assert ipfb.sample_rate == golden['sm_ipfb_rate'][0] and ipfb.shape == (21280, 2)
+    assert np.abs(ipfb._ft_inverse_response[[0, 1, 100, 255], :, 0][:, [0, 5, 31]]
+                  - golden['sm_ipfb_resp']).max() < 1e-5
+    y = ipfb.read()
+    assert_parity(y, golden['sm_ipfb'], 'inverse pfb')
+    ipfb.seek(7000)
+    assert np.array_equal(ipfb.read(200), y[7000:7200])             # across a frame seam
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""
