@@ -4,7 +4,7 @@ import operator
 
 import numpy as np
 
-from . import hip, units as u
+from . import hip
 from .base import BaseTaskBase, _stream_rate, _stream_start
 from .device_task import DeviceTaskMixin, fetch_device
 from .functions import _DetectTask

@@ -110,7 +110,6 @@ def main():
     dev = torch.device('cuda', local_rank if world > 1 else 0)
 
     import baseband_tasks_amd as bt
-    from baseband_tasks_amd import units as u
     from baseband_tasks_amd import sharding
     bt.hip.set_device(dev.index)
     bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
