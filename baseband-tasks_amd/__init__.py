@@ -15,7 +15,7 @@ from .dm import DispersionMeasure
 from .fourier import fft_maker, HipFFTMaker
 from .dispersion import Disperse, Dedisperse, DisperseSamples, DedisperseSamples
 from .convolution import Convolve
-from .sampling import ShiftAndResample, Resample, ShiftSamples
+from .sampling import ShiftAndResample, Resample, TimeDelay, ShiftSamples
 from .channelize import Channelize, Dechannelize
 from .pfb import (sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples,
                   InversePolyphaseFilterBank)

@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 106
+#define BBT_VERSION 107
 
 // ---------------------------------------------------------------------------
 // errors
@@ -318,6 +318,30 @@ static int osm_flush_timing(bbt_osm_plan* p) {
     return 0;
 }
 
+#ifndef BBT_COL_TILE
+#define BBT_COL_TILE 16
+#endif
+static int g_col_tile = -1;
+static int col_tile() {
+    if (g_col_tile < 0) {
+        const char* env = getenv("BBT_COL_TILE");
+        g_col_tile = env ? atoi(env) : BBT_COL_TILE;
+        if (g_col_tile != 32) g_col_tile = 16;
+    }
+    return g_col_tile;
+}
+
+template <bool FIRST, bool SPEC>
+static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
+                          const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
+    if (col_tile() == 32 && row_len % 32 == 0)
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
+                           dim3(512), 0, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+    else
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
+                           dim3(256), 0, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+}
+
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
                          const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
@@ -345,8 +369,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         const int m_len = 16 * p->n2;
         const dim3 gout(m_len / 16 * p->npair, ch.nblk);
         const dim3 gmid(p->n2 / 256, ch.nblk * p->npair * 256);
-        hipLaunchKernelGGL((k_osm_col256<true, false>), gout, dim3(256), 0, st, in, out, work, ch,
-                           p->S, m_len, p->tab1.tw0, so);
+        launch_col256<true, false>(p, in, out, work, ch, m_len, so, st);
         hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                            p->wroot, 0);
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
@@ -355,19 +378,16 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                            p->wroot, nch ? 1 : 0);
         if (nch)
-            hipLaunchKernelGGL((k_osm_col256<false, true>), gout, dim3(256), 0, st, in, out, work, ch,
-                               p->S, m_len, p->tab1.tw0, so);
+            launch_col256<false, true>(p, in, out, work, ch, m_len, so, st);
         else
-            hipLaunchKernelGGL((k_osm_col256<false, false>), gout, dim3(256), 0, st, in, out, work,
-                               ch, p->S, m_len, p->tab1.tw0, so);
+            launch_col256<false, false>(p, in, out, work, ch, m_len, so, st);
     } else {
         const dim3 g16(p->n2 / 256 * p->npair, ch.nblk), g256(p->n2 / 16 * p->npair, ch.nblk);
         if (p->n1 == 16)
             hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
                                p->S, p->n2, so);
         else
-            hipLaunchKernelGGL((k_osm_col256<true, false>), g256, dim3(256), 0, st, in, out, work,
-                               ch, p->S, p->n2, p->tab1.tw0, so);
+            launch_col256<true, false>(p, in, out, work, ch, p->n2, so, st);
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
         if (launch_rowpass(p, work, ch, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
@@ -380,11 +400,9 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
                                    work, ch, p->S, p->n2, so);
         } else {
             if (nch)
-                hipLaunchKernelGGL((k_osm_col256<false, true>), g256, dim3(256), 0, st, in, out,
-                                   work, ch, p->S, p->n2, p->tab1.tw0, so);
+                launch_col256<false, true>(p, in, out, work, ch, p->n2, so, st);
             else
-                hipLaunchKernelGGL((k_osm_col256<false, false>), g256, dim3(256), 0, st, in, out,
-                                   work, ch, p->S, p->n2, p->tab1.tw0, so);
+                launch_col256<false, false>(p, in, out, work, ch, p->n2, so, st);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1040,6 +1058,22 @@ extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_
         case 2: hipLaunchKernelGGL((k_real_ops<2>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
         default: hipLaunchKernelGGL((k_real_ops<3>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// per-stream complex factor
+extern "C" int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_samples, int n_elem,
+                                 const void* factor_dev, bbt_stream stream) {
+    ARG_TRY(in_dev && out_dev && factor_dev, "bbt_scale_streams: null argument");
+    ARG_TRY(n_samples >= 0 && n_elem >= 1, "bbt_scale_streams: bad sizes");
+    const long long total = (long long)n_samples * n_elem;
+    if (total == 0) return 0;
+    ARG_TRY((total + 255) / 256 < (1ll << 31), "bbt_scale_streams: too many elements for one call");
+    hipLaunchKernelGGL(k_scale_streams, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float2*)in_dev, (float2*)out_dev, total, n_elem,
+                       (const float2*)factor_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -229,12 +229,12 @@ __global__ __launch_bounds__(N / 16) void k_osm_small(const float2* __restrict__
     const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
-    wg_fft<N, -1, false>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N, -1, 0>(v, lds, tau, 0, tw0, tw1);
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (long long)c0 * N + tau;
     const cf* h1 = resp + (long long)c1 * N + tau;
     apply_resp<T>(v, h0, h1, c0 == c1);
-    wg_fft<N, +1, false>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N, +1, 0>(v, lds, tau, 0, tw0, tw1);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int r = tau + T * j - blk.valid_start;
@@ -280,19 +280,21 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     }
 }
 
-// Column pass, N1 == 256: 256 threads = 16 two-stream columns (f, fastest
-// lane index -> 256-byte runs per row) x 16 threads per 256-point transform.
-template <bool FIRST, bool SPEC = false>
-__global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ in,
-                                                    float2* __restrict__ out,
-                                                    float2* __restrict__ work, OsmChunk ch, int S,
-                                                    int N2, const cf* __restrict__ tw0, SpecOut so) {
+// Column pass, N1 == 256: FCOL two-stream columns (f, fastest lane index ->
+// FCOL * 16-byte runs per row: 256 B for 16, 512 B for 32) x 16 threads per
+// 256-point transform; FCOL * 16 threads per workgroup.
+template <bool FIRST, bool SPEC, int FCOL>
+__global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restrict__ in,
+                                                          float2* __restrict__ out,
+                                                          float2* __restrict__ work, OsmChunk ch,
+                                                          int S, int N2, const cf* __restrict__ tw0,
+                                                          SpecOut so) {
     typedef FftGeo<256> G;
-    __shared__ v2 lds[G::LDS_ELEMS * 16];
-    const int f = threadIdx.x & 15, tau = threadIdx.x >> 4;
+    __shared__ v2 lds[G::LDS_ELEMS * FCOL];
+    const int f = threadIdx.x % FCOL, tau = threadIdx.x / FCOL;
     const int npair = S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int n2 = (vb / npair) * 16 + f;
+    const int n2 = (vb / npair) * FCOL + f;
     const int b = blockIdx.y, sp = vb % npair;
     const OsmBlock blk = ch.b[b];
     // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*256 + k1)*N2 + n2
@@ -302,13 +304,13 @@ __global__ __launch_bounds__(256) void k_osm_col256(const float2* __restrict__ i
         const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)16 * j * N2 * S);
-        wg_fft<256, -1, true>(v, lds, tau, f, tw0, nullptr);
+        wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
-        wg_fft<256, +1, true>(v, lds, tau, f, tw0, nullptr);
+        wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (SPEC) {
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
     const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
-    wg_fft<N2, -1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, -1, 0, IMOFF>(v, lds, tau, 0, tw0, tw1);
     apply_resp<T>(v, h0, h1, c0 == c1);
     if constexpr (NCH > 0) {
         const int shift = ch.b[bp / npair].shift;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
             }
         }
     }
-    wg_fft<N2, +1, false, IMOFF>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, +1, 0, IMOFF>(v, lds, tau, 0, tw0, tw1);
     if (NCH > 0 && outer > 1) {
         // Three-level + fused channelizer: the outer four-step twiddle
         // W_N^{(N2 a + n2) k1o} has a factor that depends on n2; it must act
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
             for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
         }
         // the 16 sequences f = q P + c, one element b = tau each: T-point transforms over b
-        wg_fft_tail<N2, -1, false, IMOFF>(v, lds, tau, 0, tw1);
+        wg_fft_tail<N2, -1, 0, IMOFF>(v, lds, tau, 0, tw1);
         // thread tau2: register u + NU c2 holds k' = (g + R2 u) + 16 c2 of sequence f = tau2 & 15
         constexpr int R2 = G::R2, NU = 16 / R2;
         const int f = tau & 15, g = tau >> 4;
@@ -532,10 +534,10 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
     c2 va[16], vb[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) va[j] = ld_ext(za + (long long)T * j * 2);
-    wg_fft<NCH, +1, false>(va, lds, tau, 0, tw0, tw1);
+    wg_fft<NCH, +1, 0>(va, lds, tau, 0, tw0, tw1);
 #pragma unroll
     for (int j = 0; j < 16; ++j) vb[j] = ld_ext(zb + (long long)T * j * 2);
-    wg_fft<NCH, +1, false>(vb, lds, tau, 0, tw0, tw1);
+    wg_fft<NCH, +1, 0>(vb, lds, tau, 0, tw0, tw1);
     const float scale = 1.0f / (float)NCH;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
         va[j].re = (early ? va[j].re : vb[j].re) * scale;
         va[j].im = (early ? va[j].im : vb[j].im) * scale;
     }
-    wg_fft<NCH, -1, false>(va, lds, tau, 0, tw0, tw1);
+    wg_fft<NCH, -1, 0>(va, lds, tau, 0, tw0, tw1);
     float2* dst = out + ((job.spectrum * NCH + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, va[j]);
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
             }
         }
     }
-    wg_fft<N, -1, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    wg_fft<N, -1, 0>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
     if (active) {
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
 #pragma unroll
         for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
     }
-    wg_fft_tail<4096, -1, false>(v, lds, tau, 0, tw1);
+    wg_fft_tail<4096, -1, 0>(v, lds, tau, 0, tw1);
     const int f = tau & 15, g = tau >> 4;
     const int q = f / P, c = f - q * P;
     if (i0 + q < n_spec) {
@@ -793,6 +795,16 @@ __global__ __launch_bounds__(256) void k_real_ops(const void* __restrict__ in_,
         }
         ((float2*)out_)[t] = z;
     }
+}
+
+// Per-stream complex factor (reference sampling.py:374-377, TimeDelay.task:
+// data *= phase_factor): out[i, e] = in[i, e] * factor[e].
+__global__ __launch_bounds__(256) void k_scale_streams(const float2* __restrict__ in,
+                                                       float2* __restrict__ out, long long n_total,
+                                                       int n_elem, const float2* __restrict__ factor) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_total) return;
+    out[t] = cmul(in[t], factor[t % n_elem]);
 }
 
 }  // namespace bbt

@@ -179,11 +179,11 @@ struct FftGeo {
 };
 
 // LDS placement of one transform's exchange area.
-//   ROWMODE:  idx(inner) = inner            (lds already offset to this FFT's slot)
-//   COLMODE:  idx(inner) = inner * 16 + f   (16 transforms interleaved, f fastest)
-template <bool COLMODE>
+//   COLMODE == 0 (row mode):  idx(inner) = inner           (lds already offset to this FFT's slot)
+//   COLMODE == F (16 or 32):  idx(inner) = inner * F + f   (F transforms interleaved, f fastest)
+template <int COLMODE>
 __device__ __forceinline__ int lds_idx(int inner, int f) {
-    return COLMODE ? inner * 16 + f : inner;
+    return COLMODE ? inner * COLMODE + f : inner;
 }
 
 // One workgroup-cooperative FFT of both streams of a pair, as building blocks
@@ -219,7 +219,7 @@ __device__ __forceinline__ void fft_butterfly_twiddle(c2 (&v)[16], const cf (&w)
 }
 
 // exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
-template <int N, bool COLMODE, int IMOFF>
+template <int N, int COLMODE, int IMOFF>
 __device__ __forceinline__ void fft_exchange0(c2 (&v)[16], v2* __restrict__ lds, int tau, int f) {
     typedef FftGeo<N> G;
     constexpr int R2 = G::R2;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void fft_exchange0(c2 (&v)[16], v2* __restrict__ lds,
 
 // exchange 1: (c0, c1, b1) -> thread (c0 + 16 g), c1 = g + R2 u ; then the
 // radix-R2 stage.  No-op for N == 256.
-template <int N, int SIGN, bool COLMODE, int IMOFF>
+template <int N, int SIGN, int COLMODE, int IMOFF>
 __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict__ lds, int tau, int f) {
     typedef FftGeo<N> G;
     constexpr int R2 = G::R2;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
 // sequence c0 = tau2 & 15 -- for the full transform that is element
 // tau2 + T * register (k = c0 + 16 k').  The fused channelizer and the PFB
 // enter here with their own stage 0.
-template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
+template <int N, int SIGN, int COLMODE, int IMOFF = 0>
 __device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                             const cf* __restrict__ tw1) {
     fft_exchange0<N, COLMODE, IMOFF>(v, lds, tau, f);
@@ -313,7 +313,7 @@ __device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, i
     fft_exchange1_stage2<N, SIGN, COLMODE, IMOFF>(v, lds, tau, f);
 }
 
-template <int N, int SIGN, bool COLMODE, int IMOFF = 0>
+template <int N, int SIGN, int COLMODE, int IMOFF = 0>
 __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                        const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
     cf w0[15];

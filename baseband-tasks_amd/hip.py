@@ -73,6 +73,7 @@ SIGNATURES = {
     'bbt_shift_plan_destroy': [_vp],
     'bbt_shift_execute': [_vp, _vp, _vp, _i64, _vp],
     'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
+    'bbt_scale_streams': [_vp, _vp, _i64, _int, _vp, _vp],
 }
 
 _lib = None
@@ -378,6 +379,11 @@ def keep_half_spectrum(z, n_chan, n_stream, out):
 def square_real(x, out):
     check(lib().bbt_real_op(x.ptr, out.ptr, 3, out.size, 0, 0, _stream))
     return out
+
+
+def scale_streams(x, out, n_samples, n_elem, factor_dev):
+    """out[i, e] = x[i, e] * factor[e] (complex64)."""
+    check(lib().bbt_scale_streams(x.ptr, out.ptr, int(n_samples), int(n_elem), factor_dev.ptr, _stream))
 
 
 class _Plan:

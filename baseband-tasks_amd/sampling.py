@@ -4,12 +4,13 @@ import numpy as np
 
 from . import units as u
 from . import hip
-from .base import PaddedTaskBase, check_broadcast_to, _stream_rate, _stream_start
+from .base import PaddedTaskBase, TaskBase, check_broadcast_to, _stream_rate, _stream_start
 from .device_task import DeviceTaskMixin, fetch_device
 from .convolution import Convolve
 from .units import Time
 
-__all__ = ['to_sample', 'seek_float', 'ShiftAndResample', 'Resample', 'ShiftSamples']
+__all__ = ['to_sample', 'seek_float', 'ShiftAndResample', 'Resample', 'TimeDelay',
+           'ShiftSamples']
 
 
 def to_sample(ih, offset):
@@ -97,6 +98,55 @@ class Resample(ShiftAndResample):
         super().__init__(ih, shift=0., offset=offset, whence=whence, pad=pad,
                          samples_per_frame=samples_per_frame)
         self.seek(_stream_start(ih) + float(self._offset) / _stream_rate(ih))
+
+
+class TimeDelay(DeviceTaskMixin, TaskBase):
+    """Delay a complex stream: the delay is added to the time stamps and, if
+    the signal was mixed with local oscillator ``lo`` (Hz) before sampling, the
+    phases are rotated by ``-delay * lo * sideband`` cycles (no resampling;
+    reference sampling.py:315-377).  ``lo=None`` means no rotation."""
+
+    def __init__(self, ih, delay, *, lo, frequency=None, sideband=None):
+        assert np.dtype(ih.dtype).kind == 'c', "Time delay only works on complex data."
+        if np.dtype(ih.dtype) != np.complex64:
+            raise TypeError(f"the accelerated TimeDelay handles complex64 streams; got {ih.dtype}.")
+        self._delay = to_sample(ih, delay)
+        self._lo = None if lo is None else u.to_hz(lo)
+        seconds = self._delay / _stream_rate(ih)
+        super().__init__(ih, frequency=frequency, sideband=sideband)
+        self._start_time = self._start_time + float(seconds)
+        if self._lo is None:
+            self._phase_factor = None
+        else:
+            cycles = seconds * self._lo * self.sideband
+            self._phase_factor = np.exp(-2j * np.pi * cycles).astype(np.complex64)
+        self._factor_dev = None
+
+    def _compute_frames(self, first, last, out):
+        start, stop = self._frame_span(first, last)
+        x = fetch_device(self.ih, start, stop - start)
+        if self._phase_factor is None:
+            out.copy_from_device(x)
+            return
+        n_elem = 1
+        for d in self.sample_shape:
+            n_elem *= d
+        hip.scale_streams(x, out, stop - start, n_elem, self._factor())
+
+    def _factor(self):
+        if self._factor_dev is None:
+            self._factor_dev = hip.DeviceArray.from_host(np.ascontiguousarray(
+                np.broadcast_to(self._phase_factor, self.sample_shape)).ravel())
+        return self._factor_dev
+
+    def task(self, data):
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        if self._phase_factor is None:
+            return data
+        out = hip.DeviceArray(data.shape, np.complex64)
+        hip.scale_streams(hip.DeviceArray.from_host(data), out, data.shape[0],
+                          data.size // max(data.shape[0], 1), self._factor())
+        return out.to_host()
 
 
 class ShiftSamples(DeviceTaskMixin, PaddedTaskBase):

@@ -192,6 +192,12 @@ int bbt_shift_execute(bbt_shift_plan* plan, const void* in_dev, void* out_dev, i
 int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
                 int n_stream, bbt_stream stream);
 
+/* Per-stream complex factor: out[i, e] = in[i, e] * factor_dev[e] for the n_elem
+ * complex64 elements of a complete sample (TimeDelay.task, sampling.py:374-377).
+ * In-place (out_dev == in_dev) is allowed. */
+int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_samples, int n_elem,
+                      const void* factor_dev, bbt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

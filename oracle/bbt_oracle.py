@@ -591,3 +591,12 @@ def inverse_pfb(z, response, sn, pad_start=128, pad_end=128, samples_per_frame=N
         return result[ps:result.shape[0] - pe]
     geo['inverse_response'] = inverse
     return overlap_save(x, geo, task), geo
+
+
+# --------------------------------------------------------------------------
+# sampling.py:315-377
+def time_delay_stream(x, delay_s, lo_hz, sideband):
+    """TimeDelay.task: x * exp(-2 pi i delay lo sideband) (complex64 factor);
+    the stream's start time moves by ``delay_s``."""
+    factor = np.exp(-2j * np.pi * delay_s * lo_hz * np.asanyarray(sideband)).astype(x.dtype)
+    return x * factor

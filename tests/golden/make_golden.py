@@ -34,7 +34,7 @@ from baseband_tasks.channelize import Channelize, Dechannelize    # noqa: E402
 from baseband_tasks.pfb import (sinc_hamming, PolyphaseFilterBank,  # noqa: E402
                                 PolyphaseFilterBankSamples, InversePolyphaseFilterBank)
 from baseband_tasks.convolution import Convolve                   # noqa: E402
-from baseband_tasks.sampling import Resample, ShiftSamples        # noqa: E402
+from baseband_tasks.sampling import Resample, ShiftSamples, TimeDelay  # noqa: E402
 from baseband_tasks.dispersion import DisperseSamples, DedisperseSamples  # noqa: E402
 from baseband_tasks.functions import Square, Power               # noqa: E402
 from baseband_tasks.integration import Integrate                 # noqa: E402
@@ -323,6 +323,12 @@ def main():
     out['sm_ipfb_rate'] = np.array([ipfb.sample_rate.to_value(u.Hz)])
     out['sm_ipfb'] = ipfb.read()
     out['sm_ipfb_resp'] = ipfb._ft_inverse_response[[0, 1, 100, 255], :, 0][:, [0, 5, 31]]
+
+    # ---- TimeDelay (sampling.py:315-377)
+    nh = noise((3000, 2), 1. * u.MHz, 1000, 300. * u.MHz, np.array([1, -1]), seed=23)
+    td = TimeDelay(nh, 1.234 * u.us, lo=300. * u.MHz)
+    out['st_delay'] = td.read()
+    out['st_delay_shift'] = np.array([((td.start_time - nh.start_time) * nh.sample_rate).to_value(u.one)])
 
     # ---- config 5 geometry: Resample + Dedisperse, 8 streams
     nh = noise((8 * 2**20, 8), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)

@@ -553,6 +553,17 @@ def test_inverse_polyphase_filter_bank_golden(golden):
     assert np.array_equal(ipfb.read(200), y[7000:7200])             # across a frame seam
 
 
+def test_time_delay_golden(golden):
+    nh = noise(3000, (2,), 1000, seed=23, fs=1 * u.MHz, frequency=300 * u.MHz,
+               sideband=np.array([1, -1]))
+    td = bt.TimeDelay(nh, 1.234 * u.us * 1e6, lo=300 * u.MHz)      # delay in samples (1 MHz)
+    assert abs((td.start_time - nh.start_time) * 1e6 - golden['st_delay_shift'][0]) < 1e-6
+    y = td.read()
+    assert np.abs(y - golden['st_delay']).max() < 2e-6
+    nh.seek(0)
+    assert np.array_equal(bt.TimeDelay(nh, 3., lo=None).read(10), orc.noise_stream(23, 0, 10, 1000, (2,)))
+
+
 def test_giant_pulse_round_trip():
     """Reference tests/test_dispersion.py:103-124: Disperse then Dedisperse
     recovers a unit impulse (atol 1e-2 default frames, 1e-4 for 50000)."""

@@ -337,3 +337,10 @@ def test_inverse_pfb(golden):
     assert abs(48 + g['pad_start'] - golden['sm_ipfb_shift'][0]) < 1e-3
     lag = g['pad_start']
     assert rel_l2(y[2000:4000], x[lag + 2000:lag + 4000]) < 0.1
+
+
+def test_time_delay(golden):
+    x = orc.noise_stream(23, 0, 3000, 1000, (2,))
+    y = orc.time_delay_stream(x, 1.234e-6, 300e6, np.array([1, -1]))
+    assert np.abs(y - golden['st_delay']).max() < 2e-6
+    assert abs(golden['st_delay_shift'][0] - 1.234) < 1e-6
