@@ -166,25 +166,59 @@ struct SpecOut {
     int n_fft;           // N = N1 * N2
 };
 
-// Fused channelizer output of block-local element (n1, slot) of row length N2:
-// slot = q * n_chan + ch is channel ch of the spectrum whose samples are the
-// (circularly shifted) block samples [n1*N2 + q*n_chan, +n_chan).  n_chan is
-// a power of two (lg_chan), all block-local indices fit 32 bits.
-__device__ __forceinline__ void emit_spectrum(c2 val, float2* __restrict__ out, const SpecOut& so,
-                                              const OsmBlock& blk, int row_start, int slot, int S,
-                                              int sp, int npair) {
-    const int lg = so.lg_chan, nch = 1 << lg;
-    const int ch = slot & (nch - 1);
-    int ystart = row_start + (slot - ch) + blk.shift;     // first sample, unshifted block index
-    if (ystart + nch > so.n_fft) ystart -= so.n_fft;      // the one wrapped group
-    const int rel = ystart - blk.valid_start;              // w.r.t. the first kept sample
-    if (rel >= 0 && rel + nch <= blk.valid_count) {
-        const long long s = ((blk.out_off + rel) >> lg) - so.s_base;
-        if (s >= 0 && s < so.n_out) st_ext(out + (((s << lg) + ch) * S + 2 * sp), val);
-    } else if (rel < 0 && rel + nch > 0) {                 // straddles the block start
-        st_ext(so.seam + (((((long long)blk.index * 2 + 0) * npair + sp) << lg) + ch) * 2, val);
-    } else if (rel < blk.valid_count && rel + nch > blk.valid_count) {  // straddles the block end
-        st_ext(so.seam + (((((long long)blk.index * 2 + 1) * npair + sp) << lg) + ch) * 2, val);
+// Fused channelizer output.  A column-pass thread holds, for one column
+// `slot` = q * n_chan + ch of the work rows, the rows n1 = row0 + 16 j (j < 16,
+// N1 == 256) or n1 = j (N1 == 16): element j is channel ch of the spectrum
+// whose samples are the (circularly shifted) block samples
+// [n1 * N2 + q * n_chan, + n_chan).  Everything is linear in j, so the
+// per-thread part is computed once: position of the group relative to the
+// first kept sample (rel), its stride, and the output pointer and stride.
+struct SpecCursor {
+    float2* dst;        // where a fully valid element j == 0 would go
+    long long dstride;  // float2 units per j
+    float2* seam0;      // this thread's slot in the block's head / tail seam spectrum
+    float2* seam1;
+    int rel, drel;      // group start minus valid_start, and its step per j
+    int wrap_at;        // rel value from which the group wraps around the block end
+    int n_fft, nch, vc;
+    long long s0, ds, n_out;   // spectrum index (relative to out[0]) and its step per j
+};
+__device__ __forceinline__ SpecCursor spec_cursor(float2* __restrict__ out, const SpecOut& so,
+                                                  const OsmBlock& blk, int row0, int row_step,
+                                                  int N2, int slot, int S, int sp, int npair) {
+    SpecCursor c;
+    const int lg = so.lg_chan;
+    c.nch = 1 << lg;
+    const int ch = slot & (c.nch - 1);
+    c.n_fft = so.n_fft;
+    c.vc = blk.valid_count;
+    c.rel = row0 * N2 + (slot - ch) + blk.shift - blk.valid_start;
+    c.drel = row_step * N2;
+    c.wrap_at = so.n_fft - c.nch - blk.valid_start + 1;      // rel >= wrap_at  <=>  ystart + nch > N
+    c.s0 = ((blk.out_off + c.rel) >> lg) - so.s_base;        // (arithmetic shift: exact multiples)
+    c.ds = (long long)c.drel >> lg;
+    c.n_out = so.n_out;
+    c.dst = out + (((c.s0 << lg) + ch) * S + 2 * sp);
+    c.dstride = ((c.ds << lg)) * S;
+    c.seam0 = so.seam + (((((long long)blk.index * 2 + 0) * npair + sp) << lg) + ch) * 2;
+    c.seam1 = so.seam + (((((long long)blk.index * 2 + 1) * npair + sp) << lg) + ch) * 2;
+    return c;
+}
+__device__ __forceinline__ void emit_spectrum(c2 val, const SpecCursor& c, int j) {
+    int rel = c.rel + j * c.drel;
+    if (rel >= c.wrap_at) {
+        // the one group that wraps around the end of the block: it sits before sample 0
+        rel -= c.n_fft;
+        if (rel < 0 && rel + c.nch > 0) st_ext(c.seam0, val);
+        return;
+    }
+    if (rel >= 0 && rel + c.nch <= c.vc) {
+        const long long s = c.s0 + j * c.ds;
+        if (s >= 0 && s < c.n_out) st_ext(c.dst + j * c.dstride, val);
+    } else if (rel < 0 && rel + c.nch > 0) {                  // straddles the block start
+        st_ext(c.seam0, val);
+    } else if (rel < c.vc && rel + c.nch > c.vc) {            // straddles the block end
+        st_ext(c.seam1, val);
     }
 }
 
@@ -267,10 +301,12 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)j * N2 * 2);
         radix16<+1>(v);
+        SpecCursor cur;
+        if (SPEC) cur = spec_cursor(out, so, blk, 0, 1, N2, n2, S, sp, npair);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (SPEC) {
-                emit_spectrum(v[j], out, so, blk, j * N2, n2, S, sp, npair);
+                emit_spectrum(v[j], cur, j);
             } else {
                 const int r = j * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
@@ -311,10 +347,12 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
         wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
+        SpecCursor cur;
+        if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, n2, S, sp, npair);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (SPEC) {
-                emit_spectrum(v[j], out, so, blk, (tau + 16 * j) * N2, n2, S, sp, npair);
+                emit_spectrum(v[j], cur, j);
             } else {
                 const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
