@@ -237,6 +237,7 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms) {
 
 // ---------------------------------------------------------------------------
 // overlap-save spectral multiply
+#define BBT_MAX_LANES 8
 struct bbt_osm_plan {
     int device = 0;
     int64_t n = 0;
@@ -253,9 +254,9 @@ struct bbt_osm_plan {
     // column passes of one chunk run beside the latency-bound row pass of
     // another and fill each other's launch tails.
     int lanes = 1;
-    float2* lane_work[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    float2* lane_work[BBT_MAX_LANES] = {};
+    hipStream_t lane_stream[BBT_MAX_LANES] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[BBT_MAX_LANES] = {};
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     cf* wroot = nullptr;
@@ -541,14 +542,16 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             hipSuccess)
         return bail(fail("bbt_osm_plan_create: resp_index upload failed"));
 
-    // workspace: `lanes` work buffers of `chunk` blocks each, 128 MiB in total
-    // (measured best on MI355X: the buffers stay within the 256 MiB Infinity
-    // Cache between passes while each launch still has >= 1024 workgroups)
+    // workspace: `lanes` work buffers of `chunk` blocks each, 192 MiB in total.
+    // Measured on MI355X (2-pol 2^20 blocks): 2 x 6 blocks is best; a launch of
+    // 6 blocks is 1536 row-pass workgroups = exactly two rounds of the 768
+    // resident ones, while 2 x 12 (384 MiB) falls out of the 256 MiB Infinity
+    // Cache and loses 6 % although every pass alone is faster.
     int lanes = 2;
     if (const char* env = getenv("BBT_OSM_LANES")) lanes = atoi(env);
-    lanes = lanes < 1 ? 1 : (lanes > 4 ? 4 : lanes);
+    lanes = lanes < 1 ? 1 : (lanes > BBT_MAX_LANES ? BBT_MAX_LANES : lanes);
     const size_t per_block = (size_t)p->npair * n_fft * 16;
-    int chunk = (int)((128u << 20) / per_block / lanes);
+    int chunk = (int)((192u << 20) / per_block / lanes);
     if (const char* env = getenv("BBT_OSM_CHUNK")) chunk = atoi(env);
     if (chunk < 1) chunk = 1;
     if (chunk > BBT_MAX_CHUNK) chunk = BBT_MAX_CHUNK;
@@ -585,7 +588,7 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     for (auto e : p->ev) hipEventDestroy(e);
     if (p->resp) hipFree(p->resp);
     if (p->resp_index) hipFree(p->resp_index);
-    for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < BBT_MAX_LANES; ++l) {
         if (p->lane_stream[l]) {
             hipStreamSynchronize(p->lane_stream[l]);
             hipStreamDestroy(p->lane_stream[l]);

@@ -58,8 +58,13 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
     c2 v[16];
     if (active) {
         const float2* src = in + ((i * N + tau) * S + 2 * sp);
+        if (S == 2) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext_nt(src + (long long)T * j * S);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = czero();
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            st_ext(dst + (long long)T * j * S, c2{v[j].re * scale, v[j].im * scale});
+            st_ext(dst + (long long)T * j * S, c2{v[j].re * scale, v[j].im * scale}, S == 2);
     }
 }
 
@@ -182,6 +187,7 @@ struct SpecCursor {
     int wrap_at;        // rel value from which the group wraps around the block end
     int n_fft, nch, vc;
     long long s0, ds, n_out;   // spectrum index (relative to out[0]) and its step per j
+    bool nt;                   // whole-line output stream (S == 2): non-temporal stores
 };
 __device__ __forceinline__ SpecCursor spec_cursor(float2* __restrict__ out, const SpecOut& so,
                                                   const OsmBlock& blk, int row0, int row_step,
@@ -198,6 +204,7 @@ __device__ __forceinline__ SpecCursor spec_cursor(float2* __restrict__ out, cons
     c.s0 = ((blk.out_off + c.rel) >> lg) - so.s_base;        // (arithmetic shift: exact multiples)
     c.ds = (long long)c.drel >> lg;
     c.n_out = so.n_out;
+    c.nt = S == 2;
     c.dst = out + (((c.s0 << lg) + ch) * S + 2 * sp);
     c.dstride = ((c.ds << lg)) * S;
     c.seam0 = so.seam + (((((long long)blk.index * 2 + 0) * npair + sp) << lg) + ch) * 2;
@@ -214,7 +221,7 @@ __device__ __forceinline__ void emit_spectrum(c2 val, const SpecCursor& c, int j
     }
     if (rel >= 0 && rel + c.nch <= c.vc) {
         const long long s = c.s0 + j * c.ds;
-        if (s >= 0 && s < c.n_out) st_ext(c.dst + j * c.dstride, val);
+        if (s >= 0 && s < c.n_out) st_ext(c.dst + j * c.dstride, val, c.nt);
     } else if (rel < 0 && rel + c.nch > 0) {                  // straddles the block start
         st_ext(c.seam0, val);
     } else if (rel < c.vc && rel + c.nch > c.vc) {            // straddles the block end
@@ -292,8 +299,13 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     c2 v[16];
     if (FIRST) {
         const float2* src = in + ((blk.in_off + n2) * S + 2 * sp);
+        if (S == 2) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)j * N2 * S);
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext_nt(src + (long long)j * N2 * S);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)j * N2 * S);
+        }
         radix16<-1>(v);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(w + (long long)j * N2 * 2, v[j]);
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
             } else {
                 const int r = j * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
-                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
+                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
             }
         }
     }
@@ -338,8 +350,13 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     c2 v[16];
     if (FIRST) {
         const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
+        if (S == 2) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)16 * j * N2 * S);
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)16 * j * N2 * S);
+        }
         wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
             } else {
                 const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
-                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
+                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
             }
         }
     }
@@ -644,7 +661,7 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
     if (active) {
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, v[j]);
+        for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, v[j], S == 2);
     }
 }
 
@@ -726,7 +743,7 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
         float2* dst = out + (((i0 + q) * N + c) * S + 2 * sp);
 #pragma unroll
         for (int c2i = 0; c2i < 16; ++c2i)
-            st_ext(dst + (long long)(P * (g + 16 * c2i)) * S, v[c2i]);
+            st_ext(dst + (long long)(P * (g + 16 * c2i)) * S, v[c2i], S == 2);
     }
 }
 

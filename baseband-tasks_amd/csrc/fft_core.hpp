@@ -333,6 +333,23 @@ __device__ __forceinline__ c2 ld_ext(const float2* p) {
 __device__ __forceinline__ void st_ext(float2* p, c2 a) {
     *reinterpret_cast<float4*>(p) = make_float4(a.re.x, a.im.x, a.re.y, a.im.y);
 }
+// Non-temporal forms for streams that are touched once in whole cache lines
+// (S == 2: one complete sample per 16 bytes).  Measured on MI355X: the output
+// stores of the last column pass +10 %, Channelize alone 165 -> 185 Gsamples/s,
+// because the stream stops displacing the work buffers from L2 / Infinity
+// Cache.  Not for S > 2 (pairs share lines: -40 %) nor for re-read inputs (PFB).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c2 ld_ext_nt(const float2* p) {
+    const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return c2{v2{x.x, x.z}, v2{x.y, x.w}};
+}
+__device__ __forceinline__ void st_ext_nt(float2* p, c2 a) {
+    const f4v x = {a.re.x, a.im.x, a.re.y, a.im.y};
+    __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(p));
+}
+__device__ __forceinline__ void st_ext(float2* p, c2 a, bool nt) {
+    if (nt) st_ext_nt(p, a); else st_ext(p, a);
+}
 __device__ __forceinline__ c2 ld_int(const float2* p) {
     const float4 x = *reinterpret_cast<const float4*>(p);
     return c2{v2{x.x, x.y}, v2{x.z, x.w}};
