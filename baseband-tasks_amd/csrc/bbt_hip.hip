@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 107
+#define BBT_VERSION 108
 
 // ---------------------------------------------------------------------------
 // errors
@@ -116,6 +116,26 @@ static int get_wroot(cf** out) {
 
 static bool fft_len_ok(int64_t n) { return is_pow2(n) && n >= 256 && n <= 4096; }
 
+struct DevicePool {
+    std::mutex mu;
+    std::map<int, std::multimap<size_t, void*>> free_blocks;        // device -> size -> block
+    std::map<void*, std::pair<size_t, int>> live;                   // block -> (size, device)
+    size_t cached = 0;
+    static size_t limit() {                      // cached (idle) bytes kept at most; BBT_POOL_MAX_GB
+        static const size_t lim = [] {
+            const char* e = getenv("BBT_POOL_MAX_GB");
+            return (size_t)(e ? atof(e) : 96.0) << 30;
+        }();
+        return lim;
+    }
+    static bool enabled() {
+        static const bool on = [] { const char* e = getenv("BBT_POOL"); return !(e && atoi(e) == 0); }();
+        return on;
+    }
+};
+static DevicePool g_pool;
+extern "C" int bbt_pool_trim(void);
+
 // ---------------------------------------------------------------------------
 extern "C" {
 
@@ -146,13 +166,85 @@ int bbt_device_name(char* buf, int buflen) {
     return 0;
 }
 
+// Device memory comes from a caching pool: hipMalloc / hipFree of the GB-sized
+// stream buffers a reader allocates per call cost milliseconds and hipFree
+// synchronises the device, which would serialise consecutive calls.  Freed
+// blocks are kept (per device, by size) and handed out again for requests of
+// up to 1/8 less; reuse is ordered by the caller's stream, as every consumer of
+// a block is enqueued on it before the block is freed (plans join their
+// internal streams before returning).  BBT_POOL=0 disables caching.
 int bbt_malloc(void** dev_ptr, size_t nbytes) {
     ARG_TRY(dev_ptr, "bbt_malloc: null argument");
-    HIP_TRY(hipMalloc(dev_ptr, nbytes ? nbytes : 1));
+    if (!nbytes) nbytes = 1;
+    const size_t gran = nbytes >= (1u << 20) ? (size_t)2 << 20 : 512;
+    const size_t want = (nbytes + gran - 1) / gran * gran;
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_pool.mu);
+        auto& free_blocks = g_pool.free_blocks[dev];
+        auto it = free_blocks.lower_bound(want);
+        if (it != free_blocks.end() && it->first - want <= want / 8) {
+            *dev_ptr = it->second;
+            g_pool.cached -= it->first;
+            g_pool.live[it->second] = {it->first, dev};
+            free_blocks.erase(it);
+            return 0;
+        }
+    }
+    hipError_t e = hipMalloc(dev_ptr, want);
+    if (e != hipSuccess) {                      // give cached blocks back and retry once
+        (void)hipGetLastError();
+        if (bbt_pool_trim()) return 1;
+        e = hipMalloc(dev_ptr, want);
+    }
+    if (e != hipSuccess) {
+        *dev_ptr = nullptr;
+        return fail("bbt_malloc: hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    g_pool.live[*dev_ptr] = {want, dev};
     return 0;
 }
 int bbt_free(void* dev_ptr) {
-    if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+    if (!dev_ptr) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_pool.mu);
+        auto it = g_pool.live.find(dev_ptr);
+        if (it == g_pool.live.end()) return fail("bbt_free: pointer was not allocated by bbt_malloc");
+        const size_t size = it->second.first;
+        const int dev = it->second.second;
+        g_pool.live.erase(it);
+        if (g_pool.enabled() && g_pool.cached + size <= g_pool.limit()) {
+            g_pool.free_blocks[dev].emplace(size, dev_ptr);
+            g_pool.cached += size;
+            return 0;
+        }
+    }
+    HIP_TRY(hipFree(dev_ptr));
+    return 0;
+}
+int bbt_pool_trim(void) {
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lock(g_pool.mu);
+        for (auto& per_dev : g_pool.free_blocks) {
+            for (auto& b : per_dev.second) blocks.push_back(b.second);
+            per_dev.second.clear();
+        }
+        g_pool.cached = 0;
+    }
+    for (void* b : blocks) HIP_TRY(hipFree(b));
+    return 0;
+}
+int bbt_pool_info(int64_t* cached_bytes, int64_t* live_bytes) {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    if (cached_bytes) *cached_bytes = (int64_t)g_pool.cached;
+    if (live_bytes) {
+        size_t n = 0;
+        for (auto& l : g_pool.live) n += l.second.first;
+        *live_bytes = (int64_t)n;
+    }
     return 0;
 }
 int bbt_host_alloc(void** host_ptr, size_t nbytes) {

@@ -37,6 +37,8 @@ SIGNATURES = {
     'bbt_device_name': [C.c_char_p, _int],
     'bbt_malloc': [_pvp, _sz],
     'bbt_free': [_vp],
+    'bbt_pool_trim': [],
+    'bbt_pool_info': [C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     'bbt_host_alloc': [_pvp, _sz],
     'bbt_host_free': [_vp],
     'bbt_memset': [_vp, _int, _sz, _vp],
@@ -172,6 +174,18 @@ class Event:
                 lib().bbt_event_destroy(self._h)
         except Exception:
             pass
+
+
+def pool_trim():
+    """Return every idle block of the device memory pool to the driver."""
+    check(lib().bbt_pool_trim())
+
+
+def pool_info():
+    """(idle bytes kept for reuse, bytes in use) of the device memory pool."""
+    cached, live = C.c_int64(), C.c_int64()
+    check(lib().bbt_pool_info(C.byref(cached), C.byref(live)))
+    return cached.value, live.value
 
 
 class _Allocation:

@@ -17,6 +17,7 @@ nccl = RCCL); time blocks are independent, so each rank owns its own batch
 and broadcast over RCCL at plan time.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -81,16 +82,28 @@ def cpu_baseline(n_blocks):
     procs = max(1, min(os.cpu_count() or 1, 16))
     per = max(2, n_blocks // 2)
     ctx = mp.get_context('spawn')
-    t0 = time.perf_counter()
+    rates, busy, wall = [], 0.0, 0.0
     with ctx.Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [per] * procs)
-    wall = time.perf_counter() - t0
-    # rate from the slowest worker's own loop time (excludes interpreter start-up)
-    total = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
-    return dict(value=total / busy / 1e6, unit='Msamples/s', cores=procs, kind='port',
+        for _ in range(3):                              # three repeats, median
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_worker, [per] * procs)
+            wall = time.perf_counter() - t0
+            # rate from the slowest worker's own loop time (excludes interpreter start-up)
+            busy = max(r[1] for r in res)
+            rates.append(sum(r[0] for r in res) / busy / 1e6)
+    model = 'unknown CPU'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=sorted(rates)[1], unit='Msamples/s', cores=procs, kind='port',
                 sample=f'{procs} processes x {per} blocks of 2^20 x 2 pol through oracle/bbt_oracle.py '
-                       f'(numpy {np.__version__} complex64 FFT), {busy:.1f} s busy / {wall:.1f} s wall; '
+                       f'(numpy {np.__version__} complex64 FFT) on {os.cpu_count()} x {model}; median of 3 '
+                       f'repeats, last {busy:.1f} s busy / {wall:.1f} s wall; '
                        f'one process alone: {single:.1f} Msamples/s')
 
 
@@ -147,12 +160,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    gc.collect()        # CPython's full collection over torch's object graph is a ~50 ms pause;
+    gc.disable()        # the steps allocate no cycles, so none is due inside the timed region
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

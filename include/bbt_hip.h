@@ -53,8 +53,16 @@ int bbt_get_device(int* device);
 int bbt_device_name(char* buf, int buflen);
 
 /* ---- memory, streams, events (plumbing) -------------------------------- */
+/* Device memory from a caching pool: bbt_free keeps the block for reuse by a
+ * later bbt_malloc of about the same size (no hipFree, hence no device
+ * synchronisation between consecutive reader calls).  Reuse is ordered by the
+ * caller's stream.  Takes the place of the np.empty the reference's
+ * Base.read does per call (base.py:416).  BBT_POOL=0 disables caching,
+ * BBT_POOL_MAX_GB caps the idle bytes kept (default 96). */
 int bbt_malloc(void** dev_ptr, size_t nbytes);
 int bbt_free(void* dev_ptr);
+int bbt_pool_trim(void);                                   /* hipFree every idle block */
+int bbt_pool_info(int64_t* cached_bytes, int64_t* live_bytes);
 int bbt_host_alloc(void** host_ptr, size_t nbytes); /* pinned */
 int bbt_host_free(void* host_ptr);
 int bbt_memset(void* dev_ptr, int value, size_t nbytes, bbt_stream stream);

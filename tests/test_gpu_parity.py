@@ -652,3 +652,26 @@ def test_full_size_properties():
     # the float64 oracle gives rel-L2 9.4e-4, max 0.043 for this geometry
     assert np.abs(got - want).max() < 0.1
     assert rel_l2(got, want) < 5e-3
+
+
+def test_device_memory_pool_reuses_blocks():
+    """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
+    must not cost a hipMalloc + synchronising hipFree each)."""
+    hip = bt.hip
+    hip.pool_trim()
+    a = hip.DeviceArray((1 << 20, 2), np.complex64)
+    ptr, nbytes = a.ptr, a.nbytes
+    cached0, live0 = hip.pool_info()
+    assert live0 >= nbytes
+    del a
+    cached1, live1 = hip.pool_info()
+    assert cached1 - cached0 >= nbytes and live0 - live1 >= nbytes
+    b = hip.DeviceArray(((1 << 20) - 1000, 2), np.complex64)      # slightly smaller: same block
+    assert b.ptr == ptr
+    c = hip.DeviceArray((1 << 20, 2), np.complex64)               # block in use: a new one
+    assert c.ptr != ptr
+    x = np.arange(16, dtype=np.float32).view(np.complex64).reshape(4, 2)
+    d = hip.DeviceArray.from_host(x) if hasattr(hip.DeviceArray, 'from_host') else None
+    del b, c, d
+    hip.pool_trim()
+    assert hip.pool_info()[0] == 0
