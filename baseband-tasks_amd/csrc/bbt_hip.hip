@@ -358,7 +358,9 @@ struct bbt_osm_plan {
 
     // timing
     bool timing = false;
+    bool timing_isolated = false;   // mode 2: single lane, passes do not overlap
     std::vector<hipEvent_t> ev;  // 4 per chunk launch: t0, tA, tB, tC
+    std::vector<hipEvent_t> ev_free;   // recycled events
     double acc_ms[3] = {0, 0, 0};
     int64_t launches = 0;
 };
@@ -406,7 +408,7 @@ static int osm_flush_timing(bbt_osm_plan* p) {
         }
         p->launches += 1;
     }
-    for (auto e : p->ev) hipEventDestroy(e);
+    for (auto e : p->ev) p->ev_free.push_back(e);
     p->ev.clear();
     return 0;
 }
@@ -440,7 +442,14 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
     const int nch = so.n_chan;   // 0: plain overlap-save output
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (p->timing) {
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&e[i]));
+        for (int i = 0; i < 4; ++i) {
+            if (!p->ev_free.empty()) {
+                e[i] = p->ev_free.back();
+                p->ev_free.pop_back();
+            } else {
+                HIP_TRY(hipEventCreate(&e[i]));
+            }
+        }
         HIP_TRY(hipEventRecord(e[0], st));
     }
     if (p->n1 == 1) {
@@ -512,7 +521,7 @@ template <class FillChunk>
 static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n_blocks,
                        const SpecOut& so, hipStream_t st, FillChunk fill) {
     const int64_t n_chunks = (n_blocks + p->chunk - 1) / p->chunk;
-    const bool fork = p->lanes > 1 && !p->timing && n_chunks > 1;
+    const bool fork = p->lanes > 1 && !(p->timing && p->timing_isolated) && n_chunks > 1;
     if (fork) {
         HIP_TRY(hipEventRecord(p->ev_fork, st));
         for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
@@ -678,6 +687,7 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
 int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     if (!p) return 0;
     for (auto e : p->ev) hipEventDestroy(e);
+    for (auto e : p->ev_free) hipEventDestroy(e);
     if (p->resp) hipFree(p->resp);
     if (p->resp_index) hipFree(p->resp_index);
     for (int l = 0; l < BBT_MAX_LANES; ++l) {
@@ -820,6 +830,7 @@ int bbt_osm_timing_enable(bbt_osm_plan* p, int enable) {
     ARG_TRY(p, "bbt_osm_timing_enable: null plan");
     if (osm_flush_timing(p)) return 1;
     p->timing = enable != 0;
+    p->timing_isolated = enable == 2;
     p->acc_ms[0] = p->acc_ms[1] = p->acc_ms[2] = 0;
     p->launches = 0;
     return 0;

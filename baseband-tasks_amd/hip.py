@@ -478,7 +478,9 @@ class OsmPlan(_Plan):
                                             int(valid_start), _stream))
 
     def timing_enable(self, enable=True):
-        check(lib().bbt_osm_timing_enable(self._h, int(bool(enable))))
+        """False/0 off, True/1 time the normal (two-lane) schedule, 2 isolated
+        passes on a single lane."""
+        check(lib().bbt_osm_timing_enable(self._h, int(enable)))
 
     def timing_read(self):
         ms = (C.c_double * 3)()

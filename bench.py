@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--blocks', type=int, default=192, help='overlap-save blocks per step per GPU')
     ap.add_argument('--cpu-blocks', type=int, default=40, help='blocks per process for the CPU baseline (x1/2)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true',
+                    help='keep the HIP-event kernel timing out of the timed region (A/B check)')
     ap.add_argument('--gather', action='store_true', help='also time an all-gather of the outputs')
     return ap.parse_args()
 
@@ -158,11 +160,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Per-kernel timing of the overlap-save passes: HIP events on the stream
+    # each pass is launched on, recorded inside the timed region itself, in the
+    # normal two-lane schedule (what rocprofv3 --kernel-trace sees as well).
+    plan = dd._get_plan()
     for _ in range(args.warmup):
         step()
     gc.collect()        # CPython's full collection over torch's object graph is a ~50 ms pause;
     gc.disable()        # the steps allocate no cycles, so none is due inside the timed region
     fence()
+    if not args.no_kernel_timing:
+        plan.timing_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -174,25 +182,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * samples_per_step * args.steps / elapsed / 1e6
-
-    # ---- per-kernel timing of the overlap-save passes (HIP events on the
-    # launch stream), in a separate pass so the headline is not perturbed
-    plan = dd._get_plan()
-    plan.timing_enable(True)
-    ev0, ev1 = bt.hip.Event(), bt.hip.Event()
-    ev0.record()
-    for _ in range(max(3, args.steps // 2)):
-        step()
-    ev1.record()
-    ev1.synchronize()
+    n_steps_timed = args.steps
+    if args.no_kernel_timing:               # A/B switch: time the kernels in extra steps instead
+        plan.timing_enable(1)
+        n_steps_timed = max(3, args.steps // 2)
+        for _ in range(n_steps_timed):
+            step()
+        fence()
     ms, launches = plan.timing_read()
-    plan.timing_enable(False)
+    # the same passes isolated (one lane, nothing else on the GPU), for reference
+    plan.timing_enable(2)
+    n_iso = max(3, args.steps // 4)
+    for _ in range(n_iso):
+        step()
+    fence()
+    ms_iso, _ = plan.timing_read()
+    plan.timing_enable(0)
     info = plan.info()
     names = ['osm_col_forward', 'osm_rowpass', 'osm_col_inverse']
     k = int(np.argmax(ms))
     blocks_per_launch = min(info['chunk_blocks'], args.blocks)
     # launches may be ragged (last chunk smaller): use total blocks / launches
-    n_steps_timed = max(3, args.steps // 2)
     blocks_timed = n_steps_timed * args.blocks
     avg_ms = ms[k] / launches
     units_per_launch = blocks_timed / launches * spf
@@ -207,7 +217,11 @@ def main():
     roofline = dict(bound='hbm', kernel=names[k], achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
                     avg_launch_ms=round(avg_ms, 5), launches=launches,
-                    pass_ms_per_block={n: round(m / blocks_timed, 6) for n, m in zip(names, ms)})
+                    pass_ms_per_block={n: round(m / blocks_timed, 6) for n, m in zip(names, ms)},
+                    pass_ms_per_block_isolated={n: round(m / (n_iso * args.blocks), 6)
+                                                for n, m in zip(names, ms_iso)},
+                    note='launch durations from HIP events inside the timed region, two lanes active '
+                         '(a pass shares the GPU with a pass of the other lane); isolated = one lane')
     path_gbps = value * 1e6 / world * ALG_BYTES_PER_SAMPLE / 1e9
     roofline_path = dict(bound='hbm', achieved=round(path_gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                          frac=round(path_gbps / HBM_PEAK_GBPS, 4),

@@ -135,9 +135,12 @@ int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* ou
 int bbt_osm_execute_regular(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
                             int64_t n_blocks, int64_t in_off0, int64_t out_off0, int64_t hop,
                             int32_t valid_start, bbt_stream stream);
-/* Per-pass timing with HIP events on the launch stream (off by default).
- * ms[0..2] = accumulated column-forward / row / column-inverse pass time,
- * launches = number of launches of each pass since enabling. */
+/* Per-pass timing with HIP events on the stream each pass is launched on
+ * (off by default).  enable: 0 off; 1 time the normal schedule (the lanes
+ * stay on, so a pass may share the GPU with a pass of the other lane -- this
+ * is what rocprofv3 --kernel-trace sees); 2 isolated: single lane, passes run
+ * one after the other.  ms[0..2] = accumulated column-forward / row /
+ * column-inverse pass time, launches = launches of each pass since enabling. */
 int bbt_osm_timing_enable(bbt_osm_plan* plan, int enable);
 int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
 
