@@ -118,11 +118,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # BBT_BENCH_BACKEND=gloo rehearses the multi-rank code path on a box with fewer GPUs than
+        # ranks (ranks then share devices; RCCL itself refuses two ranks on one device)
+        backend = os.environ.get('BBT_BENCH_BACKEND', 'nccl')
+        dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != 'nccl' else local_rank
+        torch.cuda.set_device(dev_index)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    dev = torch.device('cuda', dev_index)
 
     import baseband_tasks_amd as bt
     from baseband_tasks_amd import sharding
