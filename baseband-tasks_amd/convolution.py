@@ -2,7 +2,9 @@
 baseband_tasks/convolution.py:65-127)."""
 import numpy as np
 
+from . import hip
 from .base import check_broadcast_to
+from .device_task import fetch_device
 from .overlap_save import SpectralMultiplyTask
 
 __all__ = ['Convolve']
@@ -40,6 +42,61 @@ class Convolve(SpectralMultiplyTask):
     def _spectral_response(self):
         return self._ft_response
 
+    # -- short responses: directly in the time domain ------------------------------
+    #: Largest number of taps convolved directly (real / complex responses); the
+    #: direct kernel costs time in proportion to the taps, the Fourier-domain
+    #: plan three passes over the stream whatever the response.  Both give the
+    #: same linear convolution (the reference's result is block independent).
+    #: Measured on MI355X, 2 streams: 129 real taps run at 68 Gsamples/s directly
+    #: against 55 through the Fourier-domain plan; break-even near 165 real taps.
+    FIR_MAX_TAPS = 160
+    FIR_MAX_TAPS_COMPLEX = 80
+    _fir = None
+
+    def _time_response(self):
+        """Response in the time domain, ``(n_tap,) + b`` with ``b`` broadcastable
+        to the sample shape."""
+        return self._response
+
+    def _use_fir(self):
+        if self._fir is None:
+            resp = np.asarray(self._time_response())
+            is_real = not np.iscomplexobj(resp) or not np.any(resp.imag)
+            limit = self.FIR_MAX_TAPS if is_real else self.FIR_MAX_TAPS_COMPLEX
+            if resp.shape[0] > limit or (self._real and not is_real):
+                self._fir = False
+            else:
+                full = np.broadcast_to(resp, resp.shape[:1] + tuple(self.sample_shape))
+                full = full.reshape(resp.shape[0], self._n_stream).astype(np.complex64)
+                if self._n_stream_even != self._n_stream:
+                    full = np.concatenate([full, np.zeros_like(full[:, :1])], axis=1)
+                self._fir = hip.FirPlan(full)
+        return self._fir is not False
+
+    def _compute_frames(self, first, last, out):
+        if not self._use_fir():
+            return super()._compute_frames(first, last, out)
+        start, stop = self._frame_span(first, last)
+        n_out, pad = stop - start, self._pad_start + self._pad_end
+        x = fetch_device(self.ih, start, n_out + pad)
+        s, se = self._n_stream, self._n_stream_even
+        if self._real:
+            x = hip.real_to_complex(x.reshape(n_out + pad, s))
+            final, out = out, hip.DeviceArray((n_out, s), np.complex64)
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+            target = hip.DeviceArray((n_out, se), np.complex64)
+        else:
+            target = out
+        self._fir.execute(x, target, n_out)
+        if se != s:
+            hip.strip_stream_pad(target, n_out, s, out)
+        if self._real:
+            hip.real_part(out, final)
+
     def close(self):
         super().close()
         self._ft_response_cache = None
+        if self._fir:
+            self._fir.close()
+        self._fir = None

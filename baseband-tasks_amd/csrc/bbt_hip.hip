@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 108
+#define BBT_VERSION 109
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1180,6 +1180,83 @@ extern "C" int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_sa
     hipLaunchKernelGGL(k_scale_streams, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float2*)in_dev, (float2*)out_dev, total, n_elem,
                        (const float2*)factor_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// short-response convolution in the time domain
+struct bbt_fir_plan {
+    int n_tap = 0, S = 0, npair = 0;
+    int n_chunks = 0, pitch = 0, tap_pitch = 0;
+    bool cplx = false;
+    float2* tre = nullptr;
+    float2* tim = nullptr;
+};
+static constexpr int BBT_FIR_R = 8;
+
+extern "C" int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream,
+                                   const void* response_host) {
+    ARG_TRY(plan && response_host, "bbt_fir_plan_create: null argument");
+    *plan = nullptr;
+    ARG_TRY(n_tap >= 1 && n_tap <= 1024, "bbt_fir_plan_create: n_tap=%d must be in [1, 1024]", n_tap);
+    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0,
+            "bbt_fir_plan_create: n_stream=%d must be even and >= 2 (pad odd counts)", n_stream);
+    constexpr int R = BBT_FIR_R;
+    bbt_fir_plan* p = new bbt_fir_plan;
+    p->n_tap = n_tap;
+    p->S = n_stream;
+    p->npair = n_stream / 2;
+    p->n_chunks = (n_tap + R - 1 + R - 1) / R;           // inputs u = r + m < n_tap + R - 1
+    p->pitch = 256 + p->n_chunks;
+    while (p->pitch % 16 != 2) ++p->pitch;
+    p->tap_pitch = R * p->n_chunks + 2 * R;              // R - 1 zeros in front, zeros behind
+    const cf* resp = (const cf*)response_host;           // (n_tap, n_stream), reference order
+    std::vector<float2> re((size_t)p->npair * p->tap_pitch, make_float2(0.f, 0.f)), im(re);
+    for (int sp = 0; sp < p->npair; ++sp)
+        for (int m = 0; m < n_tap; ++m) {
+            const cf a = resp[(size_t)(n_tap - 1 - m) * n_stream + 2 * sp];
+            const cf b = resp[(size_t)(n_tap - 1 - m) * n_stream + 2 * sp + 1];
+            re[(size_t)sp * p->tap_pitch + (R - 1) + m] = make_float2(a.x, b.x);
+            im[(size_t)sp * p->tap_pitch + (R - 1) + m] = make_float2(a.y, b.y);
+            if (a.y != 0.f || b.y != 0.f) p->cplx = true;
+        }
+    if (upload(&p->tre, re) || upload(&p->tim, im)) {
+        if (p->tre) hipFree(p->tre);
+        delete p;
+        return 1;
+    }
+    *plan = p;
+    return 0;
+}
+
+extern "C" int bbt_fir_plan_destroy(bbt_fir_plan* p) {
+    if (!p) return 0;
+    if (p->tre) hipFree(p->tre);
+    if (p->tim) hipFree(p->tim);
+    delete p;
+    return 0;
+}
+
+extern "C" int bbt_fir_execute(bbt_fir_plan* p, const void* in_dev, void* out_dev, int64_t n_out,
+                               bbt_stream stream) {
+    ARG_TRY(p && in_dev && out_dev, "bbt_fir_execute: null argument");
+    ARG_TRY(n_out >= 0, "bbt_fir_execute: n_out=%lld is negative", (long long)n_out);
+    if (n_out == 0) return 0;
+    constexpr int R = BBT_FIR_R;
+    const long long n_in = n_out + p->n_tap - 1;
+    const long long tiles = (n_out + 256 * R - 1) / (256 * R);
+    ARG_TRY(tiles * p->npair < (1ll << 31), "bbt_fir_execute: too large for one call");
+    const size_t lds = (size_t)R * p->pitch * sizeof(float4);
+    const dim3 grid((unsigned)(tiles * p->npair));
+    if (p->cplx)
+        hipLaunchKernelGGL((k_fir<R, true>), grid, dim3(256), lds, (hipStream_t)stream,
+                           (const float2*)in_dev, (float2*)out_dev, n_in, (long long)n_out, p->S,
+                           p->tre, p->tim, p->tap_pitch, p->n_chunks, p->pitch);
+    else
+        hipLaunchKernelGGL((k_fir<R, false>), grid, dim3(256), lds, (hipStream_t)stream,
+                           (const float2*)in_dev, (float2*)out_dev, n_in, (long long)n_out, p->S,
+                           p->tre, p->tim, p->tap_pitch, p->n_chunks, p->pitch);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -862,4 +862,88 @@ __global__ __launch_bounds__(256) void k_scale_streams(const float2* __restrict_
     out[t] = cmul(in[t], factor[t % n_elem]);
 }
 
+// ---------------------------------------------------------------------------
+// Time-domain FIR for short responses: Convolve.task (reference
+// convolution.py:116-120) keeps ifft(fft(x) * fft(response))[n_tap - 1:], i.e.
+//   out[i, s] = sum_{m < n_tap} in[i + m, s] * g[s][m],   g[s][m] = response[n_tap - 1 - m, s],
+// the exact linear convolution, which is block independent.  For a windowed
+// sinc of 129 taps (Resample / ShiftAndResample) doing it directly costs one
+// read and one write of the stream instead of three FFT passes.
+//
+// A thread computes R consecutive outputs of one stream pair from a sliding
+// window: per chunk of R inputs (read once from LDS) it does R*R multiply-adds
+// with the 2R-1 taps the chunk touches (uniform: scalar loads).  The input
+// tile sits in LDS as R rows of PITCH 16-byte elements, sample s at row s % R,
+// column s / R, so both the coalesced fill (16 consecutive samples -> 16
+// different 16-byte bank groups because PITCH = 2 mod 16) and the per-thread
+// reads (column t + q for thread t) are conflict free.
+//   tre/tim : [npair][tap_pitch] float2 (g_A, g_B) real / imaginary parts,
+//             R-1 zeros in front and >= R zeros behind the n_tap taps.
+template <int R, bool CPLX>
+__global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, float2* __restrict__ out,
+                                             long long n_in, long long n_out, int S,
+                                             const float2* __restrict__ tre,
+                                             const float2* __restrict__ tim, int tap_pitch,
+                                             int n_chunks, int pitch) {
+    constexpr int T = 256;
+    extern __shared__ float4 fir_tile[];
+    const int t = threadIdx.x, npair = S >> 1;
+    // the pairs of one tile share cache lines: consecutive virtual ids, one XCD
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int sp = vb % npair;
+    const long long base = (long long)(vb / npair) * (T * R);
+    const int n_tile = R * (T + n_chunks);
+    for (int s = t; s < n_tile; s += T) {
+        const long long g = base + s;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < n_in) x = *reinterpret_cast<const float4*>(in + (g * S + 2 * sp));
+        fir_tile[(s % R) * pitch + s / R] = x;
+    }
+    __syncthreads();
+    const float2* gre = tre + (long long)sp * tap_pitch;
+    const float2* gim = tim + (long long)sp * tap_pitch;
+    c2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = czero();
+    for (int q = 0; q < n_chunks; ++q) {
+        c2 x[R];
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            const float4 v = fir_tile[p * pitch + t + q];
+            x[p] = c2{v2{v.x, v.z}, v2{v.y, v.w}};
+        }
+        v2 wr[2 * R - 1], wi[2 * R - 1];
+#pragma unroll
+        for (int k = 0; k < 2 * R - 1; ++k) {
+            const float2 a = gre[R * q + k];
+            wr[k] = v2{a.x, a.y};
+            if (CPLX) {
+                const float2 b = gim[R * q + k];
+                wi[k] = v2{b.x, b.y};
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < R; ++p)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int k = p - r + R - 1;            // tap g[R q + p - r]
+                acc[r].re += x[p].re * wr[k];
+                acc[r].im += x[p].im * wr[k];
+                if (CPLX) {
+                    acc[r].re -= x[p].im * wi[k];
+                    acc[r].im += x[p].re * wi[k];
+                }
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        fir_tile[r * pitch + t] = make_float4(acc[r].re.x, acc[r].im.x, acc[r].re.y, acc[r].im.y);
+    __syncthreads();
+    for (int s = t; s < T * R; s += T) {
+        const long long g = base + s;
+        if (g < n_out) *reinterpret_cast<float4*>(out + (g * S + 2 * sp)) = fir_tile[(s % R) * pitch + s / R];
+    }
+}
+
 }  // namespace bbt

@@ -74,6 +74,9 @@ SIGNATURES = {
     'bbt_shift_plan_create': [_pvp, _int, _int, _pi32],
     'bbt_shift_plan_destroy': [_vp],
     'bbt_shift_execute': [_vp, _vp, _vp, _i64, _vp],
+    'bbt_fir_plan_create': [_pvp, _int, _int, _vp],
+    'bbt_fir_plan_destroy': [_vp],
+    'bbt_fir_execute': [_vp, _vp, _vp, _i64, _vp],
     'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
     'bbt_scale_streams': [_vp, _vp, _i64, _int, _vp, _vp],
 }
@@ -517,6 +520,23 @@ class PfbPlan(_Plan):
 
     def execute(self, in_dev, out_dev, n_spectra):
         check(lib().bbt_pfb_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_spectra), _stream))
+
+
+class FirPlan(_Plan):
+    """Time-domain convolution with a short response ``(n_tap, n_stream)``:
+    out[i] = sum_k response[k] * in[i + n_tap - 1 - k] (what Convolve keeps)."""
+    _destroy = 'bbt_fir_plan_destroy'
+
+    def __init__(self, response):
+        super().__init__()
+        response = np.ascontiguousarray(response, dtype=np.complex64)
+        assert response.ndim == 2
+        self.n_tap, self.n_stream = response.shape
+        check(lib().bbt_fir_plan_create(C.byref(self._h), self.n_tap, self.n_stream,
+                                        response.ctypes.data_as(C.c_void_p)))
+
+    def execute(self, in_dev, out_dev, n_out):
+        check(lib().bbt_fir_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_out), _stream))
 
 
 class ShiftPlan(_Plan):

@@ -90,6 +90,13 @@ class ShiftAndResample(Convolve):
         return (base * np.exp(-2j * np.pi * phase)).astype(np.complex64)
 
 
+    def _time_response(self):
+        if self._lo is None:
+            return self._response
+        phase = self._shift / self.sample_rate * self._lo * self.sideband
+        return self._response * np.exp(-2j * np.pi * phase)
+
+
 class Resample(ShiftAndResample):
     """Resample so that a sample falls exactly on ``offset`` and leave the
     sample pointer there (reference sampling.py:230-312)."""

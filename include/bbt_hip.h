@@ -43,6 +43,7 @@ typedef struct bbt_osm_plan bbt_osm_plan;
 typedef struct bbt_chan_plan bbt_chan_plan;
 typedef struct bbt_pfb_plan bbt_pfb_plan;
 typedef struct bbt_shift_plan bbt_shift_plan;
+typedef struct bbt_fir_plan bbt_fir_plan;
 
 /* ---- library / device ------------------------------------------------- */
 const char* bbt_last_error(void);
@@ -208,6 +209,21 @@ int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int 
  * In-place (out_dev == in_dev) is allowed. */
 int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_samples, int n_elem,
                       const void* factor_dev, bbt_stream stream);
+
+/* ---- short responses in the time domain ---------------------------------------
+ * Convolve.task (convolution.py:116-120) keeps
+ * ifft(fft(x) * fft(response))[n_tap-1:], the exact linear convolution
+ *   out[i, s] = sum_k response[k, s] * in[i + n_tap - 1 - k, s];
+ * for short responses (the 2*pad+1 = 129-tap windowed sinc of ShiftAndResample /
+ * Resample, sampling.py:177-193) this computes it directly: one read and one
+ * write of the stream instead of three FFT passes, and no block structure.
+ * response_host: complex64 (n_tap, n_stream), the reference's `response`
+ * broadcast to the streams (n_stream even).  `in` holds n_out + n_tap - 1
+ * complete samples.  Purely real responses take a cheaper kernel. */
+int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream, const void* response_host);
+int bbt_fir_plan_destroy(bbt_fir_plan* plan);
+int bbt_fir_execute(bbt_fir_plan* plan, const void* in_dev, void* out_dev, int64_t n_out,
+                    bbt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -675,3 +675,54 @@ def test_device_memory_pool_reuses_blocks():
     del b, c, d
     hip.pool_trim()
     assert hip.pool_info()[0] == 0
+
+
+@pytest.mark.parametrize('sample_shape,dtype', [((2,), np.complex64), ((3,), np.complex64),
+                                                ((2, 2), np.complex64), ((2,), np.float32)])
+def test_direct_and_fourier_convolution_agree(sample_shape, dtype, monkeypatch):
+    """Short responses are convolved in the time domain (k_fir), long ones in
+    the Fourier domain; both are the linear convolution the reference keeps
+    (convolution.py:116-120), so they must agree with each other and with the
+    oracle for real, complex and per-stream responses."""
+    n = 3 * 4096 + 321
+    nh = bt.NoiseGenerator((n,) + sample_shape, T0, 1 * u.MHz, 4096, seed=21, dtype=dtype,
+                           frequency=300 * u.MHz, sideband=1)
+    x = nh.read()
+    rng = np.random.default_rng(5)
+    n_stream = int(np.prod(sample_shape))
+    responses = [rng.standard_normal(129),                                          # real, shared
+                 rng.standard_normal((40,) + sample_shape)]                         # real, per stream
+    if dtype == np.complex64:
+        responses.append(rng.standard_normal(33) + 1j * rng.standard_normal(33))    # complex
+    for resp in responses:
+        direct = bt.Convolve(nh, resp, offset=7)
+        assert direct._use_fir()
+        got = direct.read()
+        monkeypatch.setattr(bt.Convolve, 'FIR_MAX_TAPS', 0)
+        monkeypatch.setattr(bt.Convolve, 'FIR_MAX_TAPS_COMPLEX', 0)
+        fourier = bt.Convolve(nh, resp, offset=7)
+        assert not fourier._use_fir()
+        want_gpu = fourier.read()
+        monkeypatch.undo()
+        # (the oracle's convolve is written for complex streams; a real stream is its real part)
+        want, geo = orc.convolve(x.astype(np.complex64), resp if resp.ndim > 1 or len(sample_shape) == 1
+                                 else resp.reshape((-1,) + (1,) * len(sample_shape)), offset=7,
+                                 ih_samples_per_frame=4096, fast_len=HipFFTMaker().next_fast_len)
+        assert got.shape == want.shape == want_gpu.shape and got.dtype == dtype
+        if dtype == np.float32:
+            want = want.real if np.iscomplexobj(want) else want
+        for a, what in ((got, 'direct'), (want_gpu, 'fourier')):
+            e2, em = rel_l2(a, want), max_over_rms(a, want)
+            assert e2 <= REL_L2_TOL and em <= MAX_TOL, (what, resp.shape, e2, em)
+    # the LO phase of ShiftAndResample makes the taps complex per stream
+    if dtype == np.complex64:
+        shift = np.linspace(-0.3, 0.4, n_stream).reshape(sample_shape)
+        sr = bt.ShiftAndResample(nh, shift, lo=299.5 * u.MHz, pad=32)
+        assert sr._use_fir()
+        got = sr.read()
+        monkeypatch.setattr(bt.Convolve, 'FIR_MAX_TAPS_COMPLEX', 0)
+        sr2 = bt.ShiftAndResample(nh, shift, lo=299.5 * u.MHz, pad=32)
+        assert not sr2._use_fir()
+        want = sr2.read()
+        monkeypatch.undo()
+        assert rel_l2(got, want) <= REL_L2_TOL and max_over_rms(got, want) <= MAX_TOL

@@ -65,6 +65,17 @@ def single_stream_configs():
     dt = timeit([dd], dd, dd.shape[0])
     print(f"config2 Dedisperse:       {dd.shape[0] / dt / 1e6:9.1f} Msamples/s")
     del dd
+    for label in ('direct', 'Fourier'):
+        limit = bt.Convolve.FIR_MAX_TAPS
+        if label == 'Fourier':
+            bt.Convolve.FIR_MAX_TAPS = 0
+        rs = bt.Resample(ds, 0.25, pad=64, samples_per_frame=2**20 - 128)
+        rs.seek(0)
+        rs.max_frames_per_call = 10**6
+        dt = timeit([rs], rs, rs.shape[0] - 64)
+        bt.Convolve.FIR_MAX_TAPS = limit
+        print(f"Resample(129 taps) alone, {label}: {(rs.shape[0] - 64) / dt / 1e6:9.1f} Msamples/s")
+    del rs
     # the metric pipeline at other band centres (SURVEY 8d variants) and with detection
     for fc, spf in ((800e6, 2**20 - 415021), (1400e6, None), (1000e6, None)):
         dsf = bt.SetAttribute(ds, frequency=fc, polarization=['X', 'Y'])
@@ -94,6 +105,24 @@ def main():
     dt = timeit([rs, dd], dd, dd.shape[0], reps=5)
     print(f"config5 Resample->Dedisperse, 8 streams: {dd.shape[0] / dt / 1e6:9.1f} Msamples/s "
           f"(complete 8-stream samples; x4 = {4 * dd.shape[0] / dt / 1e6:.0f} 2-pol-equivalent)")
+    fir_limit = bt.Convolve.FIR_MAX_TAPS
+    bt.Convolve.FIR_MAX_TAPS = 0                  # the same through the Fourier-domain plan
+    rs = bt.Resample(ds8, 0.25, pad=64, samples_per_frame=2**20 - 128)
+    rs.seek(0)
+    dd = bt.Dedisperse(rs, 100., samples_per_frame=2**20 - 212476)
+    rs.max_frames_per_call = dd.max_frames_per_call = 10**6
+    dt = timeit([rs, dd], dd, dd.shape[0], reps=5)
+    bt.Convolve.FIR_MAX_TAPS = fir_limit
+    print(f"        with the resampler in the Fourier domain: {dd.shape[0] / dt / 1e6:9.1f} Msamples/s")
+    for label in ('direct', 'Fourier'):
+        if label == 'Fourier':
+            bt.Convolve.FIR_MAX_TAPS = 0
+        rs = bt.Resample(ds8, 0.25, pad=64, samples_per_frame=2**20 - 128)
+        rs.seek(0)
+        rs.max_frames_per_call = 10**6
+        dt = timeit([rs], rs, rs.shape[0] - 64, reps=5)
+        bt.Convolve.FIR_MAX_TAPS = fir_limit
+        print(f"        Resample alone ({label}), 8 streams:  {(rs.shape[0] - 64) / dt / 1e6:9.1f} Msamples/s")
     dd8 = bt.Dedisperse(ds8, 100.)
     dd8.max_frames_per_call = 10**6
     dt = timeit([dd8], dd8, dd8.shape[0], reps=5)
