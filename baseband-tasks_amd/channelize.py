@@ -10,7 +10,7 @@ from .base import TaskBase, getattr_if_none, _stream_rate
 from .device_task import DeviceTaskMixin, fetch_device
 from .fourier import MIN_FFT_LEN, MAX_WG_FFT_LEN
 
-__all__ = ['Channelize', 'Dechannelize', 'FUSE_WITH_OVERLAP_SAVE']
+__all__ = ['Channelize', 'Dechannelize', 'FUSE_WITH_OVERLAP_SAVE', 'FUSE_DETECTION']
 
 #: When the input of a `Channelize` is a GPU overlap-save task (`Dedisperse`,
 #: `Disperse`, `Convolve`, `Resample`) the channelizer FFT is folded into that
@@ -18,6 +18,8 @@ __all__ = ['Channelize', 'Dechannelize', 'FUSE_WITH_OVERLAP_SAVE']
 #: intermediate stream never exists in memory.  Results are the same to
 #: rounding; set to False (or BBT_FUSE=0) to run the two tasks separately.
 FUSE_WITH_OVERLAP_SAVE = os.environ.get('BBT_FUSE', '1') != '0'
+#: Let Integrate(Square|Power(Channelize(overlap-save task))) run inside that task's last pass.
+FUSE_DETECTION = os.environ.get('BBT_FUSE_DETECT', '1') != '0'
 
 
 def _prod(shape):
@@ -145,6 +147,28 @@ class Channelize(_RowFFTTask):
             hip.keep_half_spectrum(full, n, self._n_stream, out)
             return
         self._run(x, n_spectra, flat)
+
+    def _compute_detected(self, first_spectrum, n_bins, step, mode, average, out):
+        """Detect (mode 0 Square, 1 Power) and integrate spectra
+        [first_spectrum, first_spectrum + n_bins * step) inside the upstream
+        overlap-save plan, without storing them.  Returns False when that
+        route does not apply (the caller then detects the stored spectra)."""
+        dd = self._fusable_input() if FUSE_DETECTION else None
+        if dd is None or dd._ih_samples_per_frame > (1 << 20):
+            return False
+        plan = dd._get_plan()
+        if plan.info()['n1'] != 256 or plan.detect_bins_max(self._n, step) > 64:
+            return False
+        n, spf = self._n, dd.samples_per_frame
+        start, stop = first_spectrum, first_spectrum + n_bins * step
+        m0, m1 = (start * n) // spf, (stop * n - 1) // spf + 1
+        in0, in_len, starts, out_abs, keep, counts = dd._block_descriptors(m0, m1)
+        if not np.all(counts >= n):
+            return False
+        x = fetch_device(dd.ih, in0, in_len)
+        plan.execute_channelized_detect(x, out, starts - in0, out_abs, keep, counts, n, start,
+                                        n_bins, step, mode, average)
+        return True
 
     def task(self, data):
         """Channelize one frame given on the host (reference channelize.py:73-74)."""

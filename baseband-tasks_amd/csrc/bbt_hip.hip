@@ -18,7 +18,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 109
+#define BBT_VERSION 110
 
 // ---------------------------------------------------------------------------
 // errors
@@ -429,6 +429,14 @@ static int col_tile() {
 template <bool FIRST, bool SPEC>
 static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                           const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
+    if constexpr (SPEC && !FIRST) {
+        if (so.det) {
+            hipLaunchKernelGGL((k_osm_col256<false, true, 16, true>),
+                               dim3(row_len / 16 * p->npair, ch.nblk), dim3(256), 0, st, in, out, work,
+                               ch, p->S, row_len, p->tab1.tw0, so);
+            return;
+        }
+    }
     if (col_tile() == 32 && row_len % 32 == 0)
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
                            dim3(512), 0, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
@@ -563,13 +571,13 @@ static int osm_check_blocks(const bbt_osm_plan* p, const char* who, int64_t n_bl
 
 template <int NCH>
 static void launch_seam_fix(bbt_osm_plan* p, float2* out, const std::vector<SeamJob>& jobs,
-                            const FftTables& tab, hipStream_t st) {
+                            const FftTables& tab, const SpecOut& so, hipStream_t st) {
     for (size_t j0 = 0; j0 < jobs.size(); j0 += BBT_SEAM_JOBS_PER_LAUNCH) {
         SeamJobs batch;
         const size_t n = std::min(jobs.size() - j0, (size_t)BBT_SEAM_JOBS_PER_LAUNCH);
         for (size_t i = 0; i < n; ++i) batch.j[i] = jobs[j0 + i];
         hipLaunchKernelGGL((k_seam_fix<NCH>), dim3((unsigned)n, p->npair), dim3(NCH / 16), 0, st,
-                           p->seam, out, batch, p->S, p->npair, tab.tw0, tab.tw1);
+                           p->seam, out, batch, p->S, p->npair, tab.tw0, tab.tw1, so);
     }
 }
 
@@ -733,26 +741,24 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
                        });
 }
 
-int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_dev,
-                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
-                                const int32_t* valid_start, const int32_t* valid_count, int n_chan,
-                                int64_t first_spectrum, int64_t n_spectra, bbt_stream stream) {
-    ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute_channelized: null argument");
-    ARG_TRY(p->n1 > 1 || p->outer > 1, "bbt_osm_execute_channelized: block length %lld is too short to fuse",
+// Channelize(overlap-save task) as one call; with det_step > 0 the spectra are
+// detected and integrated instead of stored (out_dev = float32 bins).
+static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev, void* out_dev,
+                           int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
+                           const int32_t* valid_start, const int32_t* valid_count, int n_chan,
+                           int64_t first_spectrum, int64_t n_spectra, int det_step, int det_mode,
+                           float det_scale, hipStream_t st) {
+    ARG_TRY(p && in_dev && out_dev, "%s: null argument", who);
+    ARG_TRY(p->n1 > 1 || p->outer > 1, "%s: block length %lld is too short to fuse", who,
             (long long)p->n);
     ARG_TRY(fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0,
-            "bbt_osm_execute_channelized: n_chan=%d must be a power of two in [256, %d]", n_chan,
-            p->n2);
-    ARG_TRY(first_spectrum >= 0 && n_spectra >= 0, "bbt_osm_execute_channelized: bad spectrum range");
-    if (osm_check_blocks(p, "bbt_osm_execute_channelized", n_blocks, in_off, out_off, valid_start,
-                         valid_count))
-        return 1;
+            "%s: n_chan=%d must be a power of two in [256, %d]", who, n_chan, p->n2);
+    ARG_TRY(first_spectrum >= 0 && n_spectra >= 0, "%s: bad spectrum range", who);
+    if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
     for (int64_t b = 0; b < n_blocks; ++b)
-        ARG_TRY(valid_count[b] >= n_chan,
-                "bbt_osm_execute_channelized: block %lld keeps %d samples < n_chan", (long long)b,
-                valid_count[b]);
+        ARG_TRY(valid_count[b] >= n_chan, "%s: block %lld keeps %d samples < n_chan", who,
+                (long long)b, valid_count[b]);
     if (n_blocks == 0 || n_spectra == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
     FftTables tabc;
     if (get_tables(n_chan, &tabc)) return 1;
     // seam slots and jobs
@@ -776,7 +782,7 @@ int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_d
         j.split = (int)(seam_pos - s * n_chan);
         jobs.push_back(j);
     }
-    SpecOut so;
+    SpecOut so = {};
     so.seam = p->seam;
     so.s_base = first_spectrum;
     so.n_out = n_spectra;
@@ -784,6 +790,12 @@ int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_d
     so.lg_chan = 0;
     while ((1 << so.lg_chan) < n_chan) ++so.lg_chan;
     so.n_fft = (int)p->n;
+    if (det_step > 0) {
+        so.det = (float*)out_dev;
+        so.det_step = det_step;
+        so.det_mode = det_mode;
+        so.det_scale = det_scale;
+    }
     if (osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
                     [&](OsmBlock& blk, int64_t b) {
                         blk.in_off = in_off[b];
@@ -799,15 +811,55 @@ int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_d
         return 1;
     if (!jobs.empty()) {
         switch (n_chan) {
-            case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, st); break;
-            case 512: launch_seam_fix<512>(p, (float2*)out_dev, jobs, tabc, st); break;
-            case 1024: launch_seam_fix<1024>(p, (float2*)out_dev, jobs, tabc, st); break;
-            case 2048: launch_seam_fix<2048>(p, (float2*)out_dev, jobs, tabc, st); break;
-            case 4096: launch_seam_fix<4096>(p, (float2*)out_dev, jobs, tabc, st); break;
+            case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, so, st); break;
+            case 512: launch_seam_fix<512>(p, (float2*)out_dev, jobs, tabc, so, st); break;
+            case 1024: launch_seam_fix<1024>(p, (float2*)out_dev, jobs, tabc, so, st); break;
+            case 2048: launch_seam_fix<2048>(p, (float2*)out_dev, jobs, tabc, so, st); break;
+            case 4096: launch_seam_fix<4096>(p, (float2*)out_dev, jobs, tabc, so, st); break;
         }
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+int bbt_osm_execute_channelized(bbt_osm_plan* p, const void* in_dev, void* out_dev,
+                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
+                                const int32_t* valid_start, const int32_t* valid_count, int n_chan,
+                                int64_t first_spectrum, int64_t n_spectra, bbt_stream stream) {
+    return osm_channelized(p, "bbt_osm_execute_channelized", in_dev, out_dev, n_blocks, in_off,
+                           out_off, valid_start, valid_count, n_chan, first_spectrum, n_spectra, 0,
+                           0, 0.f, (hipStream_t)stream);
+}
+
+int bbt_osm_detect_bins_max(const bbt_osm_plan* p, int n_chan, int step) {
+    // integration bins one column-pass workgroup touches: its 256 rows hold
+    // every (n2 / n_chan)-th of 256 * n2 / n_chan consecutive spectra
+    if (!p || n_chan <= 0 || step <= 0) return -1;
+    const int64_t span = 255ll * (p->n2 / n_chan);
+    return (int)(span / step) + 2;
+}
+
+int bbt_osm_execute_channelized_detect(bbt_osm_plan* p, const void* in_dev, void* out_dev,
+                                       int64_t n_blocks, const int64_t* in_off,
+                                       const int64_t* out_off, const int32_t* valid_start,
+                                       const int32_t* valid_count, int n_chan,
+                                       int64_t first_spectrum, int64_t n_bins, int step, int mode,
+                                       int average, bbt_stream stream) {
+    const char* who = "bbt_osm_execute_channelized_detect";
+    ARG_TRY(p && out_dev, "%s: null argument", who);
+    ARG_TRY(p->n1 == 256 && p->outer == 1,
+            "%s: fused detection needs a two-level transform with 256 columns (block length 2^16..2^20)",
+            who);
+    ARG_TRY(step >= 1 && n_bins >= 0 && (mode == 0 || mode == 1), "%s: bad step/bins/mode", who);
+    ARG_TRY(n_bins * (int64_t)step < (1ll << 40), "%s: too many spectra", who);
+    ARG_TRY(bbt_osm_detect_bins_max(p, n_chan, step) <= BBT_DET_MAX_BINS,
+            "%s: step=%d is too short for %d channels on rows of %d (a workgroup would touch more "
+            "than %d bins)", who, step, n_chan, p->n2, BBT_DET_MAX_BINS);
+    const size_t out_bytes = (size_t)n_bins * n_chan * p->npair * (mode ? 4 : 2) * sizeof(float);
+    if (out_bytes) HIP_TRY(hipMemsetAsync(out_dev, 0, out_bytes, (hipStream_t)stream));
+    return osm_channelized(p, who, in_dev, out_dev, n_blocks, in_off, out_off, valid_start,
+                           valid_count, n_chan, first_spectrum, n_bins * step, step, mode,
+                           average ? 1.0f / (float)step : 1.0f, (hipStream_t)stream);
 }
 
 int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,

@@ -169,7 +169,30 @@ struct SpecOut {
     int n_chan;
     int lg_chan;         // log2(n_chan)
     int n_fft;           // N = N1 * N2
+    // fused detection + integration (k_osm_col256<..., DET>): spectra are not
+    // stored; their power is summed into det[bin][channel][...], bin =
+    // (spectrum - s_base) / det_step, n_out = number of bins * det_step.
+    float* det;          // zeroed by the caller; nullptr: store spectra
+    int det_step;
+    int det_mode;        // 0 |z|^2 per stream, 1 (|X|^2, |Y|^2, Re XY*, Im XY*) per pair
+    float det_scale;
 };
+
+// floats a pair contributes per (bin, channel): 2 (mode 0) or 4 (mode 1)
+__device__ __forceinline__ float4 detect_pair(c2 z, int mode) {
+    float4 p;
+    p.x = z.re.x * z.re.x + z.im.x * z.im.x;
+    p.y = z.re.y * z.re.y + z.im.y * z.im.y;
+    p.z = mode ? z.re.x * z.re.y + z.im.x * z.im.y : 0.f;
+    p.w = mode ? z.im.x * z.re.y - z.re.x * z.im.y : 0.f;
+    return p;
+}
+// index of component 0 of (bin, channel, pair) in the detected output
+__device__ __forceinline__ long long detect_index(long long bin, int ch, int sp, int lg_chan,
+                                                  int npair, int mode) {
+    return (((bin << lg_chan) + ch) * npair + sp) * (mode ? 4 : 2);
+}
+#define BBT_DET_MAX_BINS 64      // integration bins one column-pass workgroup may touch
 
 // Fused channelizer output.  A column-pass thread holds, for one column
 // `slot` = q * n_chan + ch of the work rows, the rows n1 = row0 + 16 j (j < 16,
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
 // Column pass, N1 == 256: FCOL two-stream columns (f, fastest lane index ->
 // FCOL * 16-byte runs per row: 256 B for 16, 512 B for 32) x 16 threads per
 // 256-point transform; FCOL * 16 threads per workgroup.
-template <bool FIRST, bool SPEC, int FCOL>
+template <bool FIRST, bool SPEC, int FCOL, bool DET = false>
 __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restrict__ in,
                                                           float2* __restrict__ out,
                                                           float2* __restrict__ work, OsmChunk ch,
@@ -366,6 +389,73 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
         wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
         SpecCursor cur;
         if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, n2, S, sp, npair);
+        if constexpr (SPEC && DET) {
+            // Detection + integration instead of storing spectra.  The workgroup
+            // holds, for each of its FCOL channels, every (N2 / n_chan)-th of
+            // 256 * N2 / n_chan consecutive spectra: row n1 = tau + 16 j is
+            // spectrum s_wg + n1 * spr.  The powers go to LDS as P[n1][f] (two
+            // components at a time: 32 KiB), then one thread per (bin, channel,
+            // component) sums the rows of its bin -- they are contiguous -- and
+            // adds the result to the output once.
+            constexpr int NT = FCOL * 16;
+            float2* pw = reinterpret_cast<float2*>(lds);            // [256][FCOL]
+            static_assert(256 * FCOL * 8 <= (int)sizeof(lds), "power tile does not fit the exchange buffer");
+            const int step = so.det_step, mode = so.det_mode;
+            const int spr = N2 >> so.lg_chan;                        // spectra per row step
+            const int lg_spr = __ffs(spr) - 1;
+            const long long s_wg = cur.s0 - (long long)tau * spr;   // spectrum of row 0
+            long long b_wg = s_wg / step;
+            if (b_wg * step > s_wg) --b_wg;                          // floor: bin of row 0
+            const long long n_bins = cur.n_out / step;
+            const int ch0 = (n2 - f) & (cur.nch - 1);
+            const int nb = (int)((s_wg + 255ll * spr) / step - b_wg) + 1;   // local bins (<= BBT_DET_MAX_BINS)
+            float4 p[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int rel = cur.rel + j * cur.drel;
+                bool full = false;
+                if (rel >= cur.wrap_at) {
+                    rel -= cur.n_fft;
+                    if (rel < 0 && rel + cur.nch > 0) st_ext(cur.seam0, v[j]);
+                } else if (rel >= 0 && rel + cur.nch <= cur.vc) {
+                    full = true;
+                } else if (rel < 0 && rel + cur.nch > 0) {
+                    st_ext(cur.seam0, v[j]);
+                } else if (rel < cur.vc && rel + cur.nch > cur.vc) {
+                    st_ext(cur.seam1, v[j]);
+                }
+                const long long sj = cur.s0 + j * cur.ds;
+                p[j] = (full && sj >= 0 && sj < cur.n_out) ? detect_pair(v[j], mode)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const int npass = mode ? 2 : 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                __syncthreads();                                     // exchange buffer / previous pass done
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    pw[(tau + 16 * j) * FCOL + f] = pass ? make_float2(p[j].z, p[j].w)
+                                                         : make_float2(p[j].x, p[j].y);
+                __syncthreads();
+                const float* pf = reinterpret_cast<const float*>(pw);
+                for (int i = threadIdx.x; i < nb * FCOL * 2; i += NT) {
+                    const int bl = i / (FCOL * 2), fc = i - bl * (FCOL * 2);          // fc = 2 f + comp
+                    const long long bin = b_wg + bl;
+                    if (bin < 0 || bin >= n_bins) continue;
+                    // rows n1 with bin * step <= s_wg + n1 * spr < (bin + 1) * step  (spr = 2^k)
+                    const int d0 = (int)(bin * step - s_wg);        // > -step, <= 255 * spr
+                    int lo = d0 > 0 ? (d0 + spr - 1) >> lg_spr : 0;
+                    int hi = (d0 + step + spr - 1) >> lg_spr;
+                    if (hi > 256) hi = 256;
+                    float sum = 0.f;
+                    for (int n1 = lo; n1 < hi; ++n1) sum += pf[n1 * (FCOL * 2) + fc];
+                    if (sum != 0.f)
+                        unsafeAtomicAdd(so.det + detect_index(bin, ch0 + (fc >> 1), sp, so.lg_chan, npair, mode)
+                                            + 2 * pass + (fc & 1),
+                                        sum * so.det_scale);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (SPEC) {
@@ -578,7 +668,7 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
                                                        float2* __restrict__ out, SeamJobs jobs,
                                                        int S, int npair,
                                                        const cf* __restrict__ tw0,
-                                                       const cf* __restrict__ tw1) {
+                                                       const cf* __restrict__ tw1, SpecOut so) {
     typedef FftGeo<NCH> G;
     constexpr int T = G::T;
     __shared__ v2 lds[G::LDS_ELEMS];
@@ -601,6 +691,22 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
         va[j].im = (early ? va[j].im : vb[j].im) * scale;
     }
     wg_fft<NCH, -1, 0>(va, lds, tau, 0, tw0, tw1);
+    if (so.det) {                               // fused detection: add the spectrum's power to its bin
+        const long long bin = job.spectrum / so.det_step;
+        if (bin >= so.n_out / so.det_step) return;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 pw = detect_pair(va[j], so.det_mode);
+            float* dst = so.det + detect_index(bin, tau + T * j, sp, so.lg_chan, npair, so.det_mode);
+            unsafeAtomicAdd(dst + 0, pw.x * so.det_scale);
+            unsafeAtomicAdd(dst + 1, pw.y * so.det_scale);
+            if (so.det_mode) {
+                unsafeAtomicAdd(dst + 2, pw.z * so.det_scale);
+                unsafeAtomicAdd(dst + 3, pw.w * so.det_scale);
+            }
+        }
+        return;
+    }
     float2* dst = out + ((job.spectrum * NCH + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) st_ext(dst + (long long)T * j * S, va[j]);

@@ -87,6 +87,8 @@ class DeviceStream(Base):
                 n = min(step, source.shape[0] - start)
                 dev[start:start + n].copy_from_host(source.read(n))
             source.seek(old)
+            if samples_per_frame is None:
+                samples_per_frame = source.samples_per_frame
             for key in ('frequency', 'sideband', 'polarization'):
                 if key not in kwargs and getattr(source, key, None) is not None:
                     kwargs[key] = getattr(source, key)

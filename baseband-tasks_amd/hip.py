@@ -61,6 +61,9 @@ SIGNATURES = {
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
+    'bbt_osm_execute_channelized_detect': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int,
+                                           _i64, _i64, _int, _int, _int, _vp],
+    'bbt_osm_detect_bins_max': [_vp, _int, _int],
     'bbt_osm_execute_regular': [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     'bbt_osm_timing_enable': [_vp, _int],
     'bbt_osm_timing_read': [_vp, C.POINTER(C.c_double), _pi64],
@@ -474,6 +477,24 @@ class OsmPlan(_Plan):
             out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
             valid_count.ctypes.data_as(_pi32), int(n_chan), int(first_spectrum), int(n_spectra),
             _stream))
+
+    def detect_bins_max(self, n_chan, step):
+        """Integration bins one workgroup of the last pass would touch (<= 64
+        for the fused detection)."""
+        return int(lib().bbt_osm_detect_bins_max(self._h, int(n_chan), int(step)))
+
+    def execute_channelized_detect(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count,
+                                   n_chan, first_spectrum, n_bins, step, mode, average=True):
+        """Fused Channelize + Square/Power + Integrate(step): float32 bins."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
+        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
+        check(lib().bbt_osm_execute_channelized_detect(
+            self._h, in_dev.ptr, out_dev.ptr, in_off.shape[0], in_off.ctypes.data_as(_pi64),
+            out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
+            valid_count.ctypes.data_as(_pi32), int(n_chan), int(first_spectrum), int(n_bins),
+            int(step), int(mode), int(bool(average)), _stream))
 
     def execute_regular(self, in_dev, out_dev, n_blocks, in_off0, out_off0, hop, valid_start):
         check(lib().bbt_osm_execute_regular(self._h, in_dev.ptr, out_dev.ptr, int(n_blocks),

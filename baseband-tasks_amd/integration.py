@@ -81,6 +81,12 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
         n_out, step = b - a, self._step
         src = self.ih
         if isinstance(src, _DetectTask) and not src.closed:
+            # a channelizer on top of an overlap-save task detects and sums in
+            # that task's last pass: neither stream is ever stored
+            fused = getattr(src.ih, '_compute_detected', None)
+            if (fused is not None and not src._real and not getattr(src.ih, 'closed', False)
+                    and fused(self._ih_start + a * step, n_out, step, src._mode, self.average, out)):
+                return
             x = fetch_device(src.ih, self._ih_start + a * step, n_out * step)
             src._detect(x, n_out, step, out, self.average)
             return

@@ -131,6 +131,24 @@ int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* ou
                                 int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
                                 const int32_t* valid_start, const int32_t* valid_count, int n_chan,
                                 int64_t first_spectrum, int64_t n_spectra, bbt_stream stream);
+/* Fused Integrate(Power|Square(Channelize(Dedisperse(...), n_chan)), step)
+ * (functions.py:15-16, 131-143; integration.py:252-303 with an integer step):
+ * as bbt_osm_execute_channelized, but the spectra first_spectrum ..
+ * first_spectrum + n_bins*step - 1 are detected and summed in the epilogue of
+ * the last column pass instead of being stored, so the channelized stream never
+ * exists either.  out_dev: float32 (n_bins, n_chan, S/2, 4) for mode 1 (|X|^2,
+ * |Y|^2, Re XY*, Im XY* of each stream pair) or (n_bins, n_chan, S) for mode 0
+ * (|z|^2 per stream); average != 0 divides by step.  Sums are formed with float
+ * atomics, so the last bits depend on the order of arrival.  Needs block lengths
+ * 2^16..2^20 and bbt_osm_detect_bins_max(plan, n_chan, step) <= 64 (e.g. step
+ * >= 17 for 1024 channels on 2^20-sample blocks). */
+int bbt_osm_execute_channelized_detect(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
+                                       int64_t n_blocks, const int64_t* in_off,
+                                       const int64_t* out_off, const int32_t* valid_start,
+                                       const int32_t* valid_count, int n_chan,
+                                       int64_t first_spectrum, int64_t n_bins, int step, int mode,
+                                       int average, bbt_stream stream);
+int bbt_osm_detect_bins_max(const bbt_osm_plan* plan, int n_chan, int step);
 /* Regular case: block b has in_off = in_off0 + b*hop, out_off = out_off0 +
  * b*hop, the same valid_start and valid_count = hop. */
 int bbt_osm_execute_regular(bbt_osm_plan* plan, const void* in_dev, void* out_dev,

@@ -438,6 +438,12 @@ def test_metric_pipeline_with_detection():
     want = orc.integrate(orc.power(z), 16)
     assert got.shape == want.shape == (z.shape[0] // 16, 1024, 4)
     _close(got, want, rtol=1e-5)
+    # 64 spectra per bin: few enough bins per workgroup for the route that sums
+    # inside the last overlap-save pass (step 16 above detects stored spectra)
+    ch = bt.Channelize(bt.Dedisperse(ds, 100.), 1024, 64)
+    it = bt.Integrate(bt.Power(ch), 64, start=5)
+    assert ch.ih._get_plan().detect_bins_max(1024, 64) <= 64 < ch.ih._get_plan().detect_bins_max(1024, 16)
+    _close(it.read(), orc.integrate(orc.power(z), 64, start=5), rtol=1e-5)
 
 
 def test_shift_samples_and_incoherent_dedispersion(golden):
@@ -726,3 +732,45 @@ def test_direct_and_fourier_convolution_agree(sample_shape, dtype, monkeypatch):
         want = sr2.read()
         monkeypatch.undo()
         assert rel_l2(got, want) <= REL_L2_TOL and max_over_rms(got, want) <= MAX_TOL
+
+
+@pytest.mark.parametrize('sample_shape', [(2,), (2, 2)])
+def test_fused_detection_matches_stored_spectra(sample_shape, monkeypatch):
+    """Integrate(Power|Square(Channelize(Dedisperse))) sums the power in the
+    last pass of the overlap-save plan (float atomics); it must equal
+    detecting the stored spectra, and the oracle, for steps that do and do not
+    divide the spectra of a block, with a start offset, and fall back when a
+    workgroup would touch too many bins."""
+    import baseband_tasks_amd.channelize as chz
+    pol = ['X', 'Y']
+    nh = noise(3 * 2**18 + 5000, sample_shape, 2**18, seed=31, frequency=1000 * u.MHz, sideband=1,
+               polarization=pol)
+    ds = bt.DeviceStream(nh, T0, 16 * u.MHz)
+    x = orc.noise_stream(31, 0, nh.shape[0], 2**18, sample_shape)
+    y, info = orc.dedisperse(x, 16e6, 1000., 1, 30., ih_samples_per_frame=2**18)
+    n_chan = 256
+    n_spec = (y.shape[0] // (n_chan * 32)) * 32          # whole frames of 32 spectra
+    z = orc.channelize(y[:n_spec * n_chan], n_chan)
+    for detect, mode in ((bt.Power, 1), (bt.Square, 0)):
+        for step, start in ((64, 0), (100, 7), (17 * 4, 3), (1000, 0)):
+            def build():
+                dd = bt.Dedisperse(ds, 30.)
+                assert dd._ih_samples_per_frame == 2**18
+                ch = bt.Channelize(dd, n_chan, 32)
+                return bt.Integrate(detect(ch), step, start=start, samples_per_frame=1)
+            it = build()
+            plan = it.ih.ih.ih._get_plan()
+            assert plan.detect_bins_max(n_chan, step) <= 64
+            got = it.read()
+            monkeypatch.setattr(chz, 'FUSE_DETECTION', False)
+            want_gpu = build().read()
+            monkeypatch.undo()
+            det = orc.power(z) if mode else orc.square(z)
+            want = orc.integrate(det, step, start=start)
+            assert got.shape == want_gpu.shape == want.shape and got.dtype == np.float32
+            _close(got, want_gpu, rtol=2e-6)
+            _close(got, want, rtol=1e-5)
+    # a step too short for the fused route (more than 64 bins per workgroup) still works
+    it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds, 30.), n_chan, 32)), 8)
+    assert it.ih.ih.ih._get_plan().detect_bins_max(n_chan, 8) > 64
+    _close(it.read(), orc.integrate(orc.power(z), 8), rtol=1e-5)
