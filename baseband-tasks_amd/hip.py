@@ -336,6 +336,15 @@ def as_device_array(obj):
     raise TypeError(f"cannot interpret {type(obj)} as a device array")
 
 
+def copy_2d(dst, dst_pitch, src, src_pitch, src_offset, width, rows):
+    """Device-to-device copy of ``rows`` runs of ``width`` bytes: run r goes
+    from src + src_offset + r * src_pitch to dst + r * dst_pitch."""
+    if rows and width:
+        check(lib().bbt_memcpy2d(dst.ptr, int(dst_pitch), src.ptr + int(src_offset), int(src_pitch),
+                                 int(width), int(rows), 2, _stream))
+    return dst
+
+
 def pad_streams_to_even(dev, n_stream):
     """(n, S) complex64 with odd S -> (n, S+1) with a zero stream appended."""
     n = dev.size // n_stream

@@ -1,15 +1,20 @@
 """Multi-GPU helpers: one process per GPU, independent overlap-save blocks.
 
-The path shards with no halo exchange: block m reads input
-[m * spf, m * spf + N) and nothing else (reference base.py:783-790), so ranks
-own disjoint runs of blocks and re-read their own overlap.  The only
+The path shards with no halo exchange, in two ways.  (1) Time:
+block m reads input [m * spf, m * spf + N) and nothing else (reference
+base.py:783-790), so ranks own disjoint runs of blocks and re-read their own
+overlap (`frame_range`, `gather_frames`).  (2) Sub-bands: the streams along
+the first sample axis are independent series, so each rank takes a run of
+them with its own chirp columns (`SubbandShard`) and the results are
+concatenated along that axis (`gather_subbands`, the role
+`combining.Concatenate` plays on the host, combining.py:176-211).  The only
 collectives are one broadcast of the response (chirp) at plan time and an
 optional gather of the outputs; both go through ``torch.distributed``
 (backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).
 """
 import numpy as np
 
-__all__ = ['frame_range', 'share_response', 'gather_frames']
+__all__ = ['frame_range', 'share_response', 'gather_frames', 'SubbandShard', 'gather_subbands']
 
 
 def frame_range(n_frames, rank, world):
@@ -65,3 +70,59 @@ def gather_frames(local, torch, dist):
                       device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out
+
+
+def _slice_meta(value, lo, hi, n_axis, ndim_sample):
+    """Slice metadata (frequency, sideband, polarization) along the first
+    sample axis if it extends along it; broadcast (unit) axes stay."""
+    if value is None:
+        return None
+    arr = np.asanyarray(value)
+    if arr.ndim < ndim_sample or arr.shape[arr.ndim - ndim_sample] != n_axis:
+        return value
+    index = [slice(None)] * arr.ndim
+    index[arr.ndim - ndim_sample] = slice(lo, hi)
+    return arr[tuple(index)]
+
+
+def SubbandShard(ih, rank, world):
+    """The run of sub-bands (entries of the first sample axis) of stream ``ih``
+    that ``rank`` of ``world`` processes, as a stream with the same interface:
+    shape ``(n, k) + ih.shape[2:]``, metadata sliced to match.  Data stay where
+    they are (host reads slice, device reads copy the strided columns once)."""
+    from . import hip
+    from .base import TaskBase, META_ATTRIBUTES
+    from .device_task import DeviceTaskMixin, fetch_device
+
+    n_sub = ih.shape[1]
+    lo, hi = frame_range(n_sub, rank, world)
+    ndim_sample = len(ih.shape) - 1
+    meta = {key: _slice_meta(getattr(ih, key, None), lo, hi, n_sub, ndim_sample)
+            for key in META_ATTRIBUTES}
+
+    class _SubbandShard(DeviceTaskMixin, TaskBase):
+        subbands = (lo, hi)
+
+        def task(self, data):
+            return np.ascontiguousarray(data[:, lo:hi])
+
+        def _compute_frames(self, first, last, out):
+            start, stop = self._frame_span(first, last)
+            x = fetch_device(self.ih, start, stop - start)
+            inner = out.row_bytes // (hi - lo)             # bytes of one sub-band of a sample
+            hip.copy_2d(out, out.row_bytes, x, x.row_bytes, lo * inner, (hi - lo) * inner,
+                        stop - start)
+
+    return _SubbandShard(ih, shape=(ih.shape[0], hi - lo) + tuple(ih.shape[2:]),
+                         **{k: v for k, v in meta.items() if v is not None})
+
+
+def gather_subbands(local, torch, dist):
+    """Concatenate equally shaped per-rank results ``(n, k, ...)`` along the
+    sub-band axis, in rank order: ``(n, world * k, ...)`` on every rank."""
+    world = dist.get_world_size()
+    flat = gather_frames(local, torch, dist)                       # (world * n, k, ...)
+    n = local.shape[0]
+    stacked = flat.reshape((world, n) + tuple(local.shape[1:]))
+    order = (1, 0) + tuple(range(2, stacked.dim()))
+    return stacked.permute(*order).reshape((n, world * local.shape[1]) + tuple(local.shape[2:]))

@@ -774,3 +774,35 @@ def test_fused_detection_matches_stored_spectra(sample_shape, monkeypatch):
     it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds, 30.), n_chan, 32)), 8)
     assert it.ih.ih.ih._get_plan().detect_bins_max(n_chan, 8) > 64
     _close(it.read(), orc.integrate(orc.power(z), 8), rtol=1e-5)
+
+
+def test_subband_shards_equal_columns_of_the_whole():
+    """Config-4 style sharding: a rank's run of sub-bands is the same series as
+    those columns of the whole stream (bit-exact through a per-stream filter),
+    and dedisperses with its own chirp columns to the oracle's result."""
+    from baseband_tasks_amd import sharding
+    freq = (400. + 6.25 * np.arange(6)).reshape(6, 1) * u.MHz
+    nh = noise(3 * 2**14, (6, 2), 2**14, seed=41, fs=6.25 * u.MHz, frequency=freq, sideband=1,
+               polarization=['X', 'Y'])
+    x = nh.read()
+    resp = np.random.default_rng(2).standard_normal((31, 6, 2))
+    whole = bt.Convolve(nh, resp).read()
+    for world in (2, 3):
+        parts = []
+        for rank in range(world):
+            mine = sharding.SubbandShard(nh, rank, world)
+            lo, hi = mine.subbands
+            assert mine.shape == (nh.shape[0], hi - lo, 2) and np.all(mine.frequency == freq[lo:hi] * 1.)
+            assert np.array_equal(mine.read(), x[:, lo:hi])
+            mine.seek(1000)
+            assert np.array_equal(mine.read_device(77).to_host(), x[1000:1077, lo:hi])
+            mine.seek(0)
+            parts.append(bt.Convolve(mine, resp[:, lo:hi]).read())
+            dd = bt.Dedisperse(mine, 0.5, reference_frequency=mine.frequency)
+            want, info = orc.dedisperse(x[:, lo:hi], 6.25e6, np.asarray(freq[lo:hi]) / 1e6, 1, 0.5,
+                                        reference_frequency_mhz=np.asarray(freq[lo:hi]) / 1e6,
+                                        ih_samples_per_frame=2**14,
+                                        fast_len=HipFFTMaker.next_fast_len)
+            assert dd._ih_samples_per_frame == info['ih_spf']
+            assert_parity(dd.read(), want, f'shard {rank}/{world}')
+        assert np.array_equal(np.concatenate(parts, axis=1), whole)

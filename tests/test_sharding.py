@@ -48,8 +48,19 @@ def _worker(rank, world, port, result_dir):
         # fake "outputs": the frame indices owned, gathered in stream order
         local = torch.arange(first, first + 4, dtype=torch.float32).reshape(4, 1)
         gathered = sharding.gather_frames(local, torch, dist)
+        # sub-band sharding: 6 sub-bands x 2 pol, each rank takes 3 with their metadata
+        freq = (400. + 6.25 * np.arange(6)).reshape(6, 1) * u.MHz
+        sb = bt.NoiseGenerator((4096, 6, 2), '2020-01-01T00:00:00', 1 * u.MHz, 1024, seed=9,
+                               frequency=freq, sideband=1, polarization=['X', 'Y'])
+        mine = sharding.SubbandShard(sb, rank, world)          # (reading it needs the GPU: -m gpu suite)
+        lo, hi = mine.subbands
+        part = np.ascontiguousarray(sb.read()[:, lo:hi])
+        full = sharding.gather_subbands(torch.view_as_real(torch.from_numpy(part)), torch, dist)
         np.savez(os.path.join(result_dir, f'rank{rank}.npz'), resp=resp.numpy(), idx=idx.numpy(),
-                 span=np.array([first, last]), gathered=gathered.numpy())
+                 span=np.array([first, last]), gathered=gathered.numpy(),
+                 sub_shape=np.array(mine.shape), sub_freq=np.asarray(mine.frequency, dtype=float),
+                 sub_pol=np.asarray(mine.polarization), sub_span=np.array(mine.subbands),
+                 sub_full=torch.view_as_complex(full.contiguous()).numpy())
     finally:
         dist.destroy_process_group()
 
@@ -73,3 +84,13 @@ def test_share_response_and_gather_gloo(tmp_path):
     assert np.array_equal(r0['gathered'], r1['gathered'])
     assert r0['gathered'][:4, 0].tolist() == [0, 1, 2, 3]
     assert r0['gathered'][4, 0] == r1['span'][0]
+    # sub-band shards: 3 sub-bands each, metadata follows, concatenation restores the stream
+    sb = bt.NoiseGenerator((4096, 6, 2), '2020-01-01T00:00:00', 1 * u.MHz, 1024, seed=9,
+                           frequency=(400. + 6.25 * np.arange(6)).reshape(6, 1) * u.MHz, sideband=1,
+                           polarization=['X', 'Y'])
+    whole = sb.read()
+    for r, res in enumerate((r0, r1)):
+        assert res['sub_shape'].tolist() == [4096, 3, 2] and res['sub_span'].tolist() == [3 * r, 3 * r + 3]
+        assert np.allclose(res['sub_freq'].ravel(), (400. + 6.25 * np.arange(3 * r, 3 * r + 3)) * 1e6)
+        assert res['sub_pol'].tolist() == ['X', 'Y']
+        assert np.array_equal(res['sub_full'], whole)

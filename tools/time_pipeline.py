@@ -1,4 +1,4 @@
-"""Where does the detection pipeline spend its time? (dev tool)"""
+"""Per-pass times of the metric pipeline with and without fused detection (dev tool)."""
 import sys
 import time
 
@@ -22,48 +22,28 @@ for t in (dd, ch, pw):
     t.max_frames_per_call = 10**6
 
 
-def timed(label, fn, reps=5):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print(f"{label:50s} {dt * 1e3:8.3f} ms")
-    return dt
-
-
-def inval():
+def run(last, n):
     for t in (dd, ch, pw):
         t.invalidate_cache()
+    last.seek(0)
+    return last.read_device(n)
 
 
-def run_ch(n):
-    inval()
-    ch.seek(0)
-    return ch.read_device(n)
-
-
-def run_pw():
-    inval()
-    pw.seek(0)
-    return pw.read_device(pw.shape[0])
-
-
-print('ch.shape', ch.shape, 'pw.shape', pw.shape)
-timed('channelize all', lambda: run_ch(ch.shape[0]))
-timed('channelize pw.shape[0]*64 spectra', lambda: run_ch(pw.shape[0] * 64))
-timed('power+integrate pipeline', run_pw)
-
-# same through a SetAttribute wrapper (as tools/bench_configs.py does)
-ds2 = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=900e6, sideband=1)
-dsf = bt.SetAttribute(ds2, frequency=1000e6, polarization=['X', 'Y'])
-dd = bt.Dedisperse(dsf, 100.)
-ch = bt.Channelize(dd, 1024, 512)
-pw = bt.Integrate(bt.Power(ch), 64)
-for t in (dd, ch, pw):
-    t.max_frames_per_call = 10**6
-timed('SetAttribute: channelize all', lambda: run_ch(ch.shape[0]))
-timed('SetAttribute: power+integrate pipeline', run_pw)
+plan = dd._get_plan()
+for label, last, n in (('spectra stored', ch, ch.shape[0]), ('detected + integrated', pw, pw.shape[0])):
+    for mode in (1, 2):
+        for _ in range(3):
+            run(last, n)
+        torch.cuda.synchronize()
+        plan.timing_enable(mode)
+        t0 = time.perf_counter()
+        reps = 8
+        for _ in range(reps):
+            run(last, n)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ms, launches = plan.timing_read()
+        plan.timing_enable(0)
+        nb = 120 * reps
+        print(f"{label:24s} mode {mode}: wall {dt * 1e3:6.3f} ms  passes per block (us): "
+              f"A {ms[0] / nb * 1e3:5.2f}  B {ms[1] / nb * 1e3:5.2f}  C {ms[2] / nb * 1e3:5.2f}")
