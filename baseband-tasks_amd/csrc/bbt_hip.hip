@@ -911,9 +911,18 @@ static void launch_short(const bbt_chan_plan* p, const float2* in, float2* out, 
                          float scale, hipStream_t st) {
     constexpr int R = (N <= 16) ? 1 : N / 16;
     constexpr int FPW = 256 / R;
-    const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
-    hipLaunchKernelGGL((k_fft_short<N, SIGN>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
-                       (long long)n_fft, p->S, scale, p->wroot);
+#define BBT_SHORT(PP_)                                                                         \
+    {                                                                                          \
+        constexpr int FPB = FPW / PP_;                                                         \
+        const unsigned gx = (unsigned)((n_fft + FPB - 1) / FPB);                               \
+        hipLaunchKernelGGL((k_fft_short<N, SIGN, PP_>), dim3(gx * (p->npair / PP_)), dim3(256), 0, \
+                           st, in, out, (long long)n_fft, p->S, scale, p->wroot);              \
+    }
+    if (p->npair % 8 == 0) BBT_SHORT(8)
+    else if (p->npair % 4 == 0) BBT_SHORT(4)
+    else if (p->npair % 2 == 0) BBT_SHORT(2)
+    else BBT_SHORT(1)
+#undef BBT_SHORT
 }
 
 template <int N, int SIGN>

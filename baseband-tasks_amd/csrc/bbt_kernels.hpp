@@ -83,22 +83,27 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
 //   N = 16 R, R in {2, 4, 8}: R threads per transform; radix-16 over the
 //             elements tau + R j, twiddle W_N^{tau c}, exchange through LDS,
 //             radix-R; output k = c + 16 k'.
-// Accesses are per-thread short runs (N <= 128 samples = 2 KiB per group);
-// neighbouring lanes cover neighbouring groups so the L1/L2 see whole lines.
-template <int N, int SIGN>
+// Lanes run over PP stream pairs first (PP * 16 bytes of one complete sample
+// are contiguous: with 8 pairs a whole 128-byte line per 8 lanes; config 4's
+// share on one GPU went from 2.06 to 2.25 G complete samples/s), then over the R threads of
+// a transform (consecutive samples), then over transforms.
+template <int N, int SIGN, int PP>
 __global__ __launch_bounds__(256) void k_fft_short(const float2* __restrict__ in,
                                                    float2* __restrict__ out, long long n_fft, int S,
                                                    float scale, const cf* __restrict__ wroot) {
     constexpr int R = (N <= 16) ? 1 : N / 16;        // threads per transform
     constexpr int P = (N <= 16) ? N : 16;            // points per thread
-    constexpr int FPW = 256 / R;                     // transforms per workgroup
+    constexpr int FPW = 256 / R;                     // (transform, pair) slots per workgroup
+    constexpr int FPB = FPW / PP;                    // transforms per workgroup
     constexpr int PITCH = R + 1;
     __shared__ v2 lds[(R > 1) ? FPW * 16 * PITCH : 1];
-    const int npair = S >> 1;
+    const int npair = S >> 1, npg = npair / PP;      // pair groups (npair % PP == 0)
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int slot = threadIdx.x / R, tau = threadIdx.x % R;
-    const long long i = (long long)(vb / npair) * FPW + slot;
-    const int sp = vb % npair;
+    const int pl = threadIdx.x % PP, rest = threadIdx.x / PP;
+    const int tau = rest % R, tslot = rest / R;
+    const int slot = tslot * PP + pl;                // LDS region
+    const long long i = (long long)(vb / npg) * FPB + tslot;
+    const int sp = (vb % npg) * PP + pl;
     const bool active = i < n_fft;
     c2 v[P];
     if (active) {

@@ -331,6 +331,12 @@ def test_short_channelizer(n):
     ch.seek(0)
     back = bt.Dechannelize(ch).read()
     assert np.abs(back - x[:k * n]).max() < 1e-5
+    # the lanes run over groups of 8, 4, 2 or 1 stream pairs: 16, 12, 6 and 2 streams
+    for shape in ((8, 2), (6, 2), (3, 2), (2,)):
+        nh = noise(3000, shape, 1000, seed=22, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
+        x = orc.noise_stream(22, 0, 3000, 1000, shape)
+        z = bt.Channelize(nh, n, samples_per_frame=3).read()
+        assert_parity(z, orc.channelize(x[:z.shape[0] * n], n), f'n={n} streams {shape}')
 
 
 def test_config4_subband_block_2_24():
