@@ -52,9 +52,20 @@ def test_argument_validation_reports_errors():
     assert b'out of range' in lib.bbt_last_error()
     assert lib.bbt_osm_execute(None, None, None, 0, None, None, None, None, None) != 0
     assert lib.bbt_memcpy2d(None, 0, None, 0, 0, 0, 7, None) != 0
+    taps = np.zeros((5, 3), np.complex64)
+    assert lib.bbt_fir_plan_create(C.byref(plan), 5, 3, taps.ctypes.data) != 0
+    assert b'even' in lib.bbt_last_error()
+    assert lib.bbt_fir_plan_create(C.byref(plan), 5000, 2, taps.ctypes.data) != 0
+    assert b'n_tap' in lib.bbt_last_error()
+    assert lib.bbt_fir_execute(None, None, None, 0, None) != 0
+    assert lib.bbt_osm_execute_channelized_detect(None, None, None, 0, None, None, None, None, 1024,
+                                                  0, 0, 64, 1, 1, None) != 0
+    assert lib.bbt_osm_detect_bins_max(None, 1024, 64) == -1
+    assert lib.bbt_free(C.c_void_p(12345)) != 0 and b'not allocated' in lib.bbt_last_error()
     # destroying null plans is harmless
     assert lib.bbt_osm_plan_destroy(None) == 0 and lib.bbt_chan_plan_destroy(None) == 0
-    assert lib.bbt_pfb_plan_destroy(None) == 0
+    assert lib.bbt_pfb_plan_destroy(None) == 0 and lib.bbt_fir_plan_destroy(None) == 0
+    assert lib.bbt_shift_plan_destroy(None) == 0
 
 
 def test_python_wrappers_raise():
