@@ -315,3 +315,69 @@ def test_package_never_imports_the_oracle():
                 text = open(os.path.join(root, name)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', text, re.M), name
                 assert 'bbt_oracle' not in text, name
+
+
+# --------------------------------------------------------------------------- randomised geometry (hypothesis)
+def test_block_descriptors_match_the_oracle_for_random_geometry():
+    """The block schedule handed to the GPU (`_block_descriptors`: input start,
+    absolute output sample, first kept block sample, kept count per block)
+    restates base.py:775-795; compare with the oracle's `padded_blocks` over
+    random stream lengths, paddings and frame sizes, for every frame range."""
+    hypothesis = pytest.importorskip('hypothesis')
+    from hypothesis import given, settings, strategies as st
+    from baseband_tasks_amd.overlap_save import SpectralMultiplyTask
+
+    class _Plain(SpectralMultiplyTask):
+        _keep_from = 0
+
+        def _spectral_response(self):
+            return np.ones((self._ih_samples_per_frame, 1), np.complex64)
+
+    @settings(max_examples=60, deadline=None)
+    @given(pad_start=st.integers(0, 300), pad_end=st.integers(0, 300),
+           extra=st.integers(0, 5000), n_blocks=st.integers(1, 6), data=st.data())
+    def check(pad_start, pad_end, extra, n_blocks, data):
+        pad = pad_start + pad_end
+        ih_spf = 1024
+        spf = ih_spf - pad
+        n_in = n_blocks * spf + pad + (extra % spf)
+        nh = bt.EmptyStreamGenerator((n_in, 2), T0, 1 * u.kHz, samples_per_frame=200)
+        pt = _Plain(nh, pad_start, pad_end, samples_per_frame=spf)
+        pt._keep_from = pad_start
+        geo = orc.padded_geometry(n_in, 200, pad_start, pad_end, spf, HipFFTMaker.next_fast_len)
+        assert (pt._ih_samples_per_frame, pt.samples_per_frame, pt.shape[0]) == \
+            (geo['ih_spf'], geo['spf'], geo['n_out'])
+        blocks = list(orc.padded_blocks(n_in, geo))
+        first = data.draw(st.integers(0, len(blocks) - 1))
+        last = data.draw(st.integers(first + 1, len(blocks)))
+        in0, in_len, starts, out_abs, keep, counts = pt._block_descriptors(first, last)
+        assert in0 == blocks[first][0] and in0 + in_len == blocks[last - 1][0] + geo['ih_spf']
+        for k, (in_start, frame_offset, out_start, out_count) in enumerate(blocks[first:last]):
+            assert (starts[k], out_abs[k], keep[k], counts[k]) == \
+                (in_start, out_start, pad_start + frame_offset, out_count)
+
+    check()
+
+
+def test_integrate_and_channelize_shapes_for_random_sizes():
+    hypothesis = pytest.importorskip('hypothesis')
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(n=st.integers(2000, 50000), step=st.integers(1, 400), start=st.integers(0, 1000),
+           lg_chan=st.integers(1, 10), spf=st.integers(1, 9))
+    def check(n, step, start, lg_chan, spf):
+        nh = bt.EmptyStreamGenerator((n, 2), T0, 1 * u.kHz, samples_per_frame=100, dtype=np.float32)
+        it = bt.Integrate(nh, step, start=start)
+        want = orc.integrate(np.zeros((n, 2), np.float32), step, start=start)
+        assert it.shape == want.shape and it.sample_rate == 1e3 / step
+        assert abs((it.start_time - nh.start_time) - start / 1e3) < 1e-9
+        n_chan = 1 << lg_chan
+        if n >= n_chan * spf:
+            nc = bt.EmptyStreamGenerator((n, 2), T0, 1 * u.kHz, samples_per_frame=100,
+                                         frequency=300 * u.MHz, sideband=1)
+            ch = bt.Channelize(nc, n_chan, samples_per_frame=spf)
+            assert ch.shape == ((n // (n_chan * spf)) * spf, n_chan, 2)
+            assert ch.sample_rate == 1e3 / n_chan
+
+    check()
