@@ -784,6 +784,9 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
 // NTAP rows per spectrum.  The accumulators are then exactly the register
 // layout of the fused channelizer (NG groups of P points), so the FFT is
 // radix-P + the tail of the 4096-point transform.
+#ifndef BBT_PFB_BATCH
+#define BBT_PFB_BATCH 64
+#endif
 template <int N, int NTAP>
 __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ in,
                                                     float2* __restrict__ out, long long n_spec,
@@ -800,34 +803,56 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
     const long long i0 = (long long)(vb / npair) * NG;      // first spectrum of this workgroup
     const int sp = vb % npair;
-    float h[NTAP][P];
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int c = 0; c < P; ++c) h[t][c] = taps[t * N + tau + T * c];
     c2 v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = czero();
     const long long rows_left = n_spec + NTAP - 1 - i0;     // input rows that exist from i0 on
     const float2* src = in + ((i0 * N + tau) * S + 2 * sp);
+    // One column of the thread at a time: all NTAP + NG - 1 row loads of the
+    // column are issued together (the kernel is bound by load latency at 2
+    // waves/SIMD: this keeps 15 loads per thread in flight instead of ~4), then
+    // each row feeds the accumulators of the spectra it belongs to.
 #pragma unroll
-    for (int r = 0; r < NTAP + NG - 1; ++r) {
-        if (r < rows_left) {
-            c2 x[P];
+    for (int c = 0; c < P; ++c) {
+        float h[NTAP];
 #pragma unroll
-            for (int c = 0; c < P; ++c) x[c] = ld_ext(src + ((long long)r * N + T * c) * S);
+        for (int t = 0; t < NTAP; ++t) h[t] = taps[t * N + tau + T * c];
+        // rows past the end of the stream (last workgroup only): read the last
+        // existing row instead and zero it, so the loads stay branch free
+        constexpr int NR = NTAP + NG - 1;
+        constexpr int RB = (BBT_PFB_BATCH < NR) ? BBT_PFB_BATCH : NR;      // rows in flight per batch
 #pragma unroll
-            for (int q = 0; q < NG; ++q) {
-                const int t = r - q;                          // tap index for spectrum i0 + q
-                if (t >= 0 && t < NTAP) {
+        for (int r0 = 0; r0 < NR; r0 += RB) {
+            c2 x[RB];
 #pragma unroll
-                    for (int c = 0; c < P; ++c) {
-                        v[q * P + c].re += x[c].re * h[t][c];
-                        v[q * P + c].im += x[c].im * h[t][c];
+            for (int i = 0; i < RB; ++i) {
+                const int r = r0 + i;
+                if (r < NR) {
+                    const long long rr = r < rows_left ? r : rows_left - 1;
+                    x[i] = ld_ext(src + (rr * N + T * c) * S);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int r = r0 + i;
+                if (r < NR) {
+                    const float keep = r < rows_left ? 1.f : 0.f;
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) {
+                        const int t = r - q;                  // tap index for spectrum i0 + q
+                        if (t >= 0 && t < NTAP) {
+                            v[q * P + c].re += x[i].re * (h[t] * keep);
+                            v[q * P + c].im += x[i].im * (h[t] * keep);
+                        }
                     }
                 }
             }
+            asm volatile("" ::: "memory");
         }
+        // keep the next column's loads behind this column's arithmetic: hoisting
+        // them all (the loop is unrolled) needs 4 x 60 registers
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
     // FFT over the columns of each spectrum: radix-P, twiddle W_N^{tau c}, tail
 #pragma unroll
