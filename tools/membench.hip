@@ -56,7 +56,59 @@ static void run(const char* name, F launch, double bytes) {
     printf("%-28s %8.2f us/launch  %6.2f TB/s (read+write)\n", name, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12);
 }
 
+// producer -> consumer through the caches: one kernel writes a buffer, the next reads it
+__global__ __launch_bounds__(256) void k_fill(float4* __restrict__ out, float v) {
+    const long long base = (long long)blockIdx.x * N2 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[base + 256 * j] = make_float4(v, v, v, v);
+}
+__global__ __launch_bounds__(256) void k_sum(const float4* __restrict__ in, float* __restrict__ sink) {
+    const long long base = (long long)blockIdx.x * N2 + threadIdx.x;
+    float4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = in[base + 256 * j];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
+    if (s == 123.456f) sink[0] = s;      // never true: keeps the loads
+}
+
+static void producer_consumer() {
+    printf("write a buffer, then read it back with the next kernel (MiB: write TB/s, read TB/s)\n");
+    float* sink;
+    CHECK(hipMalloc(&sink, 4));
+    for (int mib : {32, 64, 128, 192, 256, 384, 512, 1024}) {
+        const size_t elems = (size_t)mib * 65536;            // float4 per MiB
+        float4* buf;
+        CHECK(hipMalloc(&buf, elems * 16));
+        const int rows = (int)(elems / N2);
+        hipEvent_t e0, e1, e2;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&e2));
+        float wr = 0.f, rd = 0.f;
+        const int reps = 10;
+        for (int i = 0; i < reps + 2; ++i) {
+            CHECK(hipEventRecord(e0));
+            k_fill<<<rows, 256>>>(buf, (float)i);
+            CHECK(hipEventRecord(e1));
+            k_sum<<<rows, 256>>>(buf, sink);
+            CHECK(hipEventRecord(e2));
+            CHECK(hipEventSynchronize(e2));
+            float a, b;
+            CHECK(hipEventElapsedTime(&a, e0, e1)); CHECK(hipEventElapsedTime(&b, e1, e2));
+            if (i >= 2) { wr += a; rd += b; }
+        }
+        const double bytes = (double)elems * 16;
+        printf("  %5d MiB: write %5.2f  read %5.2f\n", mib, bytes / (wr / reps * 1e-3) / 1e12,
+               bytes / (rd / reps * 1e-3) / 1e12);
+        CHECK(hipFree(buf));
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 0) {
+        producer_consumer();
+        return 0;
+    }
     const int nblk = argc > 1 ? atoi(argv[1]) : 4;              // blocks of 16 MiB per launch
     const int nbuf = argc > 2 ? atoi(argv[2]) : 1;              // rotate over this many buffer pairs (cache state)
     const size_t elems = (size_t)nblk * N1 * N2;
