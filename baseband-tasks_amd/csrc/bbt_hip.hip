@@ -394,8 +394,24 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
 template <int N>
 static void launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
                          hipStream_t st) {
-    hipLaunchKernelGGL((k_osm_small<N>), dim3(ch.nblk, p->npair), dim3(N / 16), 0, st, in, out, ch,
-                       p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
+    // lanes over groups of pairs when there are many (see k_osm_small); the
+    // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
+    constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
+    constexpr size_t lds1 = FftGeo<N>::LDS_ELEMS * sizeof(v2);
+    if (p->npair % PP == 0) {
+        static bool prepared = false;
+        if (!prepared) {
+            (void)hipFuncSetAttribute((const void*)k_osm_small<N, PP>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds1 * PP));
+            prepared = true;
+        }
+        hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(ch.nblk * (p->npair / PP)), dim3(PP * N / 16),
+                           lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0,
+                           p->tab2.tw1);
+    } else {
+        hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(ch.nblk * p->npair), dim3(N / 16), lds1, st, in, out,
+                           ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
+    }
 }
 
 static int osm_flush_timing(bbt_osm_plan* p) {

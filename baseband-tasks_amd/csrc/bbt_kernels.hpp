@@ -281,29 +281,39 @@ __device__ __forceinline__ void apply_resp(c2 (&v)[16], const cf* __restrict__ h
     }
 }
 
-// Single-kernel path, N <= 4096: one workgroup per (block, pair).
-template <int N>
-__global__ __launch_bounds__(N / 16) void k_osm_small(const float2* __restrict__ in,
-                                                       float2* __restrict__ out, OsmChunk ch, int S,
-                                                       const cf* __restrict__ resp,
-                                                       const int* __restrict__ resp_index,
-                                                       const cf* __restrict__ tw0,
-                                                       const cf* __restrict__ tw1) {
+// Single-kernel path, N <= 4096: one workgroup per (block, group of PP pairs).
+// With many streams (InversePolyphaseFilterBank runs this along the block axis
+// with n_chan * S streams) the lanes run over PP pairs first, so a wave touches
+// PP * 16 contiguous bytes of each complete sample instead of 16; the PP
+// transforms are interleaved in LDS (COLMODE = PP).
+template <int N, int PP>
+__global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restrict__ in,
+                                                          float2* __restrict__ out, OsmChunk ch, int S,
+                                                          const cf* __restrict__ resp,
+                                                          const int* __restrict__ resp_index,
+                                                          const cf* __restrict__ tw0,
+                                                          const cf* __restrict__ tw1) {
     typedef FftGeo<N> G;
     constexpr int T = G::T;
-    __shared__ v2 lds[G::LDS_ELEMS];
-    const int tau = threadIdx.x, sp = blockIdx.y;
-    const OsmBlock blk = ch.b[blockIdx.x];
+    constexpr int CM = PP > 1 ? PP : 0;
+    extern __shared__ v2 osm_small_lds[];          // G::LDS_ELEMS * PP elements (up to 72 KiB)
+    v2* lds = osm_small_lds;
+    // the pairs of one block share cache lines: consecutive virtual ids, one XCD
+    const int npg = (S >> 1) / PP;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pl = threadIdx.x % PP, tau = threadIdx.x / PP;
+    const int sp = (vb % npg) * PP + pl;
+    const OsmBlock blk = ch.b[vb / npg];
     c2 v[16];
     const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
-    wg_fft<N, -1, 0>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N, -1, CM>(v, lds, tau, pl, tw0, tw1);
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (long long)c0 * N + tau;
     const cf* h1 = resp + (long long)c1 * N + tau;
     apply_resp<T>(v, h0, h1, c0 == c1);
-    wg_fft<N, +1, 0>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N, +1, CM>(v, lds, tau, pl, tw0, tw1);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int r = tau + T * j - blk.valid_start;

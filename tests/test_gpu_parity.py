@@ -812,3 +812,19 @@ def test_subband_shards_equal_columns_of_the_whole():
             assert dd._ih_samples_per_frame == info['ih_spf']
             assert_parity(dd.read(), want, f'shard {rank}/{world}')
         assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
+@pytest.mark.parametrize('n_fft', [256, 512, 1024, 2048, 4096])
+def test_single_kernel_blocks_with_many_streams(n_fft, monkeypatch):
+    """Blocks of <= 4096 samples run as one kernel whose lanes go over groups
+    of stream pairs (2, 4 or 8) first; 16 and 6 streams take the grouped and
+    the one-pair-per-workgroup variants."""
+    monkeypatch.setattr(bt.Convolve, 'FIR_MAX_TAPS', 0)
+    resp = np.random.default_rng(8).standard_normal(20)
+    for shape in ((8, 2), (3, 2)):
+        nh = noise(5 * n_fft, shape, n_fft, seed=51, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
+        cv = bt.Convolve(nh, resp, samples_per_frame=n_fft - 19)
+        assert not cv._use_fir() and cv._ih_samples_per_frame == n_fft
+        want, _ = orc.convolve(nh.read(), resp.reshape(-1, 1, 1), samples_per_frame=n_fft - 19,
+                               ih_samples_per_frame=n_fft, fast_len=HipFFTMaker.next_fast_len)
+        assert_parity(cv.read(), want, f'n_fft={n_fft} streams {shape}')
