@@ -453,6 +453,26 @@ static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2
             return;
         }
     }
+    // Many streams: the last pass puts the lanes of a row over 8 (4) pairs, so
+    // every store instruction writes whole 128-byte lines of the output
+    // (config 4's share +8 %; the same on the first pass, i.e. for its reads,
+    // measured 8 % slower); 4 pairs: 8-stream dedispersion +11 %.
+    // BBT_COL_PP: bit 0 first pass, bit 1 last pass, bit 2 also groups of 4.
+    static const int col_pp = [] { const char* e = getenv("BBT_COL_PP"); return e ? atoi(e) : 6; }();
+    if ((FIRST && (col_pp & 1)) || (!FIRST && (col_pp & 2))) {
+        if (p->npair % 8 == 0) {
+            hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 8>),
+                               dim3(row_len / 2 * (p->npair / 8), ch.nblk), dim3(256), 0, st, in, out,
+                               work, ch, p->S, row_len, p->tab1.tw0, so);
+            return;
+        }
+        if (p->npair % 4 == 0 && (col_pp & 4)) {
+            hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 4>),
+                               dim3(row_len / 4 * (p->npair / 4), ch.nblk), dim3(256), 0, st, in, out,
+                               work, ch, p->S, row_len, p->tab1.tw0, so);
+            return;
+        }
+    }
     if (col_tile() == 32 && row_len % 32 == 0)
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
                            dim3(512), 0, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);

@@ -369,7 +369,11 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
 // Column pass, N1 == 256: FCOL two-stream columns (f, fastest lane index ->
 // FCOL * 16-byte runs per row: 256 B for 16, 512 B for 32) x 16 threads per
 // 256-point transform; FCOL * 16 threads per workgroup.
-template <bool FIRST, bool SPEC, int FCOL, bool DET = false>
+// With many streams the FCOL lanes of a row can instead cover PP pairs x
+// FCOL / PP columns (PP > 1): the stream side then moves PP * 16 contiguous
+// bytes per complete sample (a whole 128-byte line for 8 pairs) at the price
+// of FCOL / PP * 16-byte runs on the work-buffer side.
+template <bool FIRST, bool SPEC, int FCOL, bool DET = false, int PP = 1>
 __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restrict__ in,
                                                           float2* __restrict__ out,
                                                           float2* __restrict__ work, OsmChunk ch,
@@ -377,11 +381,14 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                                                           SpecOut so) {
     typedef FftGeo<256> G;
     __shared__ v2 lds[G::LDS_ELEMS * FCOL];
+    static_assert(!DET || PP == 1, "fused detection needs the lanes of a row in one stream pair");
     const int f = threadIdx.x % FCOL, tau = threadIdx.x / FCOL;
     const int npair = S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int n2 = (vb / npair) * FCOL + f;
-    const int b = blockIdx.y, sp = vb % npair;
+    constexpr int CPT = FCOL / PP;                       // columns per tile
+    const int npg = npair / PP;                          // pair groups
+    const int n2 = (vb / npg) * CPT + f / PP;
+    const int b = blockIdx.y, sp = (vb % npg) * PP + f % PP;
     const OsmBlock blk = ch.b[b];
     // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*256 + k1)*N2 + n2
     float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;

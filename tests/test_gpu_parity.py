@@ -828,3 +828,28 @@ def test_single_kernel_blocks_with_many_streams(n_fft, monkeypatch):
         want, _ = orc.convolve(nh.read(), resp.reshape(-1, 1, 1), samples_per_frame=n_fft - 19,
                                ih_samples_per_frame=n_fft, fast_len=HipFFTMaker.next_fast_len)
         assert_parity(cv.read(), want, f'n_fft={n_fft} streams {shape}')
+
+
+def test_sixteen_streams_through_the_column_passes():
+    """Eight stream pairs: the 256-point column passes put the lanes of a row
+    over the pairs (whole cache lines of each complete sample); plain,
+    channelized and detected outputs against the oracle."""
+    n_fft = 2**17
+    freq = (400. + 6.25 * np.arange(8)).reshape(8, 1) * u.MHz
+    nh = noise(3 * n_fft, (8, 2), n_fft, seed=61, fs=6.25 * u.MHz, frequency=freq, sideband=1,
+               polarization=['X', 'Y'])
+    dd = bt.Dedisperse(nh, 3., reference_frequency=freq)
+    x = nh.read()
+    want, info = orc.dedisperse(x, 6.25e6, np.asarray(freq) / 1e6, 1, 3.,
+                                reference_frequency_mhz=np.asarray(freq) / 1e6,
+                                ih_samples_per_frame=n_fft, fast_len=HipFFTMaker.next_fast_len)
+    assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
+    assert dd._get_plan().info()['n1'] == 256
+    assert_parity(dd.read(), want, 'dedisperse 16 streams')
+    ch = bt.Channelize(bt.Dedisperse(nh, 3., reference_frequency=freq), 256, 4)
+    assert ch._fusable_input() is not None
+    z = ch.read()
+    wz = orc.channelize(want[:z.shape[0] * 256], 256)
+    assert_parity(z, wz, 'fused channelizer 16 streams')
+    it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(nh, 3., reference_frequency=freq), 256, 4)), 64)
+    _close(it.read(), orc.integrate(orc.power(wz), 64), rtol=1e-5)
