@@ -233,7 +233,9 @@ def main():
     path_gbps = value * 1e6 / world * ALG_BYTES_PER_SAMPLE / 1e9
     roofline_path = dict(bound='hbm', achieved=round(path_gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                          frac=round(path_gbps / HBM_PEAK_GBPS, 4),
-                         note='whole Dedisperse->Channelize path per GPU: 36.07 B x valid samples / wall time')
+                         input_msamples_per_s=round(value * N_FFT / spf, 1),
+                         note='whole Dedisperse->Channelize path per GPU: 36.07 B x valid samples / wall time; '
+                              'input_msamples_per_s = value / eta, eta = 836100 / 2^20 (all GPUs)')
 
     gather = None
     if args.gather and world > 1:
