@@ -445,11 +445,12 @@ static int col_tile() {
 template <bool FIRST, bool SPEC>
 static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                           const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
+    constexpr size_t lds1 = FftGeo<256>::LDS_ELEMS * sizeof(v2);     // per column of a tile
     if constexpr (SPEC && !FIRST) {
         if (so.det) {
             hipLaunchKernelGGL((k_osm_col256<false, true, 16, true>),
-                               dim3(row_len / 16 * p->npair, ch.nblk), dim3(256), 0, st, in, out, work,
-                               ch, p->S, row_len, p->tab1.tw0, so);
+                               dim3(row_len / 16 * p->npair, ch.nblk), dim3(256), 16 * lds1, st, in, out,
+                               work, ch, p->S, row_len, p->tab1.tw0, so);
             return;
         }
     }
@@ -457,28 +458,52 @@ static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2
     // every store instruction writes whole 128-byte lines of the output
     // (config 4's share +8 %; the same on the first pass, i.e. for its reads,
     // measured 8 % slower); 4 pairs: 8-stream dedispersion +11 %.
-    // BBT_COL_PP: bit 0 first pass, bit 1 last pass, bit 2 also groups of 4.
-    static const int col_pp = [] { const char* e = getenv("BBT_COL_PP"); return e ? atoi(e) : 6; }();
+    // BBT_COL_PP: bit 0 first pass, bit 1 last pass, bit 2 also groups of 4,
+    // bit 3 first pass with 64-lane rows (4 pairs x 16 columns, 1024 threads:
+    // 1 KiB runs of input and 256-byte runs of work; 16 streams +3 %, 8 streams
+    // -5 %, hence only from 8 pairs on).
+    static const int col_pp = [] { const char* e = getenv("BBT_COL_PP"); return e ? atoi(e) : 14; }();
+    if constexpr (FIRST) {
+        if ((col_pp & 8) && p->npair % 4 == 0 && p->npair >= 8) {
+            static bool prepared = false;
+            if (!prepared) {
+                (void)hipFuncSetAttribute((const void*)k_osm_col256<true, SPEC, 64, false, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * lds1));
+                prepared = true;
+            }
+            hipLaunchKernelGGL((k_osm_col256<true, SPEC, 64, false, 4>),
+                               dim3(row_len / 16 * (p->npair / 4), ch.nblk), dim3(1024), 64 * lds1, st, in,
+                               out, work, ch, p->S, row_len, p->tab1.tw0, so);
+            return;
+        }
+    }
     if ((FIRST && (col_pp & 1)) || (!FIRST && (col_pp & 2))) {
         if (p->npair % 8 == 0) {
             hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 8>),
-                               dim3(row_len / 2 * (p->npair / 8), ch.nblk), dim3(256), 0, st, in, out,
-                               work, ch, p->S, row_len, p->tab1.tw0, so);
+                               dim3(row_len / 2 * (p->npair / 8), ch.nblk), dim3(256), 16 * lds1, st, in,
+                               out, work, ch, p->S, row_len, p->tab1.tw0, so);
             return;
         }
         if (p->npair % 4 == 0 && (col_pp & 4)) {
             hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 4>),
-                               dim3(row_len / 4 * (p->npair / 4), ch.nblk), dim3(256), 0, st, in, out,
-                               work, ch, p->S, row_len, p->tab1.tw0, so);
+                               dim3(row_len / 4 * (p->npair / 4), ch.nblk), dim3(256), 16 * lds1, st, in,
+                               out, work, ch, p->S, row_len, p->tab1.tw0, so);
             return;
         }
     }
-    if (col_tile() == 32 && row_len % 32 == 0)
+    if (col_tile() == 32 && row_len % 32 == 0) {
+        static bool prepared = false;
+        if (!prepared) {
+            (void)hipFuncSetAttribute((const void*)k_osm_col256<FIRST, SPEC, 32>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * lds1));
+            prepared = true;
+        }
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
-                           dim3(512), 0, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
-    else
+                           dim3(512), 32 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+    } else {
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
-                           dim3(256), 0, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+                           dim3(256), 16 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+    }
 }
 
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,

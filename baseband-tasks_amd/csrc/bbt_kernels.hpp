@@ -380,7 +380,8 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                                                           int S, int N2, const cf* __restrict__ tw0,
                                                           SpecOut so) {
     typedef FftGeo<256> G;
-    __shared__ v2 lds[G::LDS_ELEMS * FCOL];
+    extern __shared__ v2 col256_lds[];                   // G::LDS_ELEMS * FCOL elements
+    v2* lds = col256_lds;
     static_assert(!DET || PP == 1, "fused detection needs the lanes of a row in one stream pair");
     const int f = threadIdx.x % FCOL, tau = threadIdx.x / FCOL;
     const int npair = S >> 1;
@@ -421,7 +422,8 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
             // adds the result to the output once.
             constexpr int NT = FCOL * 16;
             float2* pw = reinterpret_cast<float2*>(lds);            // [256][FCOL]
-            static_assert(256 * FCOL * 8 <= (int)sizeof(lds), "power tile does not fit the exchange buffer");
+            static_assert(256 * FCOL * 8 <= G::LDS_ELEMS * FCOL * (int)sizeof(v2),
+                          "power tile does not fit the exchange buffer");
             const int step = so.det_step, mode = so.det_mode;
             const int spr = N2 >> so.lg_chan;                        // spectra per row step
             const int lg_spr = __ffs(spr) - 1;
