@@ -580,7 +580,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
     if (p->timing) {
         HIP_TRY(hipEventRecord(e[3], st));
         for (int i = 0; i < 4; ++i) p->ev.push_back(e[i]);
-        if (p->ev.size() >= 4096) return osm_flush_timing(p);
+        if (p->ev.size() >= 65536) return osm_flush_timing(p);   // (a flush waits for the events)
     }
     return 0;
 }
