@@ -52,6 +52,7 @@ class Convolve(SpectralMultiplyTask):
     FIR_MAX_TAPS = 160
     FIR_MAX_TAPS_COMPLEX = 80
     _fir = None
+    _fir_paired = False
 
     def _time_response(self):
         """Response in the time domain, ``(n_tap,) + b`` with ``b`` broadcastable
@@ -68,9 +69,15 @@ class Convolve(SpectralMultiplyTask):
             else:
                 full = np.broadcast_to(resp, resp.shape[:1] + tuple(self.sample_shape))
                 full = full.reshape(resp.shape[0], self._n_stream).astype(np.complex64)
-                if self._n_stream_even != self._n_stream:
+                # two real streams with the same (real) taps are one complex stream
+                s = self._n_stream
+                self._fir_paired = bool(self._real and self.PAIR_REAL_STREAMS and s % 2 == 0
+                                        and np.array_equal(full[:, 0::2], full[:, 1::2]))
+                if self._fir_paired:
+                    full = full[:, 0::2]
+                if full.shape[1] % 2:
                     full = np.concatenate([full, np.zeros_like(full[:, :1])], axis=1)
-                self._fir = hip.FirPlan(full)
+                self._fir = hip.FirPlan(np.ascontiguousarray(full))
         return self._fir is not False
 
     def _compute_frames(self, first, last, out):
@@ -79,10 +86,15 @@ class Convolve(SpectralMultiplyTask):
         start, stop = self._frame_span(first, last)
         n_out, pad = stop - start, self._pad_start + self._pad_end
         x = fetch_device(self.ih, start, n_out + pad)
-        s, se = self._n_stream, self._n_stream_even
-        if self._real:
+        s, final = self._n_stream, None
+        if self._real and self._fir_paired:
+            s //= 2                    # (n, S) float32 == (n, S/2) complex64, byte for byte
+            x = hip.DeviceArray((n_out + pad, s), np.complex64, ptr=x.ptr, owner=x)
+            out = hip.DeviceArray((n_out, s), np.complex64, ptr=out.ptr, owner=out)
+        elif self._real:
             x = hip.real_to_complex(x.reshape(n_out + pad, s))
             final, out = out, hip.DeviceArray((n_out, s), np.complex64)
+        se = s + s % 2
         if se != s:
             x = hip.pad_streams_to_even(x, s)
             target = hip.DeviceArray((n_out, se), np.complex64)
@@ -91,7 +103,7 @@ class Convolve(SpectralMultiplyTask):
         self._fir.execute(x, target, n_out)
         if se != s:
             hip.strip_stream_pad(target, n_out, s, out)
-        if self._real:
+        if final is not None:
             hip.real_part(out, final)
 
     def close(self):

@@ -37,9 +37,13 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
             raise TypeError("the accelerated path handles complex64 and float32 streams; got "
                             f"{ih.dtype}.")
-        # float32 streams run through the same complex kernels: zero imaginary
-        # part on the way in, Hermitian response, real part on the way out
-        # (what rfft -> multiply -> irfft computes in the reference).
+        # float32 streams run through the same complex kernels with the
+        # Hermitian-extended response (what rfft -> multiply -> irfft computes
+        # in the reference).  Its impulse response is real, so it acts on real
+        # and imaginary parts separately: two neighbouring real streams that
+        # share a response column ARE one complex stream (a reinterpretation of
+        # the same bytes, no copies, half the transforms).  Streams that cannot
+        # be paired get a zero imaginary part in and drop it on the way out.
         self._real = np.dtype(ih.dtype).kind == 'f'
         self._FFT = fft_maker.get()
         super().__init__(ih, pad_start=pad_start, pad_end=pad_end,
@@ -70,12 +74,56 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             index = np.concatenate([index, index[-1:]])
         return columns, index
 
+    #: Run pairs of real streams as single complex streams when they share a response.
+    PAIR_REAL_STREAMS = True
+    _paired = None
+
+    def _plan_layout(self):
+        """(response columns, column index per stream the plan sees, number of
+        those streams incl. the pad to even).  For float32 streams 2k, 2k+1
+        with the same response the plan sees S/2 complex streams."""
+        columns, index = self._response_columns()
+        s = self._n_stream
+        self._paired = bool(self._real and self.PAIR_REAL_STREAMS and s % 2 == 0
+                            and np.array_equal(index[0:s:2], index[1:s:2]))
+        if self._paired:
+            index = index[0:s:2]
+            if index.shape[0] % 2:
+                index = np.concatenate([index, index[-1:]])
+        return columns, np.ascontiguousarray(index, dtype=np.int32), index.shape[0]
+
     def _get_plan(self):
         if self._plan is None:
-            columns, index = self._response_columns()
-            self._plan = hip.OsmPlan(self._ih_samples_per_frame, self._n_stream_even,
-                                     columns, index)
+            columns, index, n_plan = self._plan_layout()
+            self._plan = hip.OsmPlan(self._ih_samples_per_frame, n_plan, columns, index)
         return self._plan
+
+    def _run_plan(self, x, out, n_in, n_out, *block_args):
+        """plan.execute on (n_in, S) input / (n_out, S) output in this task's
+        dtype, taking care of real streams and odd stream counts."""
+        plan = self._get_plan()
+        s = self._n_stream
+        if self._real and self._paired:
+            # (n, S) float32 == (n, S/2) complex64, byte for byte
+            s //= 2
+            x = hip.DeviceArray((n_in, s), np.complex64, ptr=x.ptr, owner=x)
+            final, out = None, hip.DeviceArray((n_out, s), np.complex64, ptr=out.ptr, owner=out)
+        elif self._real:
+            x = hip.real_to_complex(x.reshape(n_in, s))
+            final, out = out, hip.DeviceArray((n_out, s), np.complex64)
+        else:
+            final = None
+        se = s + s % 2
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+            target = hip.DeviceArray((n_out, se), np.complex64)
+        else:
+            target = out
+        plan.execute(x, target, *block_args)
+        if se != s:
+            hip.strip_stream_pad(target, n_out, s, out)
+        if final is not None:
+            hip.real_part(out, final)
 
     # -- frames ------------------------------------------------------------------
     def _block_descriptors(self, first, last):
@@ -92,26 +140,10 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         return in0, int(starts[-1]) + n - in0, starts, frames * spf, self._keep_from + skips, counts
 
     def _compute_frames(self, first, last, out):
-        plan = self._get_plan()
         in0, in_len, starts, out_abs, keep, counts = self._block_descriptors(first, last)
         x = fetch_device(self.ih, in0, in_len)
         out_off = out_abs - first * self.samples_per_frame
-        s, se = self._n_stream, self._n_stream_even
-        n_out = out.shape[0]
-        if self._real:
-            x = hip.real_to_complex(x.reshape(in_len, s))
-            final, out = out, hip.DeviceArray((n_out, s), np.complex64)
-        if se != s:
-            x = hip.pad_streams_to_even(x, s)
-            padded_out = hip.DeviceArray((n_out, se), np.complex64)
-            target = padded_out
-        else:
-            target = out
-        plan.execute(x, target, starts - in0, out_off, keep, counts)
-        if se != s:
-            hip.strip_stream_pad(padded_out, n_out, s, out)
-        if self._real:
-            hip.real_part(out, final)
+        self._run_plan(x, out, in_len, out.shape[0], starts - in0, out_off, keep, counts)
 
     def close(self):
         super().close()
@@ -123,17 +155,10 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
     def task(self, data):
         """Process one input block given on the host (the reference's hook,
         base.py:699-706).  Runs the same kernels on an uploaded copy."""
-        n = self._ih_samples_per_frame
+        n, spf = self._ih_samples_per_frame, self.samples_per_frame
         assert data.shape == (n,) + tuple(self.sample_shape)
-        data = np.ascontiguousarray(data, dtype=np.complex64)       # real input: zero imaginary part
+        data = np.ascontiguousarray(data, dtype=self.dtype)
         x = hip.DeviceArray.from_host(data.reshape(n, self._n_stream))
-        s, se = self._n_stream, self._n_stream_even
-        if se != s:
-            x = hip.pad_streams_to_even(x, s)
-        spf = self.samples_per_frame
-        y = hip.DeviceArray((spf, se), np.complex64)
-        self._get_plan().execute(x, y, [0], [0], [self._keep_from], [spf])
-        if se != s:
-            y = hip.strip_stream_pad(y, spf, s, hip.DeviceArray((spf, s), np.complex64))
-        y = y.to_host().reshape((spf,) + tuple(self.sample_shape))
-        return np.ascontiguousarray(y.real) if self._real else y
+        y = hip.DeviceArray((spf, self._n_stream), self.dtype)
+        self._run_plan(x, y, n, spf, [0], [0], [self._keep_from], [spf])
+        return y.to_host().reshape((spf,) + tuple(self.sample_shape))

@@ -40,26 +40,28 @@ def share_response(task, torch, dist, device, src=0):
     n = task._ih_samples_per_frame
     rank = dist.get_rank()
     if rank == src:
-        columns, index = task._response_columns()
-        shape = torch.tensor(list(columns.shape), dtype=torch.int64, device=device)
+        columns, index, n_plan = task._plan_layout()
+        shape = torch.tensor(list(columns.shape) + [n_plan, int(bool(task._paired))],
+                             dtype=torch.int64, device=device)
     else:
-        shape = torch.zeros(2, dtype=torch.int64, device=device)
+        shape = torch.zeros(4, dtype=torch.int64, device=device)
     dist.broadcast(shape, src)
-    ncol = int(shape[0].item())
+    ncol, n_plan = int(shape[0].item()), int(shape[2].item())
+    task._paired = bool(shape[3].item())
     assert int(shape[1].item()) == n, "ranks disagree about the block length"
     if rank == src:
         resp = torch.view_as_real(torch.from_numpy(columns)).to(device).contiguous()
         idx = torch.from_numpy(index.astype(np.int32)).to(device)
     else:
         resp = torch.empty((ncol, n, 2), dtype=torch.float32, device=device)
-        idx = torch.empty(task._n_stream_even, dtype=torch.int32, device=device)
+        idx = torch.empty(n_plan, dtype=torch.int32, device=device)
     dist.broadcast(resp, src)
     dist.broadcast(idx, src)
     if device.type == 'cuda':
         dev_resp = hip.DeviceArray((ncol, n), np.complex64, resp.data_ptr(), resp)
         if task._plan is not None:
             task._plan.close()
-        task._plan = hip.OsmPlan(n, task._n_stream_even, dev_resp, idx.cpu().numpy())
+        task._plan = hip.OsmPlan(n, n_plan, dev_resp, idx.cpu().numpy())
     return torch.view_as_complex(resp), idx
 
 

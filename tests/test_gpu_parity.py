@@ -856,3 +856,46 @@ def test_sixteen_streams_through_the_column_passes():
     assert_parity(z, wz, 'fused channelizer 16 streams')
     it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(nh, 3., reference_frequency=freq), 256, 4)), 64)
     _close(it.read(), orc.integrate(orc.power(wz), 64), rtol=1e-5)
+
+
+@pytest.mark.parametrize('sample_shape', [(2,), (4,), (3, 2)])
+def test_real_stream_pairs_run_as_complex_streams(sample_shape, monkeypatch):
+    """Two neighbouring float32 streams with the same response are one
+    complex64 stream to the overlap-save plan (a real impulse response acts on
+    real and imaginary parts separately): same result as the zero-extended
+    route and as the oracle's rfft/irfft restatement."""
+    from baseband_tasks_amd.overlap_save import SpectralMultiplyTask
+    n_fft = 2**14
+    nr = bt.NoiseGenerator((3 * n_fft + 777,) + sample_shape, T0, 1 * u.MHz, n_fft, dtype=np.float32,
+                           seed=71, frequency=300 * u.MHz, sideband=1)
+    x = nr.read()
+    want, info = orc.dedisperse(x, 1e6, 300., 1, 5., ih_samples_per_frame=n_fft,
+                                fast_len=HipFFTMaker.next_fast_len)
+    dd = bt.Dedisperse(nr, 5.)
+    assert dd._ih_samples_per_frame == info['ih_spf']
+    got = dd.read()
+    assert dd._paired and got.dtype == np.float32
+    monkeypatch.setattr(SpectralMultiplyTask, 'PAIR_REAL_STREAMS', False)
+    d1 = bt.Dedisperse(nr, 5.)
+    unpaired = d1.read()
+    assert not d1._paired
+    monkeypatch.undo()
+    rms = np.sqrt(np.mean(want.astype(float) ** 2))
+    for a, what in ((got, 'paired'), (unpaired, 'zero-extended')):
+        assert np.linalg.norm(a - want) / np.linalg.norm(want) <= REL_L2_TOL, what
+        assert np.abs(a - want).max() <= MAX_TOL * rms, what
+    nr.seek(0)
+    blk = nr.read(n_fft)
+    assert np.array_equal(dd.task(blk), got[:dd.samples_per_frame])          # the host-data hook
+    # per-stream frequencies: nothing to pair, still correct
+    if sample_shape == (2,):
+        nq = bt.NoiseGenerator((3 * n_fft,) + sample_shape, T0, 1 * u.MHz, n_fft, dtype=np.float32,
+                               seed=71, frequency=np.array([300., 301.]) * u.MHz, sideband=1)
+        dq = bt.Dedisperse(nq, 5.)
+        yq = dq.read()
+        assert not dq._paired
+        nq.seek(0)
+        wq, _ = orc.dedisperse(nq.read(), 1e6, np.array([300., 301.]), 1, 5., ih_samples_per_frame=n_fft,
+                               fast_len=HipFFTMaker.next_fast_len)
+        assert yq.shape == wq.shape
+        assert np.linalg.norm(yq - wq) / np.linalg.norm(wq) <= REL_L2_TOL
