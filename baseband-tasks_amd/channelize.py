@@ -46,10 +46,36 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
         self._n_stream = n_stream
         self._n_stream_even = n_stream + (n_stream % 2)
 
+    #: Transform two neighbouring real streams as one complex stream a + i b
+    #: (one transform for two: the spectra are separated afterwards).
+    PAIR_REAL_STREAMS = True
+    _pair_plan = None
+
     def _get_plan(self):
         if self._plan is None:
             self._plan = hip.ChanPlan(self._n, self._n_stream_even, self._direction)
         return self._plan
+
+    def _pairs(self):
+        """Number of complex streams when real streams go in pairs, else 0."""
+        return self._n_stream // 2 if (self.PAIR_REAL_STREAMS and self._n_stream % 2 == 0) else 0
+
+    def _run_pairs(self, x, n_spectra, out_flat):
+        """As `_run` for the S/2 complex streams that pairs of real streams form."""
+        p = self._pairs()
+        pe = p + p % 2
+        if self._pair_plan is None:
+            self._pair_plan = self._make_plan(pe)
+        if pe != p:
+            x = hip.pad_streams_to_even(x, p)
+            tmp = hip.DeviceArray((n_spectra * self._n, pe), np.complex64)
+            self._pair_plan.execute(x, tmp, n_spectra)
+            hip.strip_stream_pad(tmp, n_spectra * self._n, p, out_flat)
+        else:
+            self._pair_plan.execute(x, out_flat, n_spectra)
+
+    def _make_plan(self, n_stream_even):
+        return hip.ChanPlan(self._n, n_stream_even, self._direction)
 
     def _run(self, x, n_spectra, out_flat):
         """x: (n_spectra * n, S) -> out_flat: (n_spectra * n, S)."""
@@ -68,6 +94,9 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
         if self._plan is not None:
             self._plan.close()
             self._plan = None
+        if self._pair_plan is not None:
+            self._pair_plan.close()
+            self._pair_plan = None
 
 
 class Channelize(_RowFFTTask):
@@ -141,6 +170,13 @@ class Channelize(_RowFFTTask):
                                                    start, n_spectra)
                 return
         x = fetch_device(self.ih, start * n, n_spectra * n).reshape(n_spectra * n, self._n_stream)
+        if self._real and self._pairs():
+            p = self._pairs()            # (n, S) float32 == (n, S/2) complex64, byte for byte
+            z = hip.DeviceArray((n_spectra * n, p), np.complex64)
+            self._run_pairs(hip.DeviceArray((n_spectra * n, p), np.complex64, ptr=x.ptr, owner=x),
+                            n_spectra, z)
+            hip.split_real_pair_spectra(z, n, self._n_stream, out)
+            return
         if self._real:
             full = hip.DeviceArray((n_spectra * n, self._n_stream), np.complex64)
             self._run(hip.real_to_complex(x), n_spectra, full)
@@ -219,6 +255,12 @@ class Dechannelize(_RowFFTTask):
 
     def _spectra_to_stream(self, x, n_spectra, out):
         n, s = self._n, self._n_stream
+        if self._real and self._pairs():
+            p = self._pairs()
+            z = hip.merge_real_pair_spectra(x, n, s, hip.DeviceArray((n_spectra * n, p), np.complex64))
+            self._run_pairs(z, n_spectra,
+                            hip.DeviceArray((n_spectra * n, p), np.complex64, ptr=out.ptr, owner=out))
+            return
         if self._real:
             full = hip.half_to_full_spectrum(x, n, s).reshape(n_spectra * n, s)
             tmp = hip.DeviceArray((n_spectra * n, s), np.complex64)

@@ -1272,10 +1272,12 @@ extern "C" int bbt_shift_execute(bbt_shift_plan* p, const void* in_dev, void* ou
 extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
                            int n_stream, bbt_stream stream) {
     ARG_TRY(in_dev && out_dev, "bbt_real_op: null argument");
-    ARG_TRY(op >= 0 && op <= 3, "bbt_real_op: op must be 0..3");
+    ARG_TRY(op >= 0 && op <= 5, "bbt_real_op: op must be 0..5");
     ARG_TRY(n_total >= 0, "bbt_real_op: n_total < 0");
     ARG_TRY(op != 2 || (n_chan >= 2 && n_chan % 2 == 0 && n_stream >= 1),
             "bbt_real_op: half-to-full needs an even n_chan and n_stream >= 1");
+    ARG_TRY(op < 4 || (n_chan >= 2 && n_chan % 2 == 0 && n_stream >= 2 && n_stream % 2 == 0),
+            "bbt_real_op: splitting / merging two real streams needs even n_chan and n_stream");
     if (n_total == 0) return 0;
     ARG_TRY((n_total + 255) / 256 < (1ll << 31), "bbt_real_op: too many elements for one call");
     const dim3 grid((unsigned)((n_total + 255) / 256)), block(256);
@@ -1284,7 +1286,9 @@ extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_
         case 0: hipLaunchKernelGGL((k_real_ops<0>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
         case 1: hipLaunchKernelGGL((k_real_ops<1>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
         case 2: hipLaunchKernelGGL((k_real_ops<2>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
-        default: hipLaunchKernelGGL((k_real_ops<3>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        case 3: hipLaunchKernelGGL((k_real_ops<3>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        case 4: hipLaunchKernelGGL((k_real_ops<4>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        default: hipLaunchKernelGGL((k_real_ops<5>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -988,6 +988,35 @@ __global__ __launch_bounds__(256) void k_real_ops(const void* __restrict__ in_,
     } else if (MODE == 3) {
         const float x = ((const float*)in_)[t];
         ((float*)out_)[t] = x * x;
+    } else if (MODE == 4) {
+        // spectra of two real streams from the transform of z = a + i b:
+        // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2i.
+        // in (spectrum, n, s/2) complex, out (spectrum, n/2+1, s); t indexes out
+        const int half = n / 2 + 1, np2 = s >> 1;
+        const int st = (int)(t % s);
+        const long long r = t / s;
+        const int k = (int)(r % half);
+        const long long spec = r / half;
+        const float2* row = (const float2*)in_ + spec * n * np2 + (st >> 1);
+        const float2 zk = row[(long long)k * np2];
+        const float2 zm = row[(long long)((n - k) % n) * np2];
+        ((float2*)out_)[t] = (st & 1) ? make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x))
+                                      : make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    } else if (MODE == 5) {
+        // the inverse: Z[k] = A[k] + i B[k] from the half spectra of two real
+        // streams (irfft conventions: imaginary parts of DC and Nyquist ignored).
+        // in (spectrum, n/2+1, s) complex, out (spectrum, n, s/2); t indexes out
+        const int half = n / 2 + 1, np2 = s >> 1;
+        const int p = (int)(t % np2);
+        const long long r = t / np2;
+        const int k = (int)(r % n);
+        const long long spec = r / n;
+        const int kk = k <= n / 2 ? k : n - k;
+        const float2* src = (const float2*)in_ + (spec * half + kk) * s + 2 * p;
+        float2 a = src[0], b = src[1];
+        if (kk == 0 || 2 * kk == n) a.y = b.y = 0.f;
+        ((float2*)out_)[t] = k <= n / 2 ? make_float2(a.x - b.y, a.y + b.x)
+                                        : make_float2(a.x + b.y, b.x - a.y);
     } else {
         // t indexes out (spectrum, k, stream)
         const int st = (int)(t % s);

@@ -405,6 +405,20 @@ def keep_half_spectrum(z, n_chan, n_stream, out):
     return out
 
 
+def split_real_pair_spectra(z, n_chan, n_stream, out):
+    """Spectra ``(n_spec, n_chan, n_stream/2)`` of complex streams z = a + i b
+    -> half spectra ``(n_spec, n_chan/2+1, n_stream)`` of the real streams."""
+    check(lib().bbt_real_op(z.ptr, out.ptr, 4, out.size, int(n_chan), int(n_stream), _stream))
+    return out
+
+
+def merge_real_pair_spectra(z_half, n_chan, n_stream, out):
+    """Half spectra ``(n_spec, n_chan/2+1, n_stream)`` of real streams ->
+    ``(n_spec, n_chan, n_stream/2)`` spectra of the complex streams a + i b."""
+    check(lib().bbt_real_op(z_half.ptr, out.ptr, 5, out.size, int(n_chan), int(n_stream), _stream))
+    return out
+
+
 def square_real(x, out):
     check(lib().bbt_real_op(x.ptr, out.ptr, 3, out.size, 0, 0, _stream))
     return out

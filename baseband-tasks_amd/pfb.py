@@ -85,6 +85,9 @@ class PolyphaseFilterBank(_RowFFTTask):
             self._plan = hip.PfbPlan(self._response, self._n_stream_even)
         return self._plan
 
+    def _make_plan(self, n_stream_even):
+        return hip.PfbPlan(self._response, n_stream_even)
+
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
         n_spectra = stop - start
@@ -92,6 +95,14 @@ class PolyphaseFilterBank(_RowFFTTask):
         x = fetch_device(self._source, start * n, (n_spectra + n_tap - 1) * n)
         x = x.reshape((n_spectra + n_tap - 1) * n, self._n_stream)
         s, se = self._n_stream, self._n_stream_even
+        if self._real and self._pairs():
+            # the taps are real, so the filter bank too takes two real streams as one complex one
+            p = self._pairs()
+            rows = (n_spectra + n_tap - 1) * n
+            z = hip.DeviceArray((n_spectra * n, p), np.complex64)
+            self._run_pairs(hip.DeviceArray((rows, p), np.complex64, ptr=x.ptr, owner=x), n_spectra, z)
+            hip.split_real_pair_spectra(z, n, s, out)
+            return
         if self._real:
             x = hip.real_to_complex(x)
             final, out = out, hip.DeviceArray((n_spectra * n, s), np.complex64)

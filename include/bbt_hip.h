@@ -218,7 +218,13 @@ int bbt_shift_execute(bbt_shift_plan* plan, const void* in_dev, void* out_dev, i
  *   op 2  half spectrum (n_total/(n_chan*n_stream) spectra of n_chan/2+1
  *         channels, n_stream streams innermost) -> Hermitian full spectrum of
  *         n_chan channels as irfft interprets it
- *   op 3  x -> x*x */
+ *   op 3  x -> x*x
+ *   op 4  transform of z = a + i b (n_total/((n_chan/2+1)*n_stream) spectra of
+ *         n_chan channels, n_stream/2 complex streams) -> the half spectra of the
+ *         n_stream real streams a, b, ... (n_chan/2+1 channels): two real
+ *         transforms for the price of one complex one
+ *   op 5  its inverse: half spectra of n_stream real streams -> the n_chan-channel
+ *         spectra of n_stream/2 complex streams z = a + i b (n_total counts those) */
 int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
                 int n_stream, bbt_stream stream);
 

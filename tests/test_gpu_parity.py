@@ -899,3 +899,34 @@ def test_real_stream_pairs_run_as_complex_streams(sample_shape, monkeypatch):
                                fast_len=HipFFTMaker.next_fast_len)
         assert yq.shape == wq.shape
         assert np.linalg.norm(yq - wq) / np.linalg.norm(wq) <= REL_L2_TOL
+
+
+def test_real_stream_pairs_through_channelizer_and_filter_bank(monkeypatch):
+    """Channelize / Dechannelize / PolyphaseFilterBank transform two real
+    streams as one complex stream a + i b and separate the spectra afterwards;
+    same results as one zero-extended transform per stream and as the oracle."""
+    import baseband_tasks_amd.channelize as chz
+    for shape in ((2,), (6,), (2, 2)):
+        nr = bt.NoiseGenerator((40 * 256,) + shape, T0, 1 * u.MHz, 2560, dtype=np.float32, seed=81,
+                               frequency=300 * u.MHz, sideband=1)
+        x = nr.read()
+        results = {}
+        for pair in (True, False):
+            monkeypatch.setattr(chz._RowFFTTask, 'PAIR_REAL_STREAMS', pair)
+            ch = bt.Channelize(nr, 256, samples_per_frame=4)
+            assert bool(ch._pairs()) == pair
+            z = ch.read()
+            ch.seek(0)
+            back = bt.Dechannelize(ch, n=256, dtype=np.float32).read()
+            pf = bt.PolyphaseFilterBank(nr, bt.sinc_hamming(4, 256), samples_per_frame=8).read()
+            results[pair] = (z, back, pf)
+        monkeypatch.undo()
+        z, back, pf = results[True]
+        want = orc.channelize(x[:z.shape[0] * 256], 256)
+        assert z.shape == want.shape == (40, 129) + shape
+        assert_parity(z, want, f'real channelize {shape}')
+        assert np.abs(back - x[:back.shape[0]]).max() < 1e-5
+        for a, b, what in zip(results[True], results[False], ('channelize', 'dechannelize', 'pfb')):
+            assert a.shape == b.shape and a.dtype == b.dtype
+            scale = np.sqrt(np.mean(np.abs(b) ** 2))
+            assert np.abs(a - b).max() <= MAX_TOL * scale, (what, shape)
