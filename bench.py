@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--blocks', type=int, default=192, help='overlap-save blocks per step per GPU')
+    ap.add_argument('--blocks', type=int, default=768, help='overlap-save blocks per step per GPU')
     ap.add_argument('--cpu-blocks', type=int, default=40, help='blocks per process for the CPU baseline (x1/2)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
