@@ -41,12 +41,16 @@ class HipFFT:
     def __init__(self, time_shape, axis, direction, ortho, sample_rate):
         self.time_shape = self.frequency_shape = tuple(time_shape)
         self.time_dtype = self.frequency_dtype = np.dtype(np.complex64)
+        axis = operator.index(axis)
+        if not -len(self.time_shape) <= axis < len(self.time_shape):
+            raise ValueError(f"axis {axis} is out of bounds for shape {self.time_shape}.")
+        axis %= len(self.time_shape)
         self.axis, self.ortho, self.sample_rate = axis, bool(ortho), sample_rate
         self.direction = 'backward' if direction == 'backward' else 'forward'
         n = self.time_shape[axis]
-        if n < MIN_FFT_LEN or n > MAX_WG_FFT_LEN or n & (n - 1):
+        if n < 2 or n > MAX_WG_FFT_LEN or n & (n - 1):
             raise ValueError("the hip engine transforms power-of-two lengths "
-                             f"{MIN_FFT_LEN}..{MAX_WG_FFT_LEN} along an axis (got {n}).")
+                             f"2..{MAX_WG_FFT_LEN} along an axis (got {n}).")
         self._plan = None
 
     @property

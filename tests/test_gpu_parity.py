@@ -624,6 +624,14 @@ def test_fft_engine_seam():
     b = a[0, :, 0].copy().reshape(512)
     f1 = bt.fft_maker((512,), 'complex64')(b)
     assert rel_l2(f1, np.fft.fft(b.astype(np.complex128))) < REL_L2_TOL
+    # short transforms along the last axis, orthonormal scaling, backward direction
+    c = a[:, :64, :].transpose(0, 2, 1).copy()
+    fo = bt.fft_maker(c.shape, 'complex64', axis=-1, ortho=True)
+    assert rel_l2(fo(c), np.fft.fft(c.astype(np.complex128), axis=-1, norm='ortho')) < REL_L2_TOL
+    fb = bt.fft_maker(c.shape, 'complex64', direction='backward', axis=2)
+    assert rel_l2(fb(c), np.fft.ifft(c.astype(np.complex128), axis=2)) < REL_L2_TOL
+    with pytest.raises(ValueError):
+        bt.fft_maker((100,), 'complex64')
 
 
 # --------------------------------------------------------------------------- BASELINE sizes: size-independent properties
