@@ -14,6 +14,7 @@ removed in numpy >= 1.23; they are defined below before importing astropy.
 Only inputs/outputs (data) are written; no reference source is copied.
 """
 import hashlib
+import os
 
 import numpy as np
 
@@ -173,6 +174,12 @@ def main():
     resp = sinc_hamming(12, 1024)
     out['sh_12_1024_stats'] = np.array([resp.sum(), resp.max(), resp[0, 0], resp[5, 17], resp[11, 1023]])
     out['sh_guppi'] = sinc_hamming(12, 64, sinc_scale=0.95)
+    # the known-answer table the reference's own test holds (tests/test_pfb.py:26-35): GUPPI's
+    # 12-tap, 64-channel coefficients, arranged as that test arranges them
+    import baseband_tasks.tests as _ref_tests
+    a = np.loadtxt(os.path.join(os.path.dirname(_ref_tests.__file__), 'data',
+                                'bGDSP_U1_0032_T12_W095_get_pfb_coeffs.txt'))
+    out['sh_guppi_table'] = a.reshape(8, -1).T.reshape(12, 64)
     out['sh_chime_stats'] = np.array([sinc_hamming(4, 2048).sum(), sinc_hamming(4, 2048)[1, 5]])
     nh = noise((2 * 2**20, 2), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)
     pfb = PolyphaseFilterBank(nh, resp)

@@ -141,6 +141,10 @@ def test_sinc_hamming(golden):
     np.testing.assert_allclose(orc.sinc_hamming(12, 64, 0.95), golden['sh_guppi'], rtol=1e-14, atol=1e-17)
     # SURVEY 8(a) a11 known answers
     assert abs(r.sum() - 1021.688) < 1e-3 and abs(r.max() - 0.99999998) < 1e-8
+    # the GUPPI coefficient table of the reference's own test (tests/test_pfb.py:26-35), same tolerance
+    np.testing.assert_allclose(orc.sinc_hamming(12, 64, 0.95), golden['sh_guppi_table'])
+    import baseband_tasks_amd as bt
+    np.testing.assert_allclose(bt.sinc_hamming(12, 64, sinc_scale=0.95), golden['sh_guppi_table'])
 
 
 def test_config3_pfb(golden):
