@@ -938,3 +938,62 @@ def test_real_stream_pairs_through_channelizer_and_filter_bank(monkeypatch):
             assert a.shape == b.shape and a.dtype == b.dtype
             scale = np.sqrt(np.mean(np.abs(b) ** 2))
             assert np.abs(a - b).max() <= MAX_TOL * scale, (what, shape)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.complex64])
+def test_resampled_tones_match_the_finer_grid(dtype):
+    """Analytic check in the spirit of the reference's TestResampleReal /
+    TestResampleComplex (tests/test_sampling.py:77-261): two tones sampled at a
+    quarter of the rate, resampled onto quarter-sample offsets with a 65-tap
+    windowed sinc, reproduce the fully sampled signal to 7e-4 (the
+    reference's tolerance), for Resample and for per-stream ShiftAndResample."""
+    full_rate, n_full, pad = 1e3, 3 * 4096, 32
+    f_tone = full_rate * 2 / 4096 * np.array([31.092, 65.1234])          # Hz, one per stream
+
+    def tones(fh):
+        t = (fh.tell() + np.arange(fh.samples_per_frame)) / fh.sample_rate
+        phi = np.pi / 180. * np.pi + 2. * np.pi * f_tone * t[:, np.newaxis]
+        return (np.cos(phi) if np.dtype(dtype).kind == 'f' else np.exp(1j * phi)).astype(dtype)
+
+    def stream(rate, n, spf):
+        return bt.StreamGenerator(tones, (n, 2), T0, rate, samples_per_frame=spf, dtype=dtype,
+                                  frequency=400e3, sideband=np.array([-1, 1]))
+
+    full = stream(full_rate, n_full, 4096).read()
+    part_fh = stream(full_rate / 4, n_full // 4, 1024)
+    assert np.allclose(part_fh.read(), full[::4], atol=1e-6)
+    for offset in (34, 34.5, 35.75):
+        ih = bt.Resample(part_fh, offset, pad=pad)
+        assert ih.shape[0] == part_fh.shape[0] - 2 * pad and ih.tell() + pad == round(offset)
+        ih.seek(0)
+        data = ih.read()
+        first = (ih.start_time - part_fh.start_time) * full_rate            # in full-rate samples
+        assert abs(first - round(first)) < 1e-6
+        expected = full[int(round(first))::4][:data.shape[0]]
+        assert data.dtype == dtype and np.abs(data - expected).max() < 7e-4
+    shift = np.array([1.75, 10.25])
+    ih = bt.ShiftAndResample(part_fh, shift, offset=0.25, pad=pad)
+    data = ih.read()
+    for i, s in enumerate(shift):
+        first = ((ih.start_time - part_fh.start_time) * full_rate / 4 - s) * 4
+        assert abs(first - round(first)) < 1e-6 and first >= 0
+        expected = full[int(round(first))::4, i][:data.shape[0]]
+        assert np.abs(data[:, i] - expected).max() < 7e-4
+
+
+def test_convolve_equals_numpy_convolve():
+    """Independent of the oracle (which, like the reference, goes through FFTs):
+    Convolve keeps the 'valid' part of the linear convolution, shifted by
+    ``offset`` (reference tests/test_convolution.py:42-98 compare the same way)."""
+    rng = np.random.default_rng(12)
+    nh = noise(6000, (2,), 1000, seed=91, fs=1 * u.kHz)
+    x = nh.read().astype(np.complex128)
+    for n_tap, offset in ((3, 0), (3, 1), (40, 7), (300, 0)):
+        resp = rng.standard_normal(n_tap)
+        cv = bt.Convolve(nh, resp, offset=offset)
+        got = cv.read()
+        want = np.stack([np.convolve(x[:, k], resp, mode='valid') for k in range(2)], axis=1)
+        assert got.shape == want.shape
+        assert_parity(got, want.astype(np.complex64), f'{n_tap} taps')
+        # the result is attributed to input sample pad_start = n_tap - 1 - offset
+        assert abs((cv.start_time - nh.start_time) * 1e3 - (n_tap - 1 - offset)) < 1e-9
