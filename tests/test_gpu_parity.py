@@ -997,3 +997,23 @@ def test_convolve_equals_numpy_convolve():
         assert_parity(got, want.astype(np.complex64), f'{n_tap} taps')
         # the result is attributed to input sample pad_start = n_tap - 1 - offset
         assert abs((cv.start_time - nh.start_time) * 1e3 - (n_tap - 1 - offset)) < 1e-9
+
+
+def test_three_level_blocks_with_sixteen_streams():
+    """2^21-sample blocks (three-level transform) x 16 streams: plain and
+    fused-channelizer outputs, pair-grouped column passes."""
+    n_fft = 2**21
+    freq = (400. + 6.25 * np.arange(8)).reshape(8, 1) * u.MHz
+    nh = noise(n_fft + 300000, (8, 2), 2**19, seed=63, fs=6.25 * u.MHz, frequency=freq, sideband=1)
+    x = nh.read()
+    dm = 60.
+    want, info = orc.dedisperse(x, 6.25e6, np.asarray(freq) / 1e6, 1, dm,
+                                reference_frequency_mhz=np.asarray(freq) / 1e6,
+                                ih_samples_per_frame=2**19, fast_len=HipFFTMaker.next_fast_len)
+    dd = bt.Dedisperse(nh, dm, reference_frequency=freq)
+    assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
+    assert_parity(dd.read(), want, 'three-level dedisperse, 16 streams')
+    ch = bt.Channelize(bt.Dedisperse(nh, dm, reference_frequency=freq), 256, 8)
+    assert ch._fusable_input() is not None
+    z = ch.read()
+    assert_parity(z, orc.channelize(want[:z.shape[0] * 256], 256), 'three-level fused channelizer, 16 streams')
