@@ -116,11 +116,34 @@ static int get_wroot(cf** out) {
 
 static bool fft_len_ok(int64_t n) { return is_pow2(n) && n >= 256 && n <= 4096; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a
+// kernel: set it once per (device, kernel) and check the result.
+static int ensure_dyn_lds(const void* func, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find({dev, func});
+    if (it != done.end() && it->second >= bytes) return 0;
+    HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[{dev, func}] = bytes;
+    return 0;
+}
+
 struct DevicePool {
     std::mutex mu;
-    std::map<int, std::multimap<size_t, void*>> free_blocks;        // device -> size -> block
+    struct Idle {
+        void* ptr;
+        hipStream_t freed_on;   // pool stream when the block was freed
+    };
+    std::map<int, std::multimap<size_t, Idle>> free_blocks;         // device -> size -> block
     std::map<void*, std::pair<size_t, int>> live;                   // block -> (size, device)
     size_t cached = 0;
+    // The stream on which blocks of the pool are used (bbt_pool_set_stream).
+    // Reuse of a freed block is ordered by that stream; a block freed under
+    // another pool stream is handed out only after the device has drained.
+    hipStream_t stream = nullptr;
     static size_t limit() {                      // cached (idle) bytes kept at most; BBT_POOL_MAX_GB
         static const size_t lim = [] {
             const char* e = getenv("BBT_POOL_MAX_GB");
@@ -185,10 +208,16 @@ int bbt_malloc(void** dev_ptr, size_t nbytes) {
         auto& free_blocks = g_pool.free_blocks[dev];
         auto it = free_blocks.lower_bound(want);
         if (it != free_blocks.end() && it->first - want <= want / 8) {
-            *dev_ptr = it->second;
+            const DevicePool::Idle idle = it->second;
+            *dev_ptr = idle.ptr;
             g_pool.cached -= it->first;
-            g_pool.live[it->second] = {it->first, dev};
+            g_pool.live[idle.ptr] = {it->first, dev};
             free_blocks.erase(it);
+            if (idle.freed_on != g_pool.stream) {
+                // freed under another stream: its last users are not ordered
+                // before work on the current pool stream -- drain the device
+                HIP_TRY(hipDeviceSynchronize());
+            }
             return 0;
         }
     }
@@ -216,7 +245,7 @@ int bbt_free(void* dev_ptr) {
         const int dev = it->second.second;
         g_pool.live.erase(it);
         if (g_pool.enabled() && g_pool.cached + size <= g_pool.limit()) {
-            g_pool.free_blocks[dev].emplace(size, dev_ptr);
+            g_pool.free_blocks[dev].emplace(size, DevicePool::Idle{dev_ptr, g_pool.stream});
             g_pool.cached += size;
             return 0;
         }
@@ -229,12 +258,17 @@ int bbt_pool_trim(void) {
     {
         std::lock_guard<std::mutex> lock(g_pool.mu);
         for (auto& per_dev : g_pool.free_blocks) {
-            for (auto& b : per_dev.second) blocks.push_back(b.second);
+            for (auto& b : per_dev.second) blocks.push_back(b.second.ptr);
             per_dev.second.clear();
         }
         g_pool.cached = 0;
     }
     for (void* b : blocks) HIP_TRY(hipFree(b));
+    return 0;
+}
+int bbt_pool_set_stream(bbt_stream stream) {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    g_pool.stream = (hipStream_t)stream;
     return 0;
 }
 int bbt_pool_info(int64_t* cached_bytes, int64_t* live_bytes) {
@@ -331,6 +365,9 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms) {
 // overlap-save spectral multiply
 #define BBT_MAX_LANES 8
 struct bbt_osm_plan {
+    // One call at a time per plan: the lanes' work buffers, the seam buffer,
+    // the fork/join events and the timing vectors belong to the running call.
+    std::mutex mu;
     int device = 0;
     int64_t n = 0;
     int S = 0, npair = 0, C = 0;
@@ -392,19 +429,14 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
 }
 
 template <int N>
-static void launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
-                         hipStream_t st) {
+static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
+                        hipStream_t st) {
     // lanes over groups of pairs when there are many (see k_osm_small); the
     // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
     constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
     constexpr size_t lds1 = FftGeo<N>::LDS_ELEMS * sizeof(v2);
     if (p->npair % PP == 0) {
-        static bool prepared = false;
-        if (!prepared) {
-            (void)hipFuncSetAttribute((const void*)k_osm_small<N, PP>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds1 * PP));
-            prepared = true;
-        }
+        if (ensure_dyn_lds((const void*)k_osm_small<N, PP>, lds1 * PP)) return 1;
         hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(ch.nblk * (p->npair / PP)), dim3(PP * N / 16),
                            lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0,
                            p->tab2.tw1);
@@ -412,6 +444,7 @@ static void launch_small(bbt_osm_plan* p, const float2* in, float2* out, const O
         hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(ch.nblk * p->npair), dim3(N / 16), lds1, st, in, out,
                            ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
     }
+    return 0;
 }
 
 static int osm_flush_timing(bbt_osm_plan* p) {
@@ -443,7 +476,7 @@ static int col_tile() {
 }
 
 template <bool FIRST, bool SPEC>
-static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
+static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                           const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
     constexpr size_t lds1 = FftGeo<256>::LDS_ELEMS * sizeof(v2);     // per column of a tile
     if constexpr (SPEC && !FIRST) {
@@ -451,7 +484,7 @@ static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2
             hipLaunchKernelGGL((k_osm_col256<false, true, 16, true>),
                                dim3(row_len / 16 * p->npair, ch.nblk), dim3(256), 16 * lds1, st, in, out,
                                work, ch, p->S, row_len, p->tab1.tw0, so);
-            return;
+            return 0;
         }
     }
     // Many streams: the last pass puts the lanes of a row over 8 (4) pairs, so
@@ -465,16 +498,11 @@ static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2
     static const int col_pp = [] { const char* e = getenv("BBT_COL_PP"); return e ? atoi(e) : 14; }();
     if constexpr (FIRST) {
         if ((col_pp & 8) && p->npair % 4 == 0 && p->npair >= 8) {
-            static bool prepared = false;
-            if (!prepared) {
-                (void)hipFuncSetAttribute((const void*)k_osm_col256<true, SPEC, 64, false, 4>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * lds1));
-                prepared = true;
-            }
+            if (ensure_dyn_lds((const void*)k_osm_col256<true, SPEC, 64, false, 4>, 64 * lds1)) return 1;
             hipLaunchKernelGGL((k_osm_col256<true, SPEC, 64, false, 4>),
                                dim3(row_len / 16 * (p->npair / 4), ch.nblk), dim3(1024), 64 * lds1, st, in,
                                out, work, ch, p->S, row_len, p->tab1.tw0, so);
-            return;
+            return 0;
         }
     }
     if ((FIRST && (col_pp & 1)) || (!FIRST && (col_pp & 2))) {
@@ -482,28 +510,24 @@ static void launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2
             hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 8>),
                                dim3(row_len / 2 * (p->npair / 8), ch.nblk), dim3(256), 16 * lds1, st, in,
                                out, work, ch, p->S, row_len, p->tab1.tw0, so);
-            return;
+            return 0;
         }
         if (p->npair % 4 == 0 && (col_pp & 4)) {
             hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 4>),
                                dim3(row_len / 4 * (p->npair / 4), ch.nblk), dim3(256), 16 * lds1, st, in,
                                out, work, ch, p->S, row_len, p->tab1.tw0, so);
-            return;
+            return 0;
         }
     }
     if (col_tile() == 32 && row_len % 32 == 0) {
-        static bool prepared = false;
-        if (!prepared) {
-            (void)hipFuncSetAttribute((const void*)k_osm_col256<FIRST, SPEC, 32>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * lds1));
-            prepared = true;
-        }
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 32>, 32 * lds1)) return 1;
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
                            dim3(512), 32 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
     } else {
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
                            dim3(256), 16 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
     }
+    return 0;
 }
 
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
@@ -522,14 +546,16 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         HIP_TRY(hipEventRecord(e[0], st));
     }
     if (p->n1 == 1) {
+        int rc = 0;
         switch (p->n2) {
-            case 256: launch_small<256>(p, in, out, ch, st); break;
-            case 512: launch_small<512>(p, in, out, ch, st); break;
-            case 1024: launch_small<1024>(p, in, out, ch, st); break;
-            case 2048: launch_small<2048>(p, in, out, ch, st); break;
-            case 4096: launch_small<4096>(p, in, out, ch, st); break;
+            case 256: rc = launch_small<256>(p, in, out, ch, st); break;
+            case 512: rc = launch_small<512>(p, in, out, ch, st); break;
+            case 1024: rc = launch_small<1024>(p, in, out, ch, st); break;
+            case 2048: rc = launch_small<2048>(p, in, out, ch, st); break;
+            case 4096: rc = launch_small<4096>(p, in, out, ch, st); break;
             default: return fail("osm: unsupported n_fft %lld", (long long)p->n);
         }
+        if (rc) return rc;
         if (p->timing) {
             HIP_TRY(hipEventRecord(e[1], st));
             HIP_TRY(hipEventRecord(e[2], st));
@@ -540,7 +566,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         const int m_len = 16 * p->n2;
         const dim3 gout(m_len / 16 * p->npair, ch.nblk);
         const dim3 gmid(p->n2 / 256, ch.nblk * p->npair * 256);
-        launch_col256<true, false>(p, in, out, work, ch, m_len, so, st);
+        if (launch_col256<true, false>(p, in, out, work, ch, m_len, so, st)) return 1;
         hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                            p->wroot, 0);
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
@@ -548,17 +574,16 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
         hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                            p->wroot, nch ? 1 : 0);
-        if (nch)
-            launch_col256<false, true>(p, in, out, work, ch, m_len, so, st);
-        else
-            launch_col256<false, false>(p, in, out, work, ch, m_len, so, st);
+        if (nch ? launch_col256<false, true>(p, in, out, work, ch, m_len, so, st)
+                : launch_col256<false, false>(p, in, out, work, ch, m_len, so, st))
+            return 1;
     } else {
         const dim3 g16(p->n2 / 256 * p->npair, ch.nblk), g256(p->n2 / 16 * p->npair, ch.nblk);
         if (p->n1 == 16)
             hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
                                p->S, p->n2, so);
-        else
-            launch_col256<true, false>(p, in, out, work, ch, p->n2, so, st);
+        else if (launch_col256<true, false>(p, in, out, work, ch, p->n2, so, st))
+            return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
         if (launch_rowpass(p, work, ch, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
@@ -570,10 +595,9 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
                 hipLaunchKernelGGL((k_osm_col16<false, false>), g16, dim3(256), 0, st, in, out,
                                    work, ch, p->S, p->n2, so);
         } else {
-            if (nch)
-                launch_col256<false, true>(p, in, out, work, ch, p->n2, so, st);
-            else
-                launch_col256<false, false>(p, in, out, work, ch, p->n2, so, st);
+            if (nch ? launch_col256<false, true>(p, in, out, work, ch, p->n2, so, st)
+                    : launch_col256<false, false>(p, in, out, work, ch, p->n2, so, st))
+                return 1;
         }
     }
     HIP_TRY(hipGetLastError());
@@ -700,6 +724,10 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     }
     if (hipMalloc((void**)&p->resp, rbytes) != hipSuccess)
         return bail(fail("bbt_osm_plan_create: hipMalloc(response) failed"));
+    // a device-resident response may still be being written on the caller's
+    // (non-blocking) stream, which the null stream used below does not wait for
+    if (resp_on_device && hipDeviceSynchronize() != hipSuccess)
+        return bail(fail("bbt_osm_plan_create: hipDeviceSynchronize failed"));
     hipLaunchKernelGGL(k_permute_resp, dim3((unsigned)((n_fft + 255) / 256), n_resp), dim3(256), 0, 0,
                        nat, p->resp, p->outer, p->n1, (long long)p->n2, 1.0f / (float)n_fft);
     hipError_t e = hipDeviceSynchronize();
@@ -791,6 +819,7 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
         return 1;
     hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
+    std::lock_guard<std::mutex> lock(p->mu);
     return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
                        [&](OsmBlock& blk, int64_t b) {
                            blk.in_off = in_off[b];
@@ -820,6 +849,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
         ARG_TRY(valid_count[b] >= n_chan, "%s: block %lld keeps %d samples < n_chan", who,
                 (long long)b, valid_count[b]);
     if (n_blocks == 0 || n_spectra == 0) return 0;
+    std::lock_guard<std::mutex> lock(p->mu);
     FftTables tabc;
     if (get_tables(n_chan, &tabc)) return 1;
     // seam slots and jobs
@@ -941,6 +971,7 @@ int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, 
 
 int bbt_osm_timing_enable(bbt_osm_plan* p, int enable) {
     ARG_TRY(p, "bbt_osm_timing_enable: null plan");
+    std::lock_guard<std::mutex> lock(p->mu);
     if (osm_flush_timing(p)) return 1;
     p->timing = enable != 0;
     p->timing_isolated = enable == 2;
@@ -951,6 +982,7 @@ int bbt_osm_timing_enable(bbt_osm_plan* p, int enable) {
 
 int bbt_osm_timing_read(bbt_osm_plan* p, double ms[3], int64_t* launches) {
     ARG_TRY(p && ms, "bbt_osm_timing_read: null argument");
+    std::lock_guard<std::mutex> lock(p->mu);
     if (osm_flush_timing(p)) return 1;
     for (int k = 0; k < 3; ++k) ms[k] = p->acc_ms[k];
     if (launches) *launches = p->launches;

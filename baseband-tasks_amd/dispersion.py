@@ -53,8 +53,9 @@ class Disperse(SpectralMultiplyTask):
         else:
             reference_frequency = u.to_hz(reference_frequency)
         # extreme delays across the band -> padding (dispersion.py:66-74)
-        d_lo = dm.time_delay(f_lo, reference_frequency)
-        d_hi = dm.time_delay(f_hi, reference_frequency)
+        pf_lo, pf_hi, pf_ref = self._padding_band(f_lo, f_hi, reference_frequency, half)
+        d_lo = dm.time_delay(pf_lo, pf_ref)
+        d_hi = dm.time_delay(pf_hi, pf_ref)
         d_max = max(np.max(d_lo), np.max(d_hi))
         d_min = min(np.min(d_lo), np.min(d_hi))
         pad_start = int(np.ceil(d_max * rate))
@@ -81,6 +82,12 @@ class Disperse(SpectralMultiplyTask):
         self._keep_from = self._pad_start
         self._pad_slice = slice(self._pad_start, self._pad_start + self.samples_per_frame)
         self._phase_factor = None
+
+    def _padding_band(self, f_lo, f_hi, reference_frequency, half_rate):
+        """Band edges and reference frequency that set the padding: this
+        stream's own (dispersion.py:66-74).  `sharding.SubbandDedisperse`
+        substitutes those of the whole band a shard was cut from."""
+        return f_lo, f_hi, reference_frequency
 
     @property
     def phase_factor(self):

@@ -13,7 +13,9 @@ __all__ = ['HipError', 'HipLibraryMissing', 'lib', 'available', 'DeviceArray',
            'synchronize', 'Event', 'device_count', 'set_device']
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libbbt_hip.so')
+# BBT_HIP_LIB points at another build of the same library (the sanitizer build
+# of tools/build_sanitize.sh); never at a different implementation.
+LIB_PATH = os.environ.get('BBT_HIP_LIB') or os.path.join(_HERE, 'lib', 'libbbt_hip.so')
 
 
 class HipError(RuntimeError):
@@ -37,6 +39,7 @@ SIGNATURES = {
     'bbt_device_name': [C.c_char_p, _int],
     'bbt_malloc': [_pvp, _sz],
     'bbt_free': [_vp],
+    'bbt_pool_set_stream': [_vp],
     'bbt_pool_trim': [],
     'bbt_pool_info': [C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     'bbt_host_alloc': [_pvp, _sz],
@@ -145,8 +148,12 @@ _stream = None
 
 
 def set_stream(stream):
+    """Queue all further work of this package on ``stream`` (a hipStream_t as
+    int; None / 0 = the default stream).  Also becomes the stream the device
+    memory pool orders the reuse of freed blocks by (include/bbt_hip.h)."""
     global _stream
     _stream = int(stream) if stream else None
+    check(lib().bbt_pool_set_stream(_stream))
 
 
 def get_stream():

@@ -14,7 +14,8 @@ optional gather of the outputs; both go through ``torch.distributed``
 """
 import numpy as np
 
-__all__ = ['frame_range', 'share_response', 'gather_frames', 'SubbandShard', 'gather_subbands']
+__all__ = ['frame_range', 'share_response', 'gather_frames', 'SubbandShard', 'SubbandDedisperse',
+           'gather_subbands']
 
 
 def frame_range(n_frames, rank, world):
@@ -117,6 +118,34 @@ def SubbandShard(ih, rank, world):
 
     return _SubbandShard(ih, shape=(ih.shape[0], hi - lo) + tuple(ih.shape[2:]),
                          **{k: v for k, v in meta.items() if v is not None})
+
+
+def SubbandDedisperse(ih, dm, *, band_frequency, band_reference_frequency=None,
+                      reference_frequency=None, samples_per_frame=None, **kwargs):
+    """`Dedisperse` of a run of sub-bands with the block geometry of the WHOLE
+    band: the padding of a multi-sub-band task is set by its extreme sub-band
+    (reference dispersion.py:66-74 takes the max over all streams), so a rank
+    that holds only some sub-bands must pad as the whole task would for its
+    blocks -- and therefore its output -- to be those of the unsharded task.
+    ``band_frequency`` / ``band_reference_frequency`` are the centre and
+    reference frequencies of every sub-band of the band (Hz or quantities;
+    reference defaults to the mean band centre like the reference's).  The
+    chirp columns are this shard's own."""
+    from . import units as u
+    from .dispersion import Dedisperse
+
+    band = u.to_hz(band_frequency)
+    band_ref = None if band_reference_frequency is None else u.to_hz(band_reference_frequency)
+
+    class _SubbandDedisperse(Dedisperse):
+        def _padding_band(self, f_lo, f_hi, ref, half_rate):
+            lo, hi = band - half_rate, band + half_rate
+            return lo, hi, (np.mean(lo + hi) / 2. if band_ref is None else band_ref)
+
+    if np.dtype(ih.dtype).kind != 'c':
+        raise TypeError("SubbandDedisperse handles complex (baseband) sub-bands")
+    return _SubbandDedisperse(ih, dm, reference_frequency=reference_frequency,
+                              samples_per_frame=samples_per_frame, **kwargs)
 
 
 def gather_subbands(local, torch, dist):

@@ -2,24 +2,45 @@
 """Headline benchmark: Msamples/s through Dedisperse(DM=100) + Channelize(1k
 channels) on a 2-pol complex64 stream resident in HBM (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload headline|config4]
 
-One "step" = one pass of the hot path over one batch: BLOCKS overlap-save
-blocks of 2^20 samples per GPU (16 MHz band at 1000 MHz, DM 100: pad
-104963 + 107513, 836100 valid samples per block), coherently dedispersed and
-channelized to 1024 channels, through the package's task objects
-(Channelize(Dedisperse(DeviceStream))).read_device(), i.e. through the C ABI.
-Frame caches are invalidated every step so all work is redone.
+One "step" = one pass of the hot path over one batch.
 
-For N > 1 the driver launches one process per GPU (torch.distributed, backend
-nccl = RCCL); time blocks are independent, so each rank owns its own batch
-(weak scaling, no data-path collective).  The chirp is computed on rank 0
-and broadcast over RCCL at plan time.
+``--workload headline`` (default; BASELINE.json configs[1] + the metric
+pipeline): BLOCKS overlap-save blocks of 2^20 samples per GPU (16 MHz band at
+1000 MHz, DM 100: pad 104963 + 107513, 836100 valid samples per block),
+coherently dedispersed and channelized to 1024 channels through the package's
+task objects, Channelize(Dedisperse(DeviceStream)).read_device(), i.e. through
+the C ABI.  Time blocks are independent, so each rank owns its own batch (weak
+scaling, no data-path collective); the chirp is computed on rank 0 and
+broadcast at plan time.
+
+``--workload config4`` (BASELINE.json configs[3]): 400-800 MHz as 64 sub-bands
+of 6.25 MHz x 2 pol, DM 557, 2^24-sample blocks, Channelize(64) => 4096
+channels; each rank takes 8 sub-bands (`sharding.SubbandShard`; all 64 at
+--gpus 8), results are concatenated along the sub-band axis with one
+all-gather (`sharding.gather_subbands`).
+
+Both workloads print the rate with outputs left sharded (`value`) and, for
+more than one rank, the rate including the gather (`with_gather`).
+
+Launching.  Under torchrun (WORLD_SIZE set) this process is one rank.  Plain
+``python bench.py --gpus N`` with N > 1 starts the N ranks itself: the parent
+touches neither torch nor the GPU, spawns one child per GPU with
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, relays rank 0's JSON line and exits
+non-zero if any rank fails.  BBT_BENCH_BACKEND=gloo rehearses the multi-rank
+path on a box with fewer GPUs than ranks.
+
+After timing, outside the timed region, the result of the timed call shape is
+compared with the CPU oracle at the first blocks, a mid-batch seam and the last
+blocks (`verified`); the run fails if that check fails.
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,13 +49,26 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBPS = 8000.               # MI355X_MICROARCH.md: 8 TB/s spec
+TOL_REL_L2, TOL_MAX = 1e-6, 1e-5    # SURVEY 8(d) parity tolerance (float32 path vs float64-FFT oracle)
+
+# headline workload (SURVEY 8d config 2 + metric pipeline)
 N_FFT = 1 << 20
 N_CHAN = 1024
 DM = 100.
 FS_HZ = 16e6
 FC_HZ = 1000e6
+PAD_START, PAD_END = 104963, 107513
 ALG_BYTES_PER_SAMPLE = 36.07        # (8/eta + 8) * 2 pol, eta = 836100 / 2^20
-HBM_PEAK_GBPS = 8000.               # MI355X_MICROARCH.md: 8 TB/s spec
+
+# config 4
+C4_NFFT = 1 << 24
+C4_FS_HZ = 6.25e6
+C4_DM = 557.
+C4_PAD = 2756522                    # 1362235 + 1394287
+C4_NCHAN = 64
+C4_NSUB = 64
+C4_ALG_BYTES_PER_ELEM = 8.0 / ((C4_NFFT - C4_PAD) / C4_NFFT) + 8.0     # 17.57 B per c64 element
 
 
 def parse():
@@ -42,30 +76,71 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--blocks', type=int, default=768, help='overlap-save blocks per step per GPU')
-    ap.add_argument('--cpu-blocks', type=int, default=40, help='blocks per process for the CPU baseline (x1/2)')
+    ap.add_argument('--workload', choices=['headline', 'config4'], default='headline')
+    ap.add_argument('--blocks', type=int, default=None,
+                    help='overlap-save blocks per step per GPU (default 768 headline, 3 config4)')
+    ap.add_argument('--subbands-per-rank', type=int, default=8, help='config4: sub-bands per rank')
+    ap.add_argument('--cpu-seconds', type=float, default=20.,
+                    help='target wall time of the all-core CPU baseline')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-verify', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='keep the HIP-event kernel timing out of the timed region (A/B check)')
-    ap.add_argument('--gather', action='store_true', help='also time an all-gather of the outputs')
+    ap.add_argument('--no-gather', action='store_true', help='skip the timed all-gather (N > 1)')
     return ap.parse_args()
 
 
-def _cpu_worker(n_blocks):
+# ---------------------------------------------------------------------------
+# launcher: python bench.py --gpus N  ->  N ranks (no torch, no GPU call here)
+def launch_ranks(args):
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f'bench.py: rank {r} exited with {code}; stopping the others', file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline: the oracle (numpy restatement of the reference path) on the host
+def _cpu_worker(job):
     """Dedisperse -> Channelize(1024) on n_blocks blocks of 2^20 through the
-    oracle, one process; returns (valid samples, seconds)."""
+    oracle, one process; every block is fresh input.  Returns (valid samples,
+    seconds in the loop)."""
+    seed, n_blocks = job
     from oracle import bbt_oracle as orc
     g = orc.disperse_geometry(FS_HZ, FC_HZ / 1e6, 1, -DM)
     spf = N_FFT - g['pad_start'] - g['pad_end']
     h = orc.chirp(N_FFT, FS_HZ, FC_HZ / 1e6, 1, -DM, g['reference_frequency'])
-    rng = np.random.default_rng(1)
-    x = rng.standard_normal((N_FFT, 4), dtype=np.float32).view(np.complex64)
+    rng = np.random.default_rng(seed)
+    # a ring of distinct input blocks (so the FFT input is not one cache-resident array)
+    ring = [rng.standard_normal((N_FFT, 4), dtype=np.float32).view(np.complex64) for _ in range(3)]
     carry = np.empty((0, 2), np.complex64)
-    orc.disperse_block(x, h, g['pad_start'], spf, fft64=False)      # warm-up
+    orc.disperse_block(ring[0], h, g['pad_start'], spf, fft64=False)      # warm-up
     t0 = time.perf_counter()
     n_out = 0
-    for _ in range(n_blocks):
-        y = orc.disperse_block(x, h, g['pad_start'], spf, fft64=False)
+    for b in range(n_blocks):
+        y = orc.disperse_block(ring[b % 3], h, g['pad_start'], spf, fft64=False)
         y = np.concatenate([carry, y])
         k = (y.shape[0] // N_CHAN) * N_CHAN
         z = orc.channelize(y[:k], N_CHAN, fft64=False)
@@ -74,21 +149,52 @@ def _cpu_worker(n_blocks):
     return n_out, time.perf_counter() - t0
 
 
-def cpu_baseline(n_blocks):
-    """The oracle (numpy restatement of the reference path) on the host cores:
-    P independent processes over disjoint runs of blocks, P = the
-    GPU box's CPU share (<= 16).  Also quotes the single-process rate."""
+def usable_cores():
+    """Cores this process may really use: min(os.cpu_count(), affinity mask,
+    cgroup quota)."""
+    total = os.cpu_count() or 1
+    n = total
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, period = f.read().split()
+            if q != 'max':
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, total, quota
+
+
+def cpu_baseline(target_seconds):
+    """P independent processes over disjoint runs of blocks, P =
+    every core this job may use; also the single-process rate."""
     import multiprocessing as mp
-    n1, t1 = _cpu_worker(max(4, n_blocks // 8))
+    n1, t1 = _cpu_worker((1, 4))
     single = n1 / t1 / 1e6
-    procs = max(1, min(os.cpu_count() or 1, 16))
-    per = max(2, n_blocks // 2)
+    procs, total, quota = usable_cores()
+    per_block = t1 / 4
+    # three repeats of `per` blocks per process; all processes run at once, so
+    # a block takes longer than alone (shared memory bandwidth): assume 2x
+    per = max(2, int(target_seconds / 3 / (2 * per_block)))
     ctx = mp.get_context('spawn')
     rates, busy, wall = [], 0.0, 0.0
     with ctx.Pool(procs) as pool:
-        for _ in range(3):                              # three repeats, median (BASELINE.md 3)
+        pool.map(_cpu_worker, [(100 + i, 1) for i in range(procs)])       # start-up + warm-up
+        for rep in range(3):                            # three repeats, median (BASELINE.md 3)
             t0 = time.perf_counter()
-            res = pool.map(_cpu_worker, [per] * procs)
+            res = pool.map(_cpu_worker, [(1000 * rep + i, per) for i in range(procs)], chunksize=1)
             wall = time.perf_counter() - t0
             # rate from the slowest worker's own loop time (excludes interpreter start-up)
             busy = max(r[1] for r in res)
@@ -102,25 +208,125 @@ def cpu_baseline(n_blocks):
                     break
     except OSError:
         pass
-    return dict(value=sorted(rates)[1], unit='Msamples/s', cores=procs, kind='port',
-                sample=f'{procs} processes x {per} blocks of 2^20 x 2 pol through oracle/bbt_oracle.py '
-                       f'(numpy {np.__version__} complex64 FFT) on {os.cpu_count()} x {model}; median of 3 '
-                       f'repeats, last {busy:.1f} s busy / {wall:.1f} s wall; '
-                       f'one process alone: {single:.1f} Msamples/s')
+    return dict(value=round(sorted(rates)[1], 2), unit='Msamples/s', cores=procs, kind='port',
+                single_core=round(single, 2),
+                sample=f'{procs} processes (os.cpu_count()={total}, cgroup quota={quota}) x {per} fresh '
+                       f'blocks of 2^20 x 2 pol each through oracle/bbt_oracle.py (numpy {np.__version__} '
+                       f'complex64 FFT) on {model}; median of 3 repeats, last {busy:.1f} s busy / '
+                       f'{wall:.1f} s wall; one process alone: {single:.1f} Msamples/s')
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------
+def _errors(got, want):
+    got = np.asarray(got, np.complex128).ravel()
+    want = np.asarray(want, np.complex128).ravel()
+    rms = np.sqrt(np.mean(np.abs(want) ** 2))
+    return (np.linalg.norm(got - want) / np.linalg.norm(want), np.abs(got - want).max() / rms)
+
+
+def verify_headline(x, z, n_blocks, n_spec):
+    """Spot-check the spectra of the timed call against the oracle: around the
+    first seam, a mid-batch seam and the last seam (plus the very first and
+    last spectra).  x: torch (n_in, 2) complex64 on the device, z: DeviceArray
+    (n_spec, 1024, 2)."""
+    from oracle import bbt_oracle as orc
+    g = orc.disperse_geometry(FS_HZ, FC_HZ / 1e6, 1, -DM)
+    assert (g['pad_start'], g['pad_end']) == (PAD_START, PAD_END)
+    spf = N_FFT - PAD_START - PAD_END
+    h = orc.chirp(N_FFT, FS_HZ, FC_HZ / 1e6, 1, -DM, g['reference_frequency'])
+    worst = [0.0, 0.0]
+    checked = 0
+    pairs = sorted({0, max(0, n_blocks // 2 - 1), max(0, n_blocks - 2)})
+    for m in pairs:
+        nb = min(2, n_blocks - m)
+        xin = x[m * spf:(m + nb - 1) * spf + N_FFT].cpu().numpy()
+        y = np.concatenate([orc.disperse_block(xin[b * spf:b * spf + N_FFT], h, PAD_START, spf)
+                            for b in range(nb)])
+        base = m * spf                                   # stream sample of y[0]
+        s_lo = -(-base // N_CHAN)
+        s_hi = min((base + nb * spf) // N_CHAN, n_spec)
+        seam = (base + spf) // N_CHAN
+        want_idx = sorted(set(range(s_lo, min(s_lo + 6, s_hi)))
+                          | set(range(max(s_lo, seam - 3), min(seam + 4, s_hi)))
+                          | set(range(max(s_lo, s_hi - 6), s_hi)))
+        for s in want_idx:
+            want = np.fft.fft(y[s * N_CHAN - base:(s + 1) * N_CHAN - base].astype(np.complex128), axis=0)
+            got = z[s:s + 1].to_host()[0]
+            e = _errors(got, want)
+            worst = [max(worst[0], e[0]), max(worst[1], e[1])]
+            checked += 1
+    ok = worst[0] <= TOL_REL_L2 and worst[1] <= TOL_MAX
+    return dict(ok=bool(ok), rel_l2=float(f'{worst[0]:.3e}'), max_over_rms=float(f'{worst[1]:.3e}'),
+                spectra_checked=checked, blocks=[int(m) for m in pairs],
+                what=f'{n_blocks}-block timed call vs oracle/bbt_oracle.py (float64 FFT) at the first, '
+                     f'a mid-batch and the last block seam; tolerance {TOL_REL_L2:g} / {TOL_MAX:g}')
+
+
+def verify_config4(x, z, freq_mhz, n_blocks, n_spec, spf):
+    """config 4: sub-band 0 of this rank (the worst case at rank 0), the first
+    spectra of block 0, the spectra around the first seam, the last spectra."""
+    from oracle import bbt_oracle as orc
+    f0 = float(freq_mhz[0])
+    pad_start = 1362235          # the whole band's padding (its lowest sub-band; SURVEY 8d), all ranks
+    h = orc.chirp(C4_NFFT, C4_FS_HZ, f0, 1, -C4_DM, f0)
+    worst = [0.0, 0.0]
+    checked = 0
+    nb = min(2, n_blocks)
+    xin = x[:(nb - 1) * spf + C4_NFFT, 0].cpu().numpy()         # (n, 2)
+    y = np.concatenate([orc.disperse_block(xin[b * spf:b * spf + C4_NFFT], h.reshape(-1, 1), pad_start, spf)
+                        for b in range(nb)])
+    s_hi = min(nb * spf // C4_NCHAN, n_spec)
+    seam = spf // C4_NCHAN
+    idx = sorted(set(range(0, 8)) | set(range(max(0, seam - 4), min(seam + 5, s_hi))) | set(range(s_hi - 8, s_hi)))
+    for s in idx:
+        want = np.fft.fft(y[s * C4_NCHAN:(s + 1) * C4_NCHAN].astype(np.complex128), axis=0)     # (64, 2)
+        got = z[s:s + 1].to_host()[0][:, 0]                      # (64, nsub, 2) -> sub-band 0
+        e = _errors(got, want)
+        worst = [max(worst[0], e[0]), max(worst[1], e[1])]
+        checked += 1
+    ok = worst[0] <= TOL_REL_L2 and worst[1] <= TOL_MAX
+    return dict(ok=bool(ok), rel_l2=float(f'{worst[0]:.3e}'), max_over_rms=float(f'{worst[1]:.3e}'),
+                spectra_checked=checked,
+                what=f'sub-band {f0} MHz of the {n_blocks}-block timed call vs the oracle at the start, the '
+                     f'first block seam and the end of the first two blocks; tolerance {TOL_REL_L2:g} / {TOL_MAX:g}')
+
+
+# ---------------------------------------------------------------------------
+def dry_run_rank():
+    """BBT_BENCH_DRYRUN=1: exercise only the launch / rendezvous / exit-code
+    plumbing (gloo on the CPU, no GPU, no kernels); used by the CPU tests.
+    BBT_BENCH_DRYRUN_FAIL=<rank> makes that rank fail."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if os.environ.get('BBT_BENCH_DRYRUN_FAIL') == str(rank):
+        sys.exit(7)
+    if world > 1:
+        dist.init_process_group('gloo')
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()))), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_rank(args):
+    if os.environ.get('BBT_BENCH_DRYRUN'):
+        return dry_run_rank()
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('BBT_BENCH_BACKEND', 'nccl')
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # BBT_BENCH_BACKEND=gloo rehearses the multi-rank code path on a box with fewer GPUs than
         # ranks (ranks then share devices; RCCL itself refuses two ranks on one device)
-        backend = os.environ.get('BBT_BENCH_BACKEND', 'nccl')
         dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != 'nccl' else local_rank
         torch.cuda.set_device(dev_index)
         if backend == 'nccl':
@@ -131,31 +337,74 @@ def main():
         dev_index = 0
         torch.cuda.set_device(0)
     dev = torch.device('cuda', dev_index)
+    coll_dev = dev
 
     import baseband_tasks_amd as bt
     from baseband_tasks_amd import sharding
     bt.hip.set_device(dev.index)
     bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    # ---- workload: BLOCKS blocks per rank, pre-staged in HBM (synthetic noise)
-    pad = 104963 + 107513
-    spf = N_FFT - pad
-    n_in = (args.blocks - 1) * spf + N_FFT
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
-    x = torch.randn((n_in, 2, 2), generator=gen, device=dev, dtype=torch.float32)
-    x = torch.view_as_complex(x)                       # (n_in, 2) complex64, unit variance/component
-    ds = bt.DeviceStream(x, '2020-01-01T00:00:00', FS_HZ, samples_per_frame=N_FFT,
-                         frequency=FC_HZ, sideband=1, polarization=['X', 'Y'])
-    dd = bt.Dedisperse(ds, DM)
-    assert (dd._ih_samples_per_frame, dd.samples_per_frame) == (N_FFT, spf)
-    ch = bt.Channelize(dd, N_CHAN, samples_per_frame=512)
-    dd.max_frames_per_call = args.blocks
-    n_spec = (dd.shape[0] // N_CHAN // 512) * 512
-    ch.max_frames_per_call = n_spec // 512 + 1
-    # chirp: rank 0 computes, everyone receives over RCCL (no-op for one rank)
-    sharding.share_response(dd, torch, dist if world > 1 else None, dev)
-    samples_per_step = n_spec * N_CHAN                  # valid output complete samples
+
+    if args.workload == 'headline':
+        blocks = args.blocks or 768
+        spf = N_FFT - PAD_START - PAD_END
+        n_in = (blocks - 1) * spf + N_FFT
+        x = torch.view_as_complex(torch.randn((n_in, 2, 2), generator=gen, device=dev, dtype=torch.float32))
+        ds = bt.DeviceStream(x, '2020-01-01T00:00:00', FS_HZ, samples_per_frame=N_FFT,
+                             frequency=FC_HZ, sideband=1, polarization=['X', 'Y'])
+        dd = bt.Dedisperse(ds, DM)
+        assert (dd._ih_samples_per_frame, dd.samples_per_frame) == (N_FFT, spf)
+        n_chan, ch_spf = N_CHAN, 512
+        # chirp: rank 0 computes, everyone receives it (RCCL broadcast; no-op for one rank)
+        sharding.share_response(dd, torch, dist if world > 1 else None, dev)
+        sharding_note = ('independent time blocks per rank, chirp broadcast over '
+                         f'{"RCCL" if backend == "nccl" else backend}') if world > 1 else 'single GPU'
+        alg_bytes = ALG_BYTES_PER_SAMPLE
+        streams = 2
+        workload = ('configs[1]+metric pipeline: Dedisperse DM=100, 16 MHz BW at 1000 MHz, 2^20-sample '
+                    'overlap-save blocks (836100 valid) -> Channelize(1024), 2-pol complex64, '
+                    'HBM-resident input')
+    else:
+        blocks = args.blocks or 3
+        nsub = args.subbands_per_rank
+        spf = C4_NFFT - C4_PAD
+        n_in = (blocks - 1) * spf + C4_NFFT
+        # this rank's sub-bands of the 64 (rank r: [r * nsub, (r + 1) * nsub) mod 64)
+        k = (rank * nsub + np.arange(nsub)) % C4_NSUB
+        freq = (403.125e6 + 6.25e6 * k).reshape(nsub, 1)
+        x = torch.view_as_complex(torch.randn((n_in, nsub, 2, 2), generator=gen, device=dev,
+                                              dtype=torch.float32))
+        ds = bt.DeviceStream(x, '2020-01-01T00:00:00', C4_FS_HZ, samples_per_frame=C4_NFFT,
+                             frequency=freq, sideband=1)
+        # block geometry (padding) is the whole band's, set by its lowest sub-band, on every rank
+        band = (403.125e6 + 6.25e6 * np.arange(C4_NSUB)).reshape(C4_NSUB, 1)
+        dd = sharding.SubbandDedisperse(ds, C4_DM, band_frequency=band, band_reference_frequency=band,
+                                        reference_frequency=freq, samples_per_frame=spf)
+        assert (dd._ih_samples_per_frame, dd.samples_per_frame, dd._pad_start) == (C4_NFFT, spf, 1362235), \
+            (dd._ih_samples_per_frame, dd.samples_per_frame, dd._pad_start)
+        n_chan, ch_spf = C4_NCHAN, 4096
+        dd._get_plan()                       # every rank evaluates its own chirp columns: nothing to share
+        sharding_note = (f'{nsub} of 64 sub-bands per rank (sharding.SubbandShard layout), own chirp '
+                         'columns per rank, all-gather along the sub-band axis') if world > 1 \
+            else f'single GPU: {nsub} of 64 sub-bands'
+        streams = 2 * nsub
+        alg_bytes = C4_ALG_BYTES_PER_ELEM * streams
+        workload = (f'configs[3] share: {nsub} sub-bands x 2 pol of 6.25 MHz (400-800 MHz band), DM=557 with '
+                    'per-sub-band reference frequency, 2^24-sample blocks (14020694 valid) -> '
+                    'Channelize(64), complex64, HBM-resident input')
+
+    ch = bt.Channelize(dd, n_chan, samples_per_frame=ch_spf)
+    dd.max_frames_per_call = blocks
+    n_spec = (dd.shape[0] // n_chan // ch_spf) * ch_spf
+    ch.max_frames_per_call = n_spec // ch_spf + 1
+    samples_per_step = n_spec * n_chan                  # valid output complete samples
 
     def step():
         dd.invalidate_cache()
@@ -163,14 +412,9 @@ def main():
         ch.seek(0)
         return ch.read_device(n_spec)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # Per-kernel timing of the overlap-save passes: HIP events on the stream
     # each pass is launched on, recorded inside the timed region itself, in the
-    # normal two-lane schedule (what rocprofv3 --kernel-trace sees as well).
+    # normal multi-lane schedule (what rocprofv3 --kernel-trace sees as well).
     plan = dd._get_plan()
     for _ in range(args.warmup):
         step()
@@ -181,12 +425,12 @@ def main():
         plan.timing_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        z = step()
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * samples_per_step * args.steps / elapsed / 1e6
@@ -195,12 +439,26 @@ def main():
         plan.timing_enable(1)
         n_steps_timed = max(3, args.steps // 2)
         for _ in range(n_steps_timed):
-            step()
+            z = step()
         fence()
     ms, launches = plan.timing_read()
-    # the same passes isolated (one lane, nothing else on the GPU), for reference
+    plan.timing_enable(0)
+
+    # ---- the timed call shape, checked against the oracle (outside the timed region)
+    verified = None
+    if not args.no_verify:
+        if args.workload == 'headline':
+            verified = verify_headline(x, z, blocks, n_spec)
+        else:
+            verified = verify_config4(x, z, freq.ravel() / 1e6, blocks, n_spec, spf)
+        flag = torch.tensor([0 if verified['ok'] else 1], device=coll_dev, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        verified['all_ranks_ok'] = bool(int(flag.item()) == 0)
+
+    # ---- the same passes isolated (one lane, nothing else on the GPU), for reference
     plan.timing_enable(2)
-    n_iso = max(3, args.steps // 4)
+    n_iso = max(2, args.steps // 4)
     for _ in range(n_iso):
         step()
     fence()
@@ -209,71 +467,108 @@ def main():
     info = plan.info()
     names = ['osm_col_forward', 'osm_rowpass', 'osm_col_inverse']
     k = int(np.argmax(ms))
-    blocks_per_launch = min(info['chunk_blocks'], args.blocks)
-    # launches may be ragged (last chunk smaller): use total blocks / launches
-    blocks_timed = n_steps_timed * args.blocks
-    avg_ms = ms[k] / launches
-    units_per_launch = blocks_timed / launches * spf
-    achieved = units_per_launch * ALG_BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9
+    blocks_timed = n_steps_timed * blocks
+    avg_ms = ms[k] / max(launches, 1)
+    units_per_launch = blocks_timed / max(launches, 1) * spf      # launches may be ragged
+    achieved = units_per_launch * alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    traffic_note = 'no PMC profile on file for this workload'
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(names[k])
+            tj = json.load(open(tfile))
+            traffic = tj.get(args.workload, tj).get(names[k])
+            traffic_note = ('replayed from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x 2 + '
+                            'WRITE_SIZE per launch, collected in separate passes with the same kernels; '
+                            'not measured in this run), source ' + str(tj.get('source', 'n/a')))
         except Exception:
             traffic = None
     roofline = dict(bound='hbm', kernel=names[k], achieved=round(achieved, 1), peak=HBM_PEAK_GBPS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    traffic_note=traffic_note,
                     avg_launch_ms=round(avg_ms, 5), launches=launches,
+                    blocks_per_launch=round(blocks_timed / max(launches, 1), 3),
+                    alg_bytes_per_unit=round(alg_bytes, 2),
                     pass_ms_per_block={n: round(m / blocks_timed, 6) for n, m in zip(names, ms)},
-                    pass_ms_per_block_isolated={n: round(m / (n_iso * args.blocks), 6)
+                    pass_ms_per_block_isolated={n: round(m / (n_iso * blocks), 6)
                                                 for n, m in zip(names, ms_iso)},
-                    note='launch durations from HIP events inside the timed region, two lanes active '
-                         '(a pass shares the GPU with a pass of the other lane); isolated = one lane')
-    path_gbps = value * 1e6 / world * ALG_BYTES_PER_SAMPLE / 1e9
+                    note='launch durations from HIP events inside the timed region on the stream each '
+                         'pass runs on, all lanes active (a pass shares the GPU with passes of the other '
+                         'lanes); isolated = one lane; achieved = alg_bytes_per_unit x valid samples per '
+                         'launch / avg launch duration of the dominant pass')
+    path_gbps = value * 1e6 / world * alg_bytes / 1e9
     roofline_path = dict(bound='hbm', achieved=round(path_gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                          frac=round(path_gbps / HBM_PEAK_GBPS, 4),
-                         input_msamples_per_s=round(value * N_FFT / spf, 1),
-                         note='whole Dedisperse->Channelize path per GPU: 36.07 B x valid samples / wall time; '
-                              'input_msamples_per_s = value / eta, eta = 836100 / 2^20 (all GPUs)')
+                         input_msamples_per_s=round(value * dd._ih_samples_per_frame / spf, 1),
+                         note='whole path per GPU: alg_bytes_per_unit x valid samples / wall time; '
+                              'input_msamples_per_s = value / eta (all GPUs)')
 
-    gather = None
-    if args.gather and world > 1:
-        z = step()
-        zt = torch.as_tensor(z, device=dev)
-        zt = torch.view_as_real(zt)
-        out = torch.empty((world * zt.shape[0],) + tuple(zt.shape[1:]), dtype=zt.dtype, device=dev)
+    # ---- outputs gathered: time steps that end with the collective
+    with_gather = None
+    if world > 1 and not args.no_gather:
+        zt = torch.view_as_real(torch.as_tensor(z, device=dev))
+        n_g = max(2, args.steps // 4)
+
+        def gathered_step():
+            zz = step()
+            t_ = torch.view_as_real(torch.as_tensor(zz, device=dev))
+            if backend != 'nccl':
+                t_ = t_.cpu()
+            if args.workload == 'config4':
+                return sharding.gather_subbands(t_, torch, dist)
+            return sharding.gather_frames(t_, torch, dist)
+        gathered_step()
         fence()
         t0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, zt)
+        for _ in range(n_g):
+            g_out = gathered_step()
         fence()
         dt = time.perf_counter() - t0
-        gather = dict(seconds=dt, GBps_per_rank_in=zt.numel() * 4 * (world - 1) / dt / 1e9)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        with_gather = dict(value=round(world * samples_per_step * n_g / dt / 1e6, 1), unit='Msamples/s',
+                           steps=n_g, ms_per_step=round(dt / n_g * 1e3, 4),
+                           gathered_shape=list(g_out.shape),
+                           bytes_received_per_rank_per_step=int(zt.numel() * 4 * (world - 1)),
+                           collective='all_gather_into_tensor over ' + ('RCCL/xGMI' if backend == 'nccl' else backend))
+        del g_out
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.cpu_blocks)
+    if rank == 0 and world == 1 and not args.no_cpu and args.workload == 'headline':
+        cpu = cpu_baseline(args.cpu_seconds)
 
+    failed = bool(verified and not verified['all_ranks_ok'])
     if rank == 0:
         line = dict(
-            metric='Msamples/s through Dedisperse(DM=100)+Channelize(1k ch), 2-pol c64',
+            metric='Msamples/s through Dedisperse(DM=100)+Channelize(1k ch), 2-pol c64'
+            if args.workload == 'headline' else
+            'M complete samples/s (sub-bands x 2 pol per sample) through Dedisperse(DM=557)+Channelize(64)',
             value=round(value, 1), unit='Msamples/s', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
             higher_is_better=True, scaling='weak', vs_baseline=None, dtype='c64',
             data='synthetic',
-            config=dict(workload='configs[1]+metric pipeline: Dedisperse DM=100, 16 MHz BW at 1000 MHz, '
-                                 '2^20-sample overlap-save blocks (836100 valid) -> Channelize(1024), '
-                                 '2-pol complex64, HBM-resident input',
-                        blocks_per_step_per_gpu=args.blocks, n_fft=N_FFT, n_chan=N_CHAN,
+            config=dict(workload=workload, blocks_per_step_per_gpu=blocks,
+                        n_fft=N_FFT if args.workload == 'headline' else C4_NFFT, n_chan=n_chan,
+                        streams_per_gpu=streams,
                         valid_samples_per_step_per_gpu=samples_per_step,
-                        sharding='independent time blocks per rank, chirp broadcast over RCCL'
-                        if world > 1 else 'single GPU'),
-            roofline=roofline, roofline_path=roofline_path, cpu_baseline=cpu)
-        if gather:
-            line['gather'] = gather
-        print(json.dumps(line))
+                        outputs='left sharded on the ranks (value); with_gather includes the all-gather',
+                        sharding=sharding_note),
+            roofline=roofline, roofline_path=roofline_path, cpu_baseline=cpu, verified=verified,
+            with_gather=with_gather)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        print('bench.py: verification against the oracle FAILED', file=sys.stderr)
+        sys.exit(3)
+
+
+def main():
+    args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == '__main__':

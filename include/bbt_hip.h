@@ -56,12 +56,20 @@ int bbt_device_name(char* buf, int buflen);
 /* ---- memory, streams, events (plumbing) -------------------------------- */
 /* Device memory from a caching pool: bbt_free keeps the block for reuse by a
  * later bbt_malloc of about the same size (no hipFree, hence no device
- * synchronisation between consecutive reader calls).  Reuse is ordered by the
- * caller's stream.  Takes the place of the np.empty the reference's
- * Base.read does per call (base.py:416).  BBT_POOL=0 disables caching,
- * BBT_POOL_MAX_GB caps the idle bytes kept (default 96). */
+ * synchronisation between consecutive reader calls).  Takes the place of the
+ * np.empty the reference's Base.read does per call (base.py:416).
+ * RULE: blocks of the pool are used on ONE stream at a time, the "pool
+ * stream" (bbt_pool_set_stream; default NULL = the default stream), from one
+ * thread at a time: bbt_free returns a block at once, without an event, so its
+ * reuse is ordered only by that stream.  A block freed under a different pool
+ * stream is handed out after a hipDeviceSynchronize.  Work on other streams
+ * must be synchronised by the caller before its buffers are freed (plans join
+ * their internal streams before an execute call returns).
+ * BBT_POOL=0 disables caching, BBT_POOL_MAX_GB caps the idle bytes kept
+ * (default 96). */
 int bbt_malloc(void** dev_ptr, size_t nbytes);
 int bbt_free(void* dev_ptr);
+int bbt_pool_set_stream(bbt_stream stream);               /* the stream pool blocks are used on */
 int bbt_pool_trim(void);                                   /* hipFree every idle block */
 int bbt_pool_info(int64_t* cached_bytes, int64_t* live_bytes);
 int bbt_host_alloc(void** host_ptr, size_t nbytes); /* pinned */
@@ -99,6 +107,11 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  *               the inverse transform is applied by the library
  *   resp_on_device  0: `resp` is a host pointer; 1: device pointer
  *   resp_index  S ints: response column used by each stream (NULL = all 0)
+ * A plan runs one execute call at a time (calls on one plan are serialised by
+ * a mutex inside it: its work buffers, seam buffer and events belong to the
+ * running call); bbt_osm_plan_create itself synchronises the device when
+ * `resp` is a device pointer, so a response still being written on another
+ * stream is complete before it is permuted.
  */
 int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_resp,
                         const void* resp, int resp_on_device, const int32_t* resp_index);

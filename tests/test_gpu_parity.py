@@ -674,6 +674,79 @@ def test_full_size_properties():
     assert rel_l2(got, want) < 5e-3
 
 
+def test_many_blocks_in_one_call_match_the_oracle_block_by_block():
+    """The shape of the timed bench call: ONE read_device covering many
+    overlap-save blocks (max_frames_per_call >= 64: many chunk launches
+    alternating the plan's lanes, a ragged last chunk, a seam fix per block
+    boundary).  (a) 70 blocks of 2^17 (two-level 256 x 512, like the headline's
+    256 x 4096): every block and every seam spectrum against the oracle.
+    (b) 70 blocks of 2^20 (the headline geometry itself) in one call: sampled
+    blocks against the oracle, and the whole result bit-identical to the same
+    stream read in calls of at most 6 blocks."""
+    # ---- (a)
+    n, nblk = 2**17, 70
+    nh0 = noise(8 * n, (2,), n, seed=77, fs=2 * u.MHz, frequency=400 * u.MHz, sideband=1)
+    dd0 = bt.Dedisperse(nh0, 30., samples_per_frame=None)
+    pad = dd0._pad_start + dd0._pad_end
+    spf = n - pad
+    assert dd0._ih_samples_per_frame == n and 0 < pad < n // 2
+    length = (nblk - 1) * spf + n + 1000           # + a short re-aligned last block
+    x = orc.noise_stream(77, 0, length, n, (2,))
+    ds = bt.DeviceStream(x, T0, 2 * u.MHz, frequency=400 * u.MHz, sideband=1)
+    dd = bt.Dedisperse(ds, 30., samples_per_frame=spf)
+    assert dd._ih_samples_per_frame == n and dd.shape[0] == nblk * spf + 1000
+    info = dd._get_plan().info()
+    dd.max_frames_per_call = nblk + 1
+    assert (nblk + 1) % info['chunk_blocks'] != 0 and nblk + 1 > 4 * info['chunk_blocks']
+    y = dd.read_device(dd.shape[0]).to_host()
+    want, oinfo = orc.dedisperse(x, 2e6, 400., 1, 30., samples_per_frame=spf, ih_samples_per_frame=n,
+                                 fast_len=HipFFTMaker.next_fast_len)
+    assert oinfo['ih_spf'] == n
+    for m in range(nblk + 1):
+        assert_parity(y[m * spf:(m + 1) * spf], want[m * spf:(m + 1) * spf], f'block {m}')
+    dd.seek(0)
+    ch = bt.Channelize(dd, 512, samples_per_frame=64)
+    assert ch._fusable_input() is dd
+    ch.max_frames_per_call = 10**6
+    nspec = (dd.shape[0] // 512 // 64) * 64
+    z = ch.read_device(nspec).to_host()
+    wantz = orc.channelize(want[:nspec * 512], 512)
+    for m in range(nblk):
+        k = (m + 1) * spf // 512                    # the spectrum straddling seam m | m + 1
+        if k + 1 < nspec:
+            assert_parity(z[k - 1:k + 2], wantz[k - 1:k + 2], f'seam {m}')
+    assert_parity(z, wantz, 'all spectra')
+    del x, y, z, want, wantz, ds, dd, ch
+    # ---- (b)
+    n, spf, nblk = 2**20, 836100, 70
+    length = (nblk - 1) * spf + n
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((2**20, 4), dtype=np.float32).view(np.complex64)
+    reps = -(-length // 2**20)
+    x = np.concatenate([base * np.complex64(np.exp(0.37j * r)) for r in range(reps)])[:length]
+    ds = bt.DeviceStream(x, T0, 16 * u.MHz, frequency=1000 * u.MHz, sideband=1)
+    dd = bt.Dedisperse(ds, 100.)
+    ch = bt.Channelize(dd, 1024, 512)
+    dd.max_frames_per_call = nblk
+    ch.max_frames_per_call = 10**6
+    nspec = (dd.shape[0] // 1024 // 512) * 512
+    z = ch.read_device(nspec).to_host()
+    g = orc.disperse_geometry(16e6, 1000., 1, -100.)
+    h = orc.chirp(n, 16e6, 1000., 1, -100., g['reference_frequency'])
+    for m in (0, 5, 6, 35, nblk - 2):               # 6-block chunks: 5 | 6 is also a chunk (lane) seam
+        yy = np.concatenate([orc.disperse_block(x[b * spf:b * spf + n], h, g['pad_start'], spf)
+                             for b in (m, m + 1)])
+        s0 = -(-m * spf // 1024)
+        s1 = min((m + 2) * spf // 1024, nspec)
+        wantz = orc.channelize(yy[s0 * 1024 - m * spf:s1 * 1024 - m * spf], 1024)
+        assert_parity(z[s0:s1], wantz, f'blocks {m}, {m + 1}')
+    dd2 = bt.Dedisperse(ds, 100.)
+    ch2 = bt.Channelize(dd2, 1024, 512)
+    dd2.max_frames_per_call = 6
+    ch2.max_frames_per_call = 8
+    assert np.array_equal(ch2.read(nspec), z)
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""

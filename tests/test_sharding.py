@@ -94,3 +94,50 @@ def test_share_response_and_gather_gloo(tmp_path):
         assert np.allclose(res['sub_freq'].ravel(), (400. + 6.25 * np.arange(3 * r, 3 * r + 3)) * 1e6)
         assert res['sub_pol'].tolist() == ['X', 'Y']
         assert np.array_equal(res['sub_full'], whole)
+
+
+def test_subband_dedisperse_keeps_the_whole_bands_block_geometry():
+    """Config 4: every rank's shard pads like the unsharded 64-sub-band task
+    (set by the lowest sub-band), whichever sub-bands it holds."""
+    import baseband_tasks_amd as bt
+    band = (403.125e6 + 6.25e6 * np.arange(64)).reshape(64, 1)
+    spf = 2**24 - 2756522
+    whole = bt.EmptyStreamGenerator((2**25, 64, 2), '2020-01-01T00:00:00', 6.25e6, samples_per_frame=2**24,
+                                    frequency=band, sideband=1)
+    ref = bt.Dedisperse(whole, 557., reference_frequency=band, samples_per_frame=spf)
+    assert (ref._pad_start, ref._pad_end, ref._ih_samples_per_frame) == (1362235, 1394287, 2**24)
+    for rank in (0, 3, 7):
+        mine = sharding.SubbandShard(whole, rank, 8)
+        lo, hi = mine.subbands
+        assert (lo, hi) == (8 * rank, 8 * rank + 8)
+        plain = bt.Dedisperse(mine, 557., reference_frequency=band[lo:hi], samples_per_frame=spf)
+        dd = sharding.SubbandDedisperse(mine, 557., band_frequency=band, band_reference_frequency=band,
+                                        reference_frequency=band[lo:hi], samples_per_frame=spf)
+        assert (dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame) == \
+            (ref._pad_start, ref._pad_end, 2**24, spf)
+        assert dd.shape == (ref.shape[0], 8, 2) and dd.start_time == ref.start_time
+        if rank:
+            assert plain._pad_start < ref._pad_start          # its own geometry would differ
+        # chirp columns are the shard's own
+        assert np.all(np.asarray(dd.frequency) == band[lo:hi])
+
+
+def _bench(env, *argv, timeout=120):
+    import subprocess
+    e = dict(os.environ, **env)
+    e.pop('WORLD_SIZE', None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=e,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus N` (no torchrun): the parent spawns N ranks,
+    rank 0 prints the one JSON line, a failing rank fails the run.  Dry-run
+    mode: rendezvous and exit codes only (gloo, no GPU)."""
+    import json
+    r = _bench(dict(BBT_BENCH_DRYRUN='1'), '--gpus', '2')
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0]) == dict(dry_run=True, n_gpus=2, rank_sum=3)
+    r = _bench(dict(BBT_BENCH_DRYRUN='1', BBT_BENCH_DRYRUN_FAIL='1'), '--gpus', '2')
+    assert r.returncode == 7 and 'rank 1 exited with 7' in r.stderr
