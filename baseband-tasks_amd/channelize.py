@@ -8,7 +8,7 @@ import numpy as np
 from . import hip
 from .base import TaskBase, getattr_if_none, _stream_rate
 from .device_task import DeviceTaskMixin, fetch_device
-from .fourier import MIN_FFT_LEN, MAX_WG_FFT_LEN
+from .fourier import MIN_FFT_LEN, check_transform_length
 
 __all__ = ['Channelize', 'Dechannelize', 'FUSE_WITH_OVERLAP_SAVE', 'FUSE_DETECTION']
 
@@ -30,9 +30,15 @@ def _prod(shape):
 
 
 def _check_n(n, minimum=2):
-    if n < minimum or n > MAX_WG_FFT_LEN or n & (n - 1):
-        raise ValueError(f"the accelerated channelizer supports power-of-two n in "
-                         f"[{minimum}, {MAX_WG_FFT_LEN}]; got {n}.")
+    """Channel counts the kernels take: for a plain channelizer any
+    2^a 3^b 5^c 7^d up to 8192; with ``minimum`` (the polyphase filter bank's
+    fused FIR + FFT kernels) powers of two in [minimum, 4096]."""
+    if minimum > 2:
+        if n < minimum or n > 4096 or n & (n - 1):
+            raise ValueError(f"the accelerated filter bank supports power-of-two n in "
+                             f"[{minimum}, 4096]; got {n}.")
+    else:
+        check_transform_length(n, 'channel counts')
 
 
 class _RowFFTTask(DeviceTaskMixin, TaskBase):
@@ -109,7 +115,9 @@ class Channelize(_RowFFTTask):
     ----------
     ih : stream (complex64)
     n : int
-        Channels; power of two, 256..4096.
+        Channels: any product of 2, 3, 5, 7 up to 8192 (powers of two up to
+        4096 run on the tuned kernels and, from 256, fuse into an upstream
+        overlap-save task).
     samples_per_frame : int
         Spectra per frame (default 1); only affects framing.
     frequency, sideband : optional overrides of the stream metadata.
@@ -149,8 +157,7 @@ class Channelize(_RowFFTTask):
         if (dd._n_stream != dd._n_stream_even or dd.samples_per_frame < self._n
                 or self._n < MIN_FFT_LEN):
             return None
-        info = dd._get_plan().info()
-        if info['n1'] == 1 or self._n > info['n2'] or info['n2'] % self._n:
+        if not dd._get_plan().fusable(self._n):
             return None
         return dd
 

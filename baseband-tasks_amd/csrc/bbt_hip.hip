@@ -15,10 +15,11 @@
 
 #include "../../include/bbt_hip.h"
 #include "bbt_kernels.hpp"
+#include "gen_kernels.hpp"
 
 using namespace bbt;
 
-#define BBT_VERSION 110
+#define BBT_VERSION 120
 
 // ---------------------------------------------------------------------------
 // errors
@@ -116,6 +117,45 @@ static int get_wroot(cf** out) {
 
 static bool fft_len_ok(int64_t n) { return is_pow2(n) && n >= 256 && n <= 4096; }
 
+// ---- lengths 2^a 3^b 5^c 7^d (fft_generic.hpp) ------------------------------
+static bool factor_7smooth(int64_t n, GenGeo* g) {
+    if (n < 1 || n > BBT_GEN_MAX_LEN) return false;
+    g->n = (int)n;
+    g->nfac = 0;
+    int64_t m = n;
+    auto take = [&](int r) {
+        while (m % r == 0 && g->nfac < BBT_GEN_MAX_FACTORS) {
+            g->fac[g->nfac++] = r;
+            m /= r;
+        }
+    };
+    take(8); take(4); take(2); take(3); take(5); take(7);
+    return m == 1;
+}
+static bool is_7smooth(int64_t n) {
+    if (n < 1) return false;
+    for (int r : {2, 3, 5, 7})
+        while (n % r == 0) n /= r;
+    return n == 1;
+}
+// N = N1 * N2 with N1 <= N2 <= BBT_GEN_MAX_LEN, as balanced as possible
+static bool split_7smooth(int64_t n, int* n1, int* n2) {
+    int64_t best = 0;
+    for (int64_t d = 1; d * d <= n; ++d)
+        if (n % d == 0 && n / d <= BBT_GEN_MAX_LEN) best = d;
+    if (!best) return false;
+    *n1 = (int)best;
+    *n2 = (int)(n / best);
+    return true;
+}
+static int gen_threads(int elements) {          // elements <= 8 * threads, whole waves
+    int t = ((elements + 7) / 8 + 63) / 64 * 64;
+    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+static std::map<std::pair<int, int>, cf*> g_gen_tables;    // (device, n) -> W_n^k, k < n
+static int get_gen_table(int n, cf** out);
+static int make_big_twiddle(int64_t n, cf** lo, cf** hi);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a
 // kernel: set it once per (device, kernel) and check the result.
 static int ensure_dyn_lds(const void* func, size_t bytes) {
@@ -128,6 +168,32 @@ static int ensure_dyn_lds(const void* func, size_t bytes) {
     if (it != done.end() && it->second >= bytes) return 0;
     HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     done[{dev, func}] = bytes;
+    return 0;
+}
+
+static int get_gen_table(int n, cf** out) {
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto it = g_gen_tables.find({dev, n});
+    if (it != g_gen_tables.end()) {
+        *out = it->second;
+        return 0;
+    }
+    std::vector<cf> h(n);
+    for (int k = 0; k < n; ++k) h[k] = unit_root(k, n);
+    cf* d;
+    if (upload(&d, h)) return 1;
+    g_gen_tables[{dev, n}] = d;
+    *out = d;
+    return 0;
+}
+// W_N^m = hi[m >> 12] * lo[m & 4095]  (per plan: depends on N)
+static int make_big_twiddle(int64_t n, cf** lo, cf** hi) {
+    std::vector<cf> l(4096), h((size_t)((n + 4095) / 4096));
+    for (int i = 0; i < 4096; ++i) l[i] = unit_root(i, n);
+    for (size_t j = 0; j < h.size(); ++j) h[j] = unit_root((long long)j * 4096, n);
+    if (upload(lo, l) || upload(hi, h)) return 1;
     return 0;
 }
 
@@ -389,6 +455,15 @@ struct bbt_osm_plan {
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     cf* wroot = nullptr;
+    // block lengths that are not powers of two (gen_kernels.hpp): N = n1 * n2,
+    // n1 == 1 for N <= 8192
+    bool generic = false;
+    GenGeo g1 = {}, g2 = {};
+    cf* wn1 = nullptr;          // W_{n1}^k (shared table)
+    cf* wn2 = nullptr;          // W_{n2}^k (shared table)
+    cf* tlo = nullptr;          // W_N^i, i < 4096        (owned)
+    cf* thi = nullptr;          // W_N^{4096 j}           (owned)
+    int gen_ct = 1;             // columns per tile of the column passes
     // fused channelizer
     float2* seam = nullptr;     // [blocks][2][npair][n_chan] float4
     size_t seam_bytes = 0;
@@ -545,7 +620,36 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         }
         HIP_TRY(hipEventRecord(e[0], st));
     }
-    if (p->n1 == 1) {
+    if (p->generic) {
+        if (nch) return fail("osm: the fused channelizer needs a power-of-two block length");
+        if (p->n1 == 1) {
+            const size_t lds = (size_t)p->n2 * sizeof(f4);
+            if (ensure_dyn_lds((const void*)k_gen_osm_small, lds)) return 1;
+            hipLaunchKernelGGL(k_gen_osm_small, dim3(ch.nblk * p->npair), dim3(gen_threads(p->n2)), lds,
+                               st, in, out, ch, p->S, p->resp, p->resp_index, p->g2, p->wn2);
+            if (p->timing) {
+                HIP_TRY(hipEventRecord(e[1], st));
+                HIP_TRY(hipEventRecord(e[2], st));
+            }
+        } else {
+            const int ct = p->gen_ct, tiles = (p->n2 + ct - 1) / ct;
+            const size_t lds_c = (size_t)p->n1 * ct * sizeof(f4), lds_r = (size_t)p->n2 * sizeof(f4);
+            if (ensure_dyn_lds((const void*)k_gen_col<true>, lds_c) ||
+                ensure_dyn_lds((const void*)k_gen_col<false>, lds_c) ||
+                ensure_dyn_lds((const void*)k_gen_row, lds_r))
+                return 1;
+            const dim3 gcol(tiles * p->npair, ch.nblk), bcol(gen_threads(p->n1 * ct));
+            hipLaunchKernelGGL((k_gen_col<true>), gcol, bcol, lds_c, st, in, out, work, ch, p->S, p->n2,
+                               ct, p->g1, p->wn1);
+            if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+            hipLaunchKernelGGL(k_gen_row, dim3(p->n1, ch.nblk * p->npair), dim3(gen_threads(p->n2)),
+                               lds_r, st, work, p->n1, p->resp, p->resp_index, p->npair, p->g2, p->wn2,
+                               p->tlo, p->thi);
+            if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+            hipLaunchKernelGGL((k_gen_col<false>), gcol, bcol, lds_c, st, in, out, work, ch, p->S, p->n2,
+                               ct, p->g1, p->wn1);
+        }
+    } else if (p->n1 == 1) {
         int rc = 0;
         switch (p->n2) {
             case 256: rc = launch_small<256>(p, in, out, ch, st); break;
@@ -672,8 +776,12 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
                         const void* resp, int resp_on_device, const int32_t* resp_index) {
     ARG_TRY(plan && resp, "bbt_osm_plan_create: null argument");
     *plan = nullptr;
-    ARG_TRY(is_pow2(n_fft) && n_fft >= 256 && n_fft <= (1 << 24),
-            "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^24]",
+    const bool fast = is_pow2(n_fft) && n_fft >= 256 && n_fft <= (1 << 24);
+    int gn1 = 1, gn2 = 0;
+    ARG_TRY(fast || (is_7smooth(n_fft) && n_fft >= 2 &&
+                     (n_fft <= BBT_GEN_MAX_LEN || split_7smooth(n_fft, &gn1, &gn2))),
+            "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^24] or a product of "
+            "2, 3, 5, 7 that is <= 8192 or splits into two such factors",
             (long long)n_fft);
     ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
             "bbt_osm_plan_create: n_stream=%d must be even and >= 2", n_stream);
@@ -695,7 +803,14 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     p->S = n_stream;
     p->npair = n_stream / 2;
     p->C = n_resp;
-    if (n_fft <= 4096) {
+    if (!fast) {
+        p->generic = true;
+        if (n_fft <= BBT_GEN_MAX_LEN) {
+            gn1 = 1;
+            gn2 = (int)n_fft;
+        }
+        p->n1 = gn1;
+    } else if (n_fft <= 4096) {
         p->n1 = 1;
     } else if (n_fft <= (1 << 16)) {
         p->n1 = 16;
@@ -704,13 +819,24 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     } else {
         p->outer = 256;
         p->n1 = 16;
-        ARG_TRY(n_stream / 2 <= 255,
-                "bbt_osm_plan_create: blocks longer than 2^20 support at most 510 streams");
+        if (n_stream / 2 > 255)
+            return bail(fail("bbt_osm_plan_create: blocks longer than 2^20 support at most 510 streams"));
     }
     p->n2 = (int)(n_fft / p->n1 / p->outer);
-    if (get_tables(p->n2, &p->tab2)) return bail(1);
-    if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
-    if (get_wroot(&p->wroot)) return bail(1);
+    if (p->generic) {
+        if (!factor_7smooth(p->n2, &p->g2) || (p->n1 > 1 && !factor_7smooth(p->n1, &p->g1)))
+            return bail(fail("bbt_osm_plan_create: cannot factor %d x %d", p->n1, p->n2));
+        if (get_gen_table(p->n2, &p->wn2)) return bail(1);
+        if (p->n1 > 1) {
+            if (get_gen_table(p->n1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
+                return bail(1);
+            p->gen_ct = std::max(1, std::min(8, BBT_GEN_MAX_LEN / p->n1));
+        }
+    } else {
+        if (get_tables(p->n2, &p->tab2)) return bail(1);
+        if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
+        if (get_wroot(&p->wroot)) return bail(1);
+    }
 
     // response: upload (if needed), permute to [C][N1][N2], scale by 1/N
     const size_t rbytes = (size_t)n_resp * n_fft * sizeof(cf);
@@ -787,6 +913,8 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     for (auto e : p->ev_free) hipEventDestroy(e);
     if (p->resp) hipFree(p->resp);
     if (p->resp_index) hipFree(p->resp_index);
+    if (p->tlo) hipFree(p->tlo);
+    if (p->thi) hipFree(p->thi);
     for (int l = 0; l < BBT_MAX_LANES; ++l) {
         if (p->lane_stream[l]) {
             hipStreamSynchronize(p->lane_stream[l]);
@@ -809,6 +937,12 @@ int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chun
     if (n1) *n1 = p->n1;
     if (n2) *n2 = p->n2;
     return 0;
+}
+
+int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
+    // can bbt_osm_execute_channelized take Channelize(n_chan) into the row pass?
+    if (!p || p->generic || (p->n1 == 1 && p->outer == 1)) return 0;
+    return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
 }
 
 int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,
@@ -839,6 +973,8 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
                            int64_t first_spectrum, int64_t n_spectra, int det_step, int det_mode,
                            float det_scale, hipStream_t st) {
     ARG_TRY(p && in_dev && out_dev, "%s: null argument", who);
+    ARG_TRY(!p->generic, "%s: the fused channelizer needs a power-of-two block length (got %lld)",
+            who, (long long)p->n);
     ARG_TRY(p->n1 > 1 || p->outer > 1, "%s: block length %lld is too short to fuse", who,
             (long long)p->n);
     ARG_TRY(fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0,
@@ -997,6 +1133,11 @@ struct bbt_chan_plan {
     int n = 0, S = 0, npair = 0, dir = -1;
     FftTables tab;
     cf* wroot = nullptr;
+    // channel counts that are not powers of two, or 8192 (gen_kernels.hpp)
+    bool generic = false;
+    GenGeo g = {};
+    cf* wn = nullptr;
+    int ct = 1;                 // stream pairs per workgroup tile
 };
 
 template <int N, int SIGN>
@@ -1053,8 +1194,10 @@ extern "C" {
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction) {
     ARG_TRY(plan, "bbt_chan_plan_create: null argument");
     *plan = nullptr;
-    ARG_TRY(is_pow2(n_chan) && n_chan >= 2 && n_chan <= 4096,
-            "bbt_chan_plan_create: n_chan=%d must be a power of two in [2, 4096]", n_chan);
+    const bool fast = is_pow2(n_chan) && n_chan >= 2 && n_chan <= 4096;
+    ARG_TRY(fast || (n_chan >= 2 && n_chan <= BBT_GEN_MAX_LEN && is_7smooth(n_chan)),
+            "bbt_chan_plan_create: n_chan=%d must be a power of two in [2, 4096] or a product of "
+            "2, 3, 5, 7 up to 8192", n_chan);
     ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
             "bbt_chan_plan_create: n_stream=%d must be even and >= 2", n_stream);
     ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1 or +1");
@@ -1063,7 +1206,20 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     p->S = n_stream;
     p->npair = n_stream / 2;
     p->dir = direction;
-    if ((n_chan >= 256 && get_tables(n_chan, &p->tab)) || (n_chan < 256 && get_wroot(&p->wroot))) {
+    if (!fast) {
+        p->generic = true;
+        if (!factor_7smooth(n_chan, &p->g) || get_gen_table(n_chan, &p->wn)) {
+            if (g_err.empty()) fail("bbt_chan_plan_create: cannot factor n_chan=%d", n_chan);
+            delete p;
+            return 1;
+        }
+        for (int ct = 8; ct >= 1; --ct)
+            if (p->npair % ct == 0 && (int64_t)n_chan * ct <= BBT_GEN_MAX_LEN) {
+                p->ct = ct;
+                break;
+            }
+    } else if ((n_chan >= 256 && get_tables(n_chan, &p->tab)) ||
+               (n_chan < 256 && get_wroot(&p->wroot))) {
         delete p;
         return 1;
     }
@@ -1088,6 +1244,20 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
     for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {
         const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
         const int64_t off = s0 * p->n * p->S;
+        if (p->generic) {
+            const size_t lds = (size_t)p->n * p->ct * sizeof(f4);
+            const dim3 grid((unsigned)(ns * (p->npair / p->ct))), block(gen_threads(p->n * p->ct));
+            if (p->dir < 0) {
+                if (ensure_dyn_lds((const void*)k_gen_fft_rows<-1>, lds)) return 1;
+                hipLaunchKernelGGL((k_gen_fft_rows<-1>), grid, block, lds, (hipStream_t)stream, in + off,
+                                   out + off, p->S, p->ct, 1.0f, p->g, p->wn);
+            } else {
+                if (ensure_dyn_lds((const void*)k_gen_fft_rows<+1>, lds)) return 1;
+                hipLaunchKernelGGL((k_gen_fft_rows<+1>), grid, block, lds, (hipStream_t)stream, in + off,
+                                   out + off, p->S, p->ct, 1.0f / (float)p->n, p->g, p->wn);
+            }
+            continue;
+        }
         int rc = (p->dir < 0)
                      ? chan_dispatch<-1>(p, in + off, out + off, ns, 1.0f, (hipStream_t)stream)
                      : chan_dispatch<+1>(p, in + off, out + off, ns, 1.0f / (float)p->n,

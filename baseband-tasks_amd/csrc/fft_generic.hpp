@@ -1,0 +1,177 @@
+// Workgroup FFT for any length n = 2^a 3^b 5^c 7^d <= 8192 (gfx950, wave64).
+//
+// The reference sizes its overlap-save blocks with the FFT engine's
+// next_fast_len -- for its NumPy engine the smallest 2^a 3^b 5^c 7^d >= n
+// (baseband_tasks/fourier/numpy.py:99-126; block rule base.py:750-758) -- so
+// the reference's DEFAULT block lengths are not powers of two (6174 in its
+// tests, 1 049 760 for Resample at 2^20, 11 059 200 for config 4).  The
+// power-of-two core (fft_core.hpp) is the fast path; this file provides the
+// same transforms for every length the reference's engine would choose.
+//
+// Stockham autosort, in place in LDS.  The tile is `ct` interleaved
+// transforms (element i of transform c at lds[i * ct + c], 16 bytes each: both
+// streams of a pair, re_A re_B im_A im_B).  A stage of radix R with
+// Ns = product of the earlier radices:
+//
+//   for j in [0, n / R):  k = j mod Ns
+//       v[r]  = x[j + r n/R] * W_{Ns R}^{r k}          r < R
+//       v     = DFT_R(v)
+//       x'[(j - k) R + k + r Ns] = v[r]
+//
+// after the last stage x' is the transform in natural order.  Every thread
+// first reads all its butterflies into registers, the workgroup synchronises,
+// then it writes: one buffer suffices, so n * ct <= 8192 elements (128 KiB)
+// fit one CU.  A thread owns at most MAXB(R) = ceil(8 / R) butterflies per
+// stage, so the caller must launch with  n * ct <= 8 * blockDim.x.
+//
+// Twiddles come from a table wn[k] = exp(-2 pi i k / n), k < n, evaluated in
+// double on the host.  Butterflies for 2, 4, 8 are those of fft_core.hpp; 3, 5
+// and 7 use the symmetric form (pairs v[k] +- v[p-k], real coefficient sums).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fft_core.hpp"
+
+namespace bbt {
+
+#define BBT_GEN_MAX_FACTORS 24
+#define BBT_GEN_MAX_LEN 8192          // elements of one LDS tile (n * ct)
+struct GenGeo {
+    int n;                            // transform length
+    int nfac;                         // number of stages
+    int fac[BBT_GEN_MAX_FACTORS];     // radices in {2, 3, 4, 5, 7, 8}, product n
+};
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c2 f4_to_c2(f4 x) { return c2{v2{x.x, x.y}, v2{x.z, x.w}}; }
+__device__ __forceinline__ f4 c2_to_f4(c2 a) { return f4{a.re.x, a.re.y, a.im.x, a.im.y}; }
+
+// cos / sin (2 pi m / p) for the odd radices
+template <int P> struct OddRoots;
+template <> struct OddRoots<3> {
+    static constexpr float c[3] = {1.f, -0.5f, -0.5f};
+    static constexpr float s[3] = {0.f, 0.86602540378443864676f, -0.86602540378443864676f};
+};
+template <> struct OddRoots<5> {
+    static constexpr float c[5] = {1.f, 0.30901699437494742410f, -0.80901699437494742410f,
+                                   -0.80901699437494742410f, 0.30901699437494742410f};
+    static constexpr float s[5] = {0.f, 0.95105651629515357212f, 0.58778525229247312917f,
+                                   -0.58778525229247312917f, -0.95105651629515357212f};
+};
+template <> struct OddRoots<7> {
+    static constexpr float c[7] = {1.f, 0.62348980185873353053f, -0.22252093395631440429f,
+                                   -0.90096886790241912624f, -0.90096886790241912624f,
+                                   -0.22252093395631440429f, 0.62348980185873353053f};
+    static constexpr float s[7] = {0.f, 0.78183148246802980871f, 0.97492791218182360702f,
+                                   0.43388373911755812048f, -0.43388373911755812048f,
+                                   -0.97492791218182360702f, -0.78183148246802980871f};
+};
+
+// DFT of odd prime length P, natural order in and out.
+//   a_k = v_k + v_{P-k}, b_k = v_k - v_{P-k}
+//   X_j, X_{P-j} = (v_0 + sum_k cos(2 pi j k / P) a_k)  -+ i (sum_k sin(2 pi j k / P) b_k)   (forward)
+template <int SIGN, int P>
+__device__ __forceinline__ void radix_odd(c2 (&v)[P]) {
+    constexpr int H = (P - 1) / 2;
+    c2 a[H], b[H];
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        a[k - 1] = cadd(v[k], v[P - k]);
+        b[k - 1] = csub(v[k], v[P - k]);
+    }
+    const c2 v0 = v[0];
+    c2 sum = v0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) sum = cadd(sum, a[k]);
+    v[0] = sum;
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+        c2 cc = v0, ss = czero();
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            const float co = OddRoots<P>::c[(j * k) % P], si = OddRoots<P>::s[(j * k) % P];
+            cc.re += a[k - 1].re * co;
+            cc.im += a[k - 1].im * co;
+            ss.re += b[k - 1].re * si;
+            ss.im += b[k - 1].im * si;
+        }
+        // -i ss = (ss.im, -ss.re)
+        const c2 lo = c2{cc.re + ss.im, cc.im - ss.re};      // cc - i ss
+        const c2 hi = c2{cc.re - ss.im, cc.im + ss.re};      // cc + i ss
+        v[j] = SIGN < 0 ? lo : hi;
+        v[P - j] = SIGN < 0 ? hi : lo;
+    }
+}
+
+template <int SIGN, int R>
+__device__ __forceinline__ void gen_butterfly(c2 (&v)[R]) {
+    if constexpr (R == 2 || R == 4 || R == 8) radixR<SIGN, R>(v);
+    else radix_odd<SIGN, R>(v);
+}
+
+// One in-place Stockham stage over a tile of `ct` interleaved transforms.
+template <int SIGN, int R>
+__device__ __forceinline__ void gen_stage(f4* __restrict__ lds, int n, int ns, int ct,
+                                          const cf* __restrict__ wn, int tid, int nthr) {
+    constexpr int MAXB = (8 + R - 1) / R;
+    const int m = n / R;               // butterflies per transform
+    const int total = m * ct;
+    const int wstep = n / (ns * R);    // W_{ns R}^x = wn[x * wstep]
+    c2 v[MAXB][R];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int idx = tid + b * nthr;
+        if (idx < total) {
+            const int j = idx / ct, col = idx - j * ct;
+            const int k = j % ns;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c2 t = f4_to_c2(lds[(j + r * m) * ct + col]);
+                if (r > 0) t = twmul<SIGN>(t, wn[(r * k) * wstep]);
+                v[b][r] = t;
+            }
+            gen_butterfly<SIGN, R>(v[b]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int idx = tid + b * nthr;
+        if (idx < total) {
+            const int j = idx / ct, col = idx - j * ct;
+            const int k = j % ns;
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) lds[(j0 + r * ns) * ct + col] = c2_to_f4(v[b][r]);
+        }
+    }
+    __syncthreads();
+}
+
+// The whole transform; all threads of the workgroup call it together.  The
+// tile must be complete (a __syncthreads() after filling it) on entry; on
+// return it holds the transforms in natural order and is synchronised.
+template <int SIGN>
+__device__ __forceinline__ void gen_fft(f4* __restrict__ lds, const GenGeo& g, int ct,
+                                        const cf* __restrict__ wn, int tid, int nthr) {
+    int ns = 1;
+    for (int s = 0; s < g.nfac; ++s) {
+        const int r = g.fac[s];
+        switch (r) {
+            case 2: gen_stage<SIGN, 2>(lds, g.n, ns, ct, wn, tid, nthr); break;
+            case 3: gen_stage<SIGN, 3>(lds, g.n, ns, ct, wn, tid, nthr); break;
+            case 4: gen_stage<SIGN, 4>(lds, g.n, ns, ct, wn, tid, nthr); break;
+            case 5: gen_stage<SIGN, 5>(lds, g.n, ns, ct, wn, tid, nthr); break;
+            case 7: gen_stage<SIGN, 7>(lds, g.n, ns, ct, wn, tid, nthr); break;
+            default: gen_stage<SIGN, 8>(lds, g.n, ns, ct, wn, tid, nthr); break;
+        }
+        ns *= r;
+    }
+}
+
+// W_N^m for m < N up to 2^26 from two tables evaluated in double on the host:
+//   lo[i] = W_N^i (i < 4096),  hi[j] = W_N^{4096 j}
+__device__ __forceinline__ cf big_twiddle(const cf* __restrict__ lo, const cf* __restrict__ hi, int m) {
+    return cmul(hi[m >> 12], lo[m & 4095]);
+}
+
+}  // namespace bbt

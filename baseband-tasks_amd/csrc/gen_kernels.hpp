@@ -1,0 +1,154 @@
+// Kernels for block / channel counts that are not powers of two
+// (n = 2^a 3^b 5^c 7^d), built on the LDS Stockham transform of
+// fft_generic.hpp.  Same data contract and the same three-pass structure as the
+// power-of-two path in bbt_kernels.hpp:
+//
+//   k_gen_osm_small   N <= 8192: ifft(fft(x) * H)[valid] in one workgroup
+//                     (reference dispersion.py:135-139, convolution.py:116-120)
+//   k_gen_col         N = N1 x N2: column transforms over n1 (forward: stream ->
+//                     work; inverse: work -> valid output samples)
+//   k_gen_row         row k1: four-step twiddle, forward over n2, * H, inverse
+//                     over k2, conjugate twiddle, in place
+//   k_gen_fft_rows    Channelize.task / Dechannelize.task for such n
+//                     (reference channelize.py:73-74, 164-165)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bbt_kernels.hpp"
+#include "fft_generic.hpp"
+
+namespace bbt {
+
+__device__ __forceinline__ f4 ld_ext_f4(const float2* p) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    return f4{x.x, x.z, x.y, x.w};
+}
+__device__ __forceinline__ void st_ext_f4(float2* p, f4 a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.x, a.z, a.y, a.w);
+}
+__device__ __forceinline__ f4 f4_mul_resp(f4 a, cf x, cf y) {     // stream A times x, stream B times y
+    return f4{a.x * x.x - a.z * x.y, a.y * y.x - a.w * y.y, a.x * x.y + a.z * x.x, a.y * y.y + a.w * y.x};
+}
+__device__ __forceinline__ f4 f4_twmul(f4 a, cf w) { return f4_mul_resp(a, w, w); }
+
+// One workgroup per (block, pair): n = g.n <= 8192 elements of dynamic LDS.
+__global__ __launch_bounds__(1024) void k_gen_osm_small(const float2* __restrict__ in,
+                                                        float2* __restrict__ out, OsmChunk ch, int S,
+                                                        const cf* __restrict__ resp,
+                                                        const int* __restrict__ resp_index, GenGeo g,
+                                                        const cf* __restrict__ wn) {
+    extern __shared__ f4 gen_lds[];
+    const int npair = S >> 1, n = g.n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int sp = blockIdx.x % npair;
+    const OsmBlock blk = ch.b[blockIdx.x / npair];
+    const float2* src = in + (blk.in_off * S + 2 * sp);
+    for (int i = tid; i < n; i += nthr) gen_lds[i] = ld_ext_f4(src + (long long)i * S);
+    __syncthreads();
+    gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
+    const cf* h0 = resp + (long long)resp_index[2 * sp] * n;
+    const cf* h1 = resp + (long long)resp_index[2 * sp + 1] * n;
+    for (int i = tid; i < n; i += nthr) gen_lds[i] = f4_mul_resp(gen_lds[i], h0[i], h1[i]);
+    __syncthreads();
+    gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
+    for (int i = tid; i < n; i += nthr) {
+        const int r = i - blk.valid_start;
+        if (r >= 0 && r < blk.valid_count) st_ext_f4(out + ((blk.out_off + r) * S + 2 * sp), gen_lds[i]);
+    }
+}
+
+// Column pass: tile of `ct` columns n2 of one (block, pair), all N1 = g.n rows.
+//   grid (tiles * npair, blocks); work element (k1, n2) at ((b*npair+sp)*N1 + k1)*N2 + n2.
+template <bool FIRST>
+__global__ __launch_bounds__(1024) void k_gen_col(const float2* __restrict__ in,
+                                                  float2* __restrict__ out,
+                                                  float2* __restrict__ work, OsmChunk ch, int S,
+                                                  int N2, int ct, GenGeo g,
+                                                  const cf* __restrict__ wn) {
+    extern __shared__ f4 gen_lds[];
+    const int npair = S >> 1, N1 = g.n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int sp = blockIdx.x % npair, n2_0 = (blockIdx.x / npair) * ct;
+    const int b = blockIdx.y;
+    const OsmBlock blk = ch.b[b];
+    f4* w = reinterpret_cast<f4*>(work) + ((long long)(b * npair + sp) * N1) * N2;
+    const int total = N1 * ct;
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int n1 = idx / ct, n2 = n2_0 + (idx - n1 * ct);
+        f4 x = f4{0.f, 0.f, 0.f, 0.f};
+        if (n2 < N2) {
+            if (FIRST) x = ld_ext_f4(in + ((blk.in_off + (long long)n1 * N2 + n2) * S + 2 * sp));
+            else x = w[(long long)n1 * N2 + n2];
+        }
+        gen_lds[idx] = x;
+    }
+    __syncthreads();
+    gen_fft<FIRST ? -1 : +1>(gen_lds, g, ct, wn, tid, nthr);
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int n1 = idx / ct, n2 = n2_0 + (idx - n1 * ct);
+        if (n2 >= N2) continue;
+        if (FIRST) {
+            w[(long long)n1 * N2 + n2] = gen_lds[idx];
+        } else {
+            const long long r = (long long)n1 * N2 + n2 - blk.valid_start;
+            if (r >= 0 && r < blk.valid_count) st_ext_f4(out + ((blk.out_off + r) * S + 2 * sp), gen_lds[idx]);
+        }
+    }
+}
+
+// Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair).
+//   resp  : [C][N1][N2] = H[c][k1 + N1 k2] / N
+//   wn    : W_{N2}^k ;  tlo / thi : W_N^m tables (big_twiddle)
+__global__ __launch_bounds__(1024) void k_gen_row(float2* __restrict__ work, int N1,
+                                                  const cf* __restrict__ resp,
+                                                  const int* __restrict__ resp_index, int npair,
+                                                  GenGeo g, const cf* __restrict__ wn,
+                                                  const cf* __restrict__ tlo,
+                                                  const cf* __restrict__ thi) {
+    extern __shared__ f4 gen_lds[];
+    const int N2 = g.n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int k1 = blockIdx.x, sp = blockIdx.y % npair;
+    f4* row = reinterpret_cast<f4*>(work) + ((long long)blockIdx.y * N1 + k1) * N2;
+    for (int i = tid; i < N2; i += nthr) gen_lds[i] = f4_twmul(row[i], big_twiddle(tlo, thi, k1 * i));
+    __syncthreads();
+    gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
+    const cf* h0 = resp + ((long long)resp_index[2 * sp] * N1 + k1) * N2;
+    const cf* h1 = resp + ((long long)resp_index[2 * sp + 1] * N1 + k1) * N2;
+    for (int i = tid; i < N2; i += nthr) gen_lds[i] = f4_mul_resp(gen_lds[i], h0[i], h1[i]);
+    __syncthreads();
+    gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
+    for (int i = tid; i < N2; i += nthr) {
+        const cf w = big_twiddle(tlo, thi, k1 * i);
+        row[i] = f4_twmul(gen_lds[i], make_float2(w.x, -w.y));
+    }
+}
+
+// Batched transforms over contiguous groups of n = g.n complete samples, for a
+// tile of `ct` stream pairs (ct * 16 contiguous bytes per complete sample).
+//   grid (n_fft * (npair / ct))
+template <int SIGN>
+__global__ __launch_bounds__(1024) void k_gen_fft_rows(const float2* __restrict__ in,
+                                                       float2* __restrict__ out, int S, int ct,
+                                                       float scale, GenGeo g,
+                                                       const cf* __restrict__ wn) {
+    extern __shared__ f4 gen_lds[];
+    const int npair = S >> 1, n = g.n, npg = npair / ct;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const long long i = blockIdx.x / npg;
+    const int sp0 = (blockIdx.x % npg) * ct;
+    const int total = n * ct;
+    const float2* src = in + (i * n * S + 2 * sp0);
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int e = idx / ct, c = idx - e * ct;
+        gen_lds[idx] = ld_ext_f4(src + ((long long)e * S + 2 * c));
+    }
+    __syncthreads();
+    gen_fft<SIGN>(gen_lds, g, ct, wn, tid, nthr);
+    float2* dst = out + (i * n * S + 2 * sp0);
+    for (int idx = tid; idx < total; idx += nthr) {
+        const int e = idx / ct, c = idx - e * ct;
+        st_ext_f4(dst + ((long long)e * S + 2 * c), gen_lds[idx] * scale);
+    }
+}
+
+}  // namespace bbt

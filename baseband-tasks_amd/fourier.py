@@ -4,8 +4,10 @@ The reference lets tasks pick an FFT engine through the `fft_maker` state
 (baseband_tasks/fourier/base.py:348-466) and asks the engine for
 ``next_fast_len`` when sizing overlap-save blocks (base.py:757-758).  This
 package has a single engine, the hand-written gfx950 FFT inside
-libbbt_hip.so.  Its fast lengths are powers of two, up to 2^24 for
-overlap-save blocks.
+libbbt_hip.so.  Like the reference's NumPy engine its fast lengths are the
+products of 2, 3, 5 and 7 (fourier/numpy.py:99-126), so default-argument tasks
+get the reference's block geometry; powers of two run on the tuned kernels,
+other lengths on a generic LDS Stockham transform.
 """
 import operator
 
@@ -15,9 +17,26 @@ __all__ = ['HipFFTMaker', 'fft_maker', 'FFT_MAKER_CLASSES']
 
 FFT_MAKER_CLASSES = {}
 
-MIN_FFT_LEN = 256
-MAX_BLOCK_LEN = 1 << 24
-MAX_WG_FFT_LEN = 4096
+MIN_FFT_LEN = 256               # shortest transform the fused (power-of-two) paths take
+MAX_BLOCK_LEN = 1 << 26         # overlap-save blocks: two factors of at most MAX_WG_FFT_LEN
+MAX_WG_FFT_LEN = 8192           # longest transform done by one workgroup
+
+
+def is_fast_len(n):
+    """True for n = 2^a 3^b 5^c 7^d."""
+    n = operator.index(n)
+    if n < 1:
+        return False
+    for p in (2, 3, 5, 7):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+def check_transform_length(n, what='transform length'):
+    if n < 2 or n > MAX_WG_FFT_LEN or not is_fast_len(n):
+        raise ValueError(f"the hip engine handles {what} n = 2^a 3^b 5^c 7^d with 2 <= n <= "
+                         f"{MAX_WG_FFT_LEN}; got {n}.")
 
 
 class FFTMakerBase:
@@ -36,11 +55,15 @@ class FFTMakerBase:
 
 class HipFFT:
     """One pre-defined transform (reference fourier/base.py:59-218): FFT along
-    ``axis`` of complex64 arrays of ``time_shape``; host in, host out."""
+    ``axis`` of arrays of ``time_shape``; host in, host out.  complex64 time
+    data transform to complex64 of the same shape; float32 time data to
+    ``n // 2 + 1`` complex64 frequencies (fourier/base.py:313-340), computed as
+    the complex transform of the zero-imaginary-part data (forward) or of the
+    Hermitian-extended half spectrum (backward)."""
 
-    def __init__(self, time_shape, axis, direction, ortho, sample_rate):
-        self.time_shape = self.frequency_shape = tuple(time_shape)
-        self.time_dtype = self.frequency_dtype = np.dtype(np.complex64)
+    def __init__(self, time_shape, time_dtype, axis, direction, ortho, sample_rate):
+        self.time_shape = tuple(operator.index(d) for d in time_shape)
+        self.time_dtype = np.dtype(time_dtype)
         axis = operator.index(axis)
         if not -len(self.time_shape) <= axis < len(self.time_shape):
             raise ValueError(f"axis {axis} is out of bounds for shape {self.time_shape}.")
@@ -48,36 +71,39 @@ class HipFFT:
         self.axis, self.ortho, self.sample_rate = axis, bool(ortho), sample_rate
         self.direction = 'backward' if direction == 'backward' else 'forward'
         n = self.time_shape[axis]
-        if n < 2 or n > MAX_WG_FFT_LEN or n & (n - 1):
-            raise ValueError("the hip engine transforms power-of-two lengths "
-                             f"2..{MAX_WG_FFT_LEN} along an axis (got {n}).")
+        check_transform_length(n)
+        self._real = self.time_dtype.kind == 'f'
+        self.frequency_dtype = np.dtype(np.complex64)
+        fshape = list(self.time_shape)
+        if self._real:
+            fshape[axis] = n // 2 + 1
+        self.frequency_shape = tuple(fshape)
         self._plan = None
 
     @property
     def frequency(self):
         rate = 1. if self.sample_rate is None else self.sample_rate
-        f = np.fft.fftfreq(self.time_shape[self.axis], d=1. / rate)
+        n = self.time_shape[self.axis]
+        f = (np.fft.rfftfreq if self._real else np.fft.fftfreq)(n, d=1. / rate)
         return f.reshape(f.shape + (1,) * (len(self.time_shape) - self.axis - 1))
 
     def inverse(self):
-        return HipFFT(self.time_shape, self.axis,
+        return HipFFT(self.time_shape, self.time_dtype, self.axis,
                       'forward' if self.direction == 'backward' else 'backward',
                       self.ortho, self.sample_rate)
 
-    def __call__(self, a):
+    def _transform(self, a, sign):
+        """Complex transform of ``a`` (time_shape, complex64) along the axis."""
         from . import hip
-        a = np.ascontiguousarray(a, dtype=np.complex64)
-        assert a.shape == self.time_shape
         n = self.time_shape[self.axis]
         outer = int(np.prod(self.time_shape[:self.axis], dtype=np.int64))
         inner = int(np.prod(self.time_shape[self.axis + 1:], dtype=np.int64))
-        flat = a.reshape(outer * n, inner)
+        flat = np.ascontiguousarray(a, dtype=np.complex64).reshape(outer * n, inner)
         odd = inner % 2 == 1
         if odd:
             flat = np.concatenate([flat, np.zeros_like(flat[:, :1])], axis=1)
-        streams = flat.shape[1]
         if self._plan is None:
-            self._plan = hip.ChanPlan(n, streams, -1 if self.direction == 'forward' else +1)
+            self._plan = hip.ChanPlan(n, flat.shape[1], sign)
         din = hip.DeviceArray.from_host(flat)
         dout = hip.DeviceArray(flat.shape, np.complex64)
         self._plan.execute(din, dout, outer)
@@ -86,40 +112,109 @@ class HipFFT:
             res = res[:, :inner]
         res = np.ascontiguousarray(res).reshape(self.time_shape)
         if self.ortho:
-            res *= np.float32(np.sqrt(n) if self.direction == 'backward' else 1. / np.sqrt(n))
+            res *= np.float32(np.sqrt(n) if sign > 0 else 1. / np.sqrt(n))
         return res
+
+    def __call__(self, a):
+        a = np.asanyarray(a)
+        n = self.time_shape[self.axis]
+        if self.direction == 'forward':
+            assert a.shape == self.time_shape
+            res = self._transform(a, -1)
+            if self._real:
+                res = np.ascontiguousarray(np.take(res, range(n // 2 + 1), axis=self.axis))
+            return res
+        assert a.shape == self.frequency_shape
+        if not self._real:
+            return self._transform(a, +1)
+        # irfft semantics: imaginary parts of the DC (and Nyquist) bins are ignored
+        half = np.moveaxis(np.array(a, dtype=np.complex64), self.axis, 0)
+        half[0] = half[0].real
+        if n % 2 == 0:
+            half[-1] = half[-1].real
+        full = np.concatenate([half, half[-2 if n % 2 == 0 else -1:0:-1].conj()])
+        res = self._transform(np.moveaxis(full, 0, self.axis), +1)
+        return np.ascontiguousarray(res.real)
 
     def __repr__(self):
         return (f"<HipFFT direction={self.direction},\n    axis={self.axis}, ortho={self.ortho},"
                 f" sample_rate={self.sample_rate}\n    Time domain: shape={self.time_shape},"
-                f" dtype=complex64\n    Frequency domain: shape={self.frequency_shape},"
+                f" dtype={self.time_dtype}\n    Frequency domain: shape={self.frequency_shape},"
                 " dtype=complex64>")
 
 
 class HipFFTMaker(FFTMakerBase):
-    """The gfx950 engine."""
+    """The gfx950 engine.
+
+    Parameters
+    ----------
+    power_of_two : bool
+        Size overlap-save blocks to the next power of two (>= 256) instead of
+        the next product of 2, 3, 5, 7.  Those blocks run on the tuned kernels
+        and can host the fused channelizer, but the block geometry -- and with
+        it the output at the 1e-3 level, a chirp not being time limited -- then
+        differs from the reference's default.  Default False.
+    """
+
+    def __init__(self, power_of_two=False):
+        self.power_of_two = bool(power_of_two)
+        if self.power_of_two:
+            self.next_fast_len = self._next_power_of_two
 
     def __call__(self, shape, dtype, direction='forward', axis=0, ortho=False,
                  sample_rate=None):
-        if np.dtype(dtype) != np.complex64:
-            raise TypeError("the hip engine transforms complex64 data only.")
-        return HipFFT(tuple(shape), operator.index(axis), direction, ortho, sample_rate)
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the hip engine transforms complex64 and float32 data only.")
+        return HipFFT(tuple(shape), dtype, operator.index(axis), direction, ortho, sample_rate)
 
     @staticmethod
     def next_fast_len(n):
-        """Smallest supported block length >= n (a power of two >= 256)."""
+        """Smallest 2^a 3^b 5^c 7^d >= n -- the rule of the reference's NumPy
+        engine (fourier/numpy.py:99-126), so that default block lengths agree."""
+        n = operator.index(n)
+        if n <= 7:
+            return n
+        best = None
+        p7 = 1
+        while best is None or p7 < best:
+            p57 = p7
+            while best is None or p57 < best:
+                p357 = p57
+                while best is None or p357 < best:
+                    # smallest power of two that lifts p357 to >= n
+                    need = -(-n // p357)
+                    cand = p357 << max(need - 1, 0).bit_length()
+                    if best is None or cand < best:
+                        best = cand
+                    if p357 >= n:
+                        break
+                    p357 *= 3
+                if p57 >= n:
+                    break
+                p57 *= 5
+            if p7 >= n:
+                break
+            p7 *= 7
+        if best > MAX_BLOCK_LEN:
+            raise ValueError(f"block length {n} needs a transform of {best} points; this "
+                             f"build supports up to {MAX_BLOCK_LEN} (reduce samples_per_frame "
+                             "or the padding).")
+        return best
+
+    @staticmethod
+    def _next_power_of_two(n):
         n = operator.index(n)
         fast = MIN_FFT_LEN
         while fast < n:
             fast *= 2
-        if fast > MAX_BLOCK_LEN:
-            raise ValueError(f"block length {n} needs a transform of {fast} points; this "
-                             f"build supports up to {MAX_BLOCK_LEN} (reduce samples_per_frame "
-                             "or the padding).")
+        if fast > (1 << 24):
+            raise ValueError(f"block length {n} needs a transform of {fast} points; the "
+                             "power-of-two path supports up to 2^24.")
         return fast
 
     def __repr__(self):
-        return "HipFFTMaker()"
+        return f"HipFFTMaker(power_of_two={self.power_of_two})"
 
 
 class _FFTMakerState:

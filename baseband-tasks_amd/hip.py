@@ -61,6 +61,7 @@ SIGNATURES = {
     'bbt_osm_plan_create': [_pvp, _i64, _int, _int, _vp, _int, _pi32],
     'bbt_osm_plan_destroy': [_vp],
     'bbt_osm_plan_info': [_vp, _pi64, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
+    'bbt_osm_plan_fusable': [_vp, _int],
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
@@ -481,6 +482,10 @@ class OsmPlan(_Plan):
         check(lib().bbt_osm_plan_info(self._h, C.byref(ws), C.byref(chunk), C.byref(n1),
                                       C.byref(n2)))
         return dict(workspace_bytes=ws.value, chunk_blocks=chunk.value, n1=n1.value, n2=n2.value)
+
+    def fusable(self, n_chan):
+        """Can `execute_channelized` take Channelize(n_chan) into the row pass?"""
+        return bool(lib().bbt_osm_plan_fusable(self._h, int(n_chan)))
 
     def execute(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
         in_off = np.ascontiguousarray(in_off, dtype=np.int64)

@@ -98,7 +98,11 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  *
  *   n_fft       block length N (= PaddedTaskBase._ih_samples_per_frame),
  *               a power of two, 256 <= N <= 2^24 (one kernel up to 4096,
- *               two-level four-step up to 2^20, three-level above)
+ *               two-level four-step up to 2^20, three-level above): the fast
+ *               path; or any N = 2^a 3^b 5^c 7^d -- the lengths the
+ *               reference's NumPy engine picks (fourier/numpy.py:99-126,
+ *               block rule base.py:750-758) -- that is <= 8192 or splits
+ *               into two such factors <= 8192 (generic LDS Stockham path)
  *   n_stream    S, even
  *   n_resp      number of distinct response columns C
  *   resp        C x N complex64, FFT-natural order, UNSCALED
@@ -120,6 +124,10 @@ int bbt_osm_plan_destroy(bbt_osm_plan* plan);
  * processes per kernel launch. */
 int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* chunk_blocks,
                       int* n1, int* n2);
+/* 1 if bbt_osm_execute_channelized can take Channelize(n_chan) into this
+ * plan's row pass (power-of-two block of two or three levels, n_chan a power
+ * of two in [256, 4096] dividing the row length), else 0. */
+int bbt_osm_plan_fusable(const bbt_osm_plan* plan, int n_chan);
 /* Process n_blocks overlap-save blocks.  Block b reads input complete
  * samples [in_off[b], in_off[b] + N) of `in_dev` and writes block samples
  * [valid_start[b], valid_start[b] + valid_count[b]) to output complete
@@ -181,7 +189,8 @@ int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
  * n_chan consecutive complete samples; in (n_spectra*n_chan, S) ->
  * out (n_spectra, n_chan, S).  direction -1: forward, unnormalised
  * (Channelize); +1: inverse, scaled by 1/n_chan (Dechannelize,
- * channelize.py:164-165).  n_chan a power of two, 2..4096. */
+ * channelize.py:164-165).  n_chan a power of two, 2..4096 (fast path), or
+ * any 2^a 3^b 5^c 7^d <= 8192. */
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction);
 int bbt_chan_plan_destroy(bbt_chan_plan* plan);
 int bbt_chan_execute(bbt_chan_plan* plan, const void* in_dev, void* out_dev, int64_t n_spectra,

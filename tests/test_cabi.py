@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_argument_validation_reports_errors():
     lib = hip.lib()
     plan = C.c_void_p()
-    assert lib.bbt_chan_plan_create(C.byref(plan), 1000, 2, -1) != 0
+    assert lib.bbt_chan_plan_create(C.byref(plan), 1001, 2, -1) != 0      # 7 x 11 x 13
     assert b'power of two' in lib.bbt_last_error()
     assert lib.bbt_chan_plan_create(C.byref(plan), 1024, 3, -1) != 0
     assert b'even' in lib.bbt_last_error()
@@ -41,8 +41,8 @@ def test_argument_validation_reports_errors():
     assert lib.bbt_pfb_plan_create(C.byref(plan), 0, 1024, 2,
                                    taps.ctypes.data_as(C.POINTER(C.c_float))) != 0
     assert b'n_tap' in lib.bbt_last_error()
-    resp = np.zeros((1, 300), np.complex64)
-    assert lib.bbt_osm_plan_create(C.byref(plan), 300, 2, 1, resp.ctypes.data, 0, None) != 0
+    resp = np.zeros((1, 311), np.complex64)
+    assert lib.bbt_osm_plan_create(C.byref(plan), 311, 2, 1, resp.ctypes.data, 0, None) != 0      # prime
     assert b'power of two' in lib.bbt_last_error()
     assert lib.bbt_osm_plan_create(C.byref(plan), 2**25, 2, 1, resp.ctypes.data, 0, None) != 0
     idx = np.array([0, 5], np.int32)
@@ -71,7 +71,8 @@ def test_argument_validation_reports_errors():
 def test_python_wrappers_raise():
     import pytest
     with pytest.raises(hip.HipError, match='power of two'):
-        hip.ChanPlan(100, 2)
+        hip.ChanPlan(22, 2)
+    assert hip.OsmPlan.fusable.__doc__
     d = hip.DeviceArray.__new__(hip.DeviceArray)      # views without touching the device
     d.shape, d.dtype, d.ptr, d.owner = (10, 4), np.dtype(np.complex64), 1 << 20, None
     v = d[2:5]
@@ -97,7 +98,7 @@ def test_sanitized_host_build_passes_the_abi_checks():
         pytest.skip('no hipcc: cannot make the sanitizer build here')
     lib = os.path.join(ROOT, 'build', 'libbbt_hip_asan.so')
     src = [os.path.join(ROOT, 'baseband-tasks_amd', 'csrc', f)
-           for f in ('bbt_hip.hip', 'bbt_kernels.hpp', 'fft_core.hpp', 'fft_generic.hpp')]
+           for f in ('bbt_hip.hip', 'bbt_kernels.hpp', 'fft_core.hpp', 'fft_generic.hpp', 'gen_kernels.hpp')]
     src = [f for f in src if os.path.exists(f)] + [os.path.join(ROOT, 'include', 'bbt_hip.h')]
     if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in src):
         subprocess.check_call([script], stdout=subprocess.DEVNULL)

@@ -181,6 +181,81 @@ def test_small_dedisperse_two_sidebands_golden(golden):
     assert_parity(dd.read(), golden['sb_out'], 'sb')
 
 
+@pytest.mark.parametrize('tag,kw', [('sa', {}), ('sc', dict(reference_frequency=300.4 * u.MHz)),
+                                    ('sd', dict(reference_frequency=300.7 * u.MHz))])
+def test_reference_default_geometry_golden(golden, tag, kw):
+    """Default arguments give the reference's own block geometry -- here
+    6174-sample blocks (2 x 3^2 x 7^3, fourier/numpy.py:99-126 via base.py:750-758)
+    -- and the complete outputs the reference produced with it."""
+    nh = noise(10000, (2,), 4000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,
+               sideband=np.array([1, -1]))
+    dd = bt.Dedisperse(nh, 5., **kw)
+    assert [dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame,
+            dd.shape[0], dd._sample_offset] == list(golden[tag + '_geo'])
+    assert dd._ih_samples_per_frame & (dd._ih_samples_per_frame - 1)       # not a power of two
+    assert abs((dd.start_time - nh.start_time) * 1e6 - golden[tag + '_shift'][0]) < 1e-4
+    assert_parity(dd.read(), golden[tag + '_out'], tag)
+
+
+@pytest.mark.parametrize('n_fft', [6, 60, 210, 1000, 2187, 6174, 7203, 8192,           # one workgroup
+                                   8232, 19200, 19324 + 6404, 2 * 3**9, 131250, 1049760])  # two factors
+def test_block_lengths_that_are_not_powers_of_two(n_fft):
+    """Overlap-save blocks of every kind of 2^a 3^b 5^c 7^d length against the
+    oracle (random response, so every bin matters; three streams)."""
+    assert HipFFTMaker.next_fast_len(n_fft) == n_fft
+    n_tap = max(2, min(n_fft // 3, 40000))
+    rng = np.random.default_rng(n_fft)
+    resp = (rng.standard_normal((n_tap, 3)) + 1j * rng.standard_normal((n_tap, 3))) / np.sqrt(n_tap)
+    n_in = 2 * n_fft + n_fft // 2 + 5
+    x = (rng.standard_normal((n_in, 6), dtype=np.float32)).view(np.complex64)
+    ds = bt.DeviceStream(x, T0, 1 * u.MHz)
+    limit = bt.Convolve.FIR_MAX_TAPS_COMPLEX
+    bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0           # the Fourier-domain plan, not the direct FIR
+    try:
+        cv = bt.Convolve(ds, resp.astype(np.complex64), samples_per_frame=n_fft - n_tap + 1)
+        assert cv._ih_samples_per_frame == n_fft
+        got = cv.read()
+    finally:
+        bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
+    want, info = orc.convolve(x, resp.astype(np.complex64), samples_per_frame=n_fft - n_tap + 1,
+                              ih_samples_per_frame=1000)
+    assert info['ih_spf'] == n_fft
+    assert_parity(got, want, f'n_fft {n_fft}')
+
+
+def test_config5_at_the_references_default_block():
+    """Config 5 with default arguments: Resample picks 1 049 760 = 2^5 3^8 5
+    sample blocks, Dedisperse on top keeps 2^20."""
+    n_in = 2 * 1049760 + 3000
+    rng = np.random.default_rng(55)
+    x = rng.standard_normal((n_in, 4), dtype=np.float32).view(np.complex64)        # 2 streams
+    ds = bt.DeviceStream(x, T0, 16 * u.MHz, samples_per_frame=2**20, frequency=1000 * u.MHz, sideband=1)
+    limit = bt.Convolve.FIR_MAX_TAPS
+    bt.Convolve.FIR_MAX_TAPS = 0
+    try:
+        rs = bt.Resample(ds, 0.25, pad=64)
+        assert rs._ih_samples_per_frame == 1049760
+        rs.seek(0)
+        got = rs.read()
+    finally:
+        bt.Convolve.FIR_MAX_TAPS = limit
+    want, info = orc.resample(x, 0.25, pad=64, ih_samples_per_frame=2**20)
+    assert info['ih_spf'] == 1049760
+    assert_parity(got, want, 'resample, default block')
+
+
+@pytest.mark.parametrize('n', [3, 5, 6, 7, 12, 100, 360, 1000, 1029, 3000, 6561, 8192])
+def test_channel_counts_that_are_not_powers_of_two(n):
+    for shape in ((2,), (3,), (8, 2)):
+        nh = noise(5 * n + 3, shape, 1000, seed=23, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
+        x = orc.noise_stream(23, 0, 5 * n + 3, 1000, shape)
+        ch = bt.Channelize(nh, n, samples_per_frame=2)
+        z = ch.read()
+        assert_parity(z, orc.channelize(x[:z.shape[0] * n], n), f'n={n} streams {shape}')
+        back = bt.Dechannelize(ch).read()
+        assert_parity(back, x[:back.shape[0]], f'round trip n={n} streams {shape}')
+
+
 @pytest.mark.parametrize('ref_mhz', [None, 300.4, 300.7, 299.2])
 def test_small_dedisperse_reference_frequencies(ref_mhz):
     """Reference frequency inside, at and outside the band (sample_offset != 0),
@@ -631,7 +706,23 @@ def test_fft_engine_seam():
     fb = bt.fft_maker(c.shape, 'complex64', direction='backward', axis=2)
     assert rel_l2(fb(c), np.fft.ifft(c.astype(np.complex128), axis=2)) < REL_L2_TOL
     with pytest.raises(ValueError):
-        bt.fft_maker((100,), 'complex64')
+        bt.fft_maker((101,), 'complex64')               # 101 is prime: not a 2^a 3^b 5^c 7^d length
+    # lengths that are not powers of two, and real data (rfft / irfft shapes,
+    # reference fourier/base.py:313-340, fourier/numpy.py:41-49)
+    d = (rng.normal(size=(4, 1000, 2)) + 1j * rng.normal(size=(4, 1000, 2))).astype(np.complex64)
+    fd = bt.fft_maker(d.shape, 'complex64', axis=1)
+    assert rel_l2(fd(d), np.fft.fft(d.astype(np.complex128), axis=1)) < REL_L2_TOL
+    for n in (1000, 945, 512):
+        r = rng.normal(size=(3, n, 4)).astype(np.float32)
+        fr = bt.fft_maker(r.shape, 'float32', axis=1, sample_rate=2.)
+        assert fr.frequency_shape == (3, n // 2 + 1, 4) and fr.frequency_dtype == np.complex64
+        assert np.allclose(fr.frequency[:, 0], np.fft.rfftfreq(n, 0.5))
+        fz = fr(r)
+        assert fz.shape == fr.frequency_shape
+        assert rel_l2(fz, np.fft.rfft(r.astype(np.float64), axis=1)) < REL_L2_TOL
+        back = fr.inverse()(fz)
+        assert back.dtype == np.float32 and back.shape == r.shape
+        assert np.linalg.norm(back - r) / np.linalg.norm(r) < REL_L2_TOL
 
 
 # --------------------------------------------------------------------------- BASELINE sizes: size-independent properties

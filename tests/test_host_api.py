@@ -171,10 +171,20 @@ def test_padded_task_base_blocks_like_the_oracle():
     with pytest.warns(UserWarning, match='inefficient'):
         _HostPadded(nh, 30, 30, samples_per_frame=10)
     # next_fast_len table of the hip engine
-    assert [HipFFTMaker.next_fast_len(n) for n in (1, 256, 257, 19324 + 6401, 2**20, 2**20 + 1)] == \
+    # (the reference's rule, fourier/numpy.py:99-126; known answers tests/test_base.py:522-529 style)
+    assert [HipFFTMaker.next_fast_len(n) for n in (1, 7, 11, 256, 257, 19324 + 6401, 2**20, 2**20 + 1,
+                                                   2**20 + 128, 1000003)] == \
+        [1, 7, 12, 256, 270, 25725, 2**20, 1049760, 1049760, 1000188]
+    for n in list(range(1, 400)) + [5000, 65537, 10**6 + 7, 2**24 - 1]:
+        assert HipFFTMaker.next_fast_len(n) == orc.next_fast_len(n)
+    with pytest.raises(ValueError):
+        HipFFTMaker.next_fast_len(2**26 + 1)
+    # the explicit power-of-two option (fast kernels, not the reference's geometry)
+    pow2 = HipFFTMaker(power_of_two=True)
+    assert [pow2.next_fast_len(n) for n in (1, 256, 257, 19324 + 6401, 2**20, 2**20 + 1)] == \
         [256, 256, 512, 32768, 2**20, 2**21]
     with pytest.raises(ValueError):
-        HipFFTMaker.next_fast_len(2**24 + 1)
+        pow2.next_fast_len(2**24 + 1)
 
 
 # --------------------------------------------------------------------------- geometry of the GPU tasks vs the reference
@@ -250,11 +260,13 @@ def test_channelize_pfb_resample_geometry(golden):
     assert ch.frequency.shape == (1024, 1)
     np.testing.assert_allclose(ch.frequency[[0, 1, 511, 512, 1023], 0] / 1e6, golden['c2ch_freq'],
                                rtol=1e-15)
-    with pytest.raises(ValueError):
-        bt.Channelize(nh, 1000)
+    assert bt.Channelize(nh, 1000).shape == (2 * 2**20 // 1000, 1000, 2)   # any 2^a 3^b 5^c 7^d count
     assert bt.Channelize(nh, 64).shape == (2 * 2**20 // 64, 64, 2)     # short transforms are fine
+    assert bt.Channelize(nh, 8192).shape == (256, 8192, 2)
     with pytest.raises(ValueError):
-        bt.Channelize(nh, 8192)
+        bt.Channelize(nh, 1001)                                        # 7 x 11 x 13
+    with pytest.raises(ValueError):
+        bt.Channelize(nh, 16384)
     with pytest.raises(TypeError):
         bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f8'), 256)
     real = bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f4'), 256)
