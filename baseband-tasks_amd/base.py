@@ -383,6 +383,11 @@ class TaskBase(BaseTaskBase):
         else:
             sample_rate = u.to_hz(sample_rate)
             ratio = ih_rate / sample_rate
+            # rates here are floats in Hz: (fs / 7) * 7 is not fs to the last bit, so snap
+            # a ratio within rounding of an integer (or of 1 / integer) onto it
+            nearest = float(round(ratio)) if ratio >= 1. else 1. / max(round(1. / ratio), 1)
+            if abs(nearest - ratio) <= 1e-12 * ratio:
+                ratio = nearest
         if samples_per_frame is None:
             if ih_samples_per_frame is None:
                 ih_samples_per_frame = ih.samples_per_frame

@@ -494,6 +494,11 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
         return 0;                                       \
     }
     BBT_RP(256, 0) BBT_RP(512, 0) BBT_RP(1024, 0) BBT_RP(2048, 0) BBT_RP(4096, 0)
+    BBT_RP(256, 16) BBT_RP(256, 32) BBT_RP(256, 64) BBT_RP(256, 128)
+    BBT_RP(512, 16) BBT_RP(512, 32) BBT_RP(512, 64) BBT_RP(512, 128)
+    BBT_RP(1024, 16) BBT_RP(1024, 32) BBT_RP(1024, 64) BBT_RP(1024, 128)
+    BBT_RP(2048, 16) BBT_RP(2048, 32) BBT_RP(2048, 64) BBT_RP(2048, 128)
+    BBT_RP(4096, 16) BBT_RP(4096, 32) BBT_RP(4096, 64) BBT_RP(4096, 128)
     BBT_RP(256, 256)
     BBT_RP(512, 256) BBT_RP(512, 512)
     BBT_RP(1024, 256) BBT_RP(1024, 512) BBT_RP(1024, 1024)
@@ -605,6 +610,32 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
     return 0;
 }
 
+// 4096-point column pass (blocks longer than 2^20): first pass with the lanes
+// of a row over 4 neighbouring columns of one pair (64-byte runs of the work
+// buffer), last pass over 4 pairs of one column when there are that many
+// (64-byte runs of the output); BBT_COL4096_PP: bit 0 / bit 1 switch the first /
+// last pass to the other arrangement.
+template <bool FIRST, bool SPEC>
+static int launch_col4096(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
+                          const OsmChunk& ch, const SpecOut& so, hipStream_t st) {
+    constexpr size_t lds = FftGeo<4096>::LDS_ELEMS * sizeof(v2) * 4;
+    static const int flip = [] { const char* e = getenv("BBT_COL4096_PP"); return e ? atoi(e) : 0; }();
+    bool pairs = FIRST ? false : true;
+    if (flip & (FIRST ? 1 : 2)) pairs = !pairs;
+    if (pairs && p->npair % 4 == 0) {
+        if (ensure_dyn_lds((const void*)k_osm_col4096<FIRST, SPEC, 4>, lds)) return 1;
+        hipLaunchKernelGGL((k_osm_col4096<FIRST, SPEC, 4>), dim3(p->n2 * (p->npair / 4), ch.nblk),
+                           dim3(1024), lds, st, in, out, work, ch, p->S, p->n2, p->tab1.tw0,
+                           p->tab1.tw1, so);
+    } else {
+        if (ensure_dyn_lds((const void*)k_osm_col4096<FIRST, SPEC, 1>, lds)) return 1;
+        hipLaunchKernelGGL((k_osm_col4096<FIRST, SPEC, 1>), dim3(p->n2 / 4 * p->npair, ch.nblk),
+                           dim3(1024), lds, st, in, out, work, ch, p->S, p->n2, p->tab1.tw0,
+                           p->tab1.tw1, so);
+    }
+    return 0;
+}
+
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
                          const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
@@ -664,6 +695,14 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             HIP_TRY(hipEventRecord(e[1], st));
             HIP_TRY(hipEventRecord(e[2], st));
         }
+    } else if (p->n1 == 4096) {
+        if (launch_col4096<true, false>(p, in, out, work, ch, so, st)) return 1;
+        if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+        if (launch_rowpass(p, work, ch, nch, st)) return 1;
+        if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+        if (nch ? launch_col4096<false, true>(p, in, out, work, ch, so, st)
+                : launch_col4096<false, false>(p, in, out, work, ch, so, st))
+            return 1;
     } else if (p->outer > 1) {
         // three levels: outer 256-point column pass over rows of M = 16 * n2, then
         // the two-level machinery in place on every outer row
@@ -816,11 +855,13 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         p->n1 = 16;
     } else if (n_fft <= (1 << 20)) {
         p->n1 = 256;
-    } else {
-        p->outer = 256;
+    } else if (const char* env = getenv("BBT_OSM_THREE_LEVEL"); env && atoi(env)) {
+        p->outer = 256;          // the older three-level scheme 256 x 16 x N2, kept for comparison
         p->n1 = 16;
         if (n_stream / 2 > 255)
             return bail(fail("bbt_osm_plan_create: blocks longer than 2^20 support at most 510 streams"));
+    } else {
+        p->n1 = 4096;            // 4096 x N2, N2 = 512 .. 4096
     }
     p->n2 = (int)(n_fft / p->n1 / p->outer);
     if (p->generic) {
@@ -835,6 +876,7 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     } else {
         if (get_tables(p->n2, &p->tab2)) return bail(1);
         if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
+        if (p->n1 == 4096 && get_tables(4096, &p->tab1)) return bail(1);
         if (get_wroot(&p->wroot)) return bail(1);
     }
 
@@ -883,6 +925,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         while (chunk > 1 && (long long)chunk * p->npair * p->outer > 65535) --chunk;
         if (chunk * per_block * lanes > (768u << 20)) lanes = 1;
     }
+    while (chunk > 1 && (long long)chunk * p->npair > 65535) --chunk;      // grid.y of the row pass
+    if ((double)chunk * per_block * lanes > 16.0 * (1u << 30)) lanes = 1;   // (config 4: 2 x 2 GiB)
     p->chunk = chunk;
     p->lanes = lanes;
     if (p->n1 > 1) {
@@ -942,6 +986,8 @@ int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chun
 int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     // can bbt_osm_execute_channelized take Channelize(n_chan) into the row pass?
     if (!p || p->generic || (p->n1 == 1 && p->outer == 1)) return 0;
+    if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
+        return p->outer == 1 && (p->n1 == 256 || p->n1 == 4096);            // exchange in the row pass
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
 }
 
@@ -977,8 +1023,11 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
             who, (long long)p->n);
     ARG_TRY(p->n1 > 1 || p->outer > 1, "%s: block length %lld is too short to fuse", who,
             (long long)p->n);
-    ARG_TRY(fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0,
-            "%s: n_chan=%d must be a power of two in [256, %d]", who, n_chan, p->n2);
+    ARG_TRY(bbt_osm_plan_fusable(p, n_chan),
+            "%s: n_chan=%d must be a power of two in [256, %d] (or 16..128 for blocks of two levels "
+            "with 256 or 4096 columns)", who, n_chan, p->n2);
+    const bool small = n_chan < 256;
+    ARG_TRY(!(small && det_step > 0), "%s: fused detection needs n_chan >= 256", who);
     ARG_TRY(first_spectrum >= 0 && n_spectra >= 0, "%s: bad spectrum range", who);
     if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
     for (int64_t b = 0; b < n_blocks; ++b)
@@ -987,7 +1036,11 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
     if (n_blocks == 0 || n_spectra == 0) return 0;
     std::lock_guard<std::mutex> lock(p->mu);
     FftTables tabc;
-    if (get_tables(n_chan, &tabc)) return 1;
+    GenGeo gsmall = {};
+    cf* wsmall = nullptr;
+    if (small ? (!factor_7smooth(n_chan, &gsmall) || get_gen_table(n_chan, &wsmall))
+              : get_tables(n_chan, &tabc))
+        return 1;
     // seam slots and jobs
     const size_t need = (size_t)n_blocks * 2 * p->npair * n_chan * 16;
     if (need > p->seam_bytes) {
@@ -1017,6 +1070,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
     so.lg_chan = 0;
     while ((1 << so.lg_chan) < n_chan) ++so.lg_chan;
     so.n_fft = (int)p->n;
+    so.small_l = small ? n_chan / 16 : 0;
     if (det_step > 0) {
         so.det = (float*)out_dev;
         so.det_step = det_step;
@@ -1036,7 +1090,17 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
                         blk.index = (int)b;
                     }))
         return 1;
-    if (!jobs.empty()) {
+    if (!jobs.empty() && small) {
+        const size_t lds = (size_t)2 * n_chan * sizeof(f4);
+        for (size_t j0 = 0; j0 < jobs.size(); j0 += BBT_SEAM_JOBS_PER_LAUNCH) {
+            SeamJobs batch;
+            const size_t n = std::min(jobs.size() - j0, (size_t)BBT_SEAM_JOBS_PER_LAUNCH);
+            for (size_t i = 0; i < n; ++i) batch.j[i] = jobs[j0 + i];
+            hipLaunchKernelGGL(k_seam_fix_gen, dim3((unsigned)n, p->npair), dim3(gen_threads(2 * n_chan)),
+                               lds, st, p->seam, (float2*)out_dev, batch, p->S, p->npair, gsmall, wsmall, so);
+        }
+        HIP_TRY(hipGetLastError());
+    } else if (!jobs.empty()) {
         switch (n_chan) {
             case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, so, st); break;
             case 512: launch_seam_fix<512>(p, (float2*)out_dev, jobs, tabc, so, st); break;

@@ -181,7 +181,20 @@ struct SpecOut {
     int det_step;
     int det_mode;        // 0 |z|^2 per stream, 1 (|X|^2, |Y|^2, Re XY*, Im XY*) per pair
     float det_scale;
+    // n_chan < 256: the row pass leaves channel a + 16 bitrev_L(c) of group q at
+    // row position (L q + c) + T a, L = n_chan / 16, T = N2 / 16 (k_osm_rowpass)
+    int small_l;         // 0: natural order (position == q * n_chan + channel)
 };
+
+// Row position -> q * n_chan + channel for the small-channel-count layout.
+__device__ __forceinline__ int small_channel_slot(int pos, int N2, const SpecOut& so) {
+    if (!so.small_l) return pos;
+    const int L = so.small_l, T = N2 >> 4;
+    const int a = pos / T, t = pos - a * T;
+    const int q = t / L, c = t - q * L;
+    const int r = L == 1 ? 0 : (int)(__brev((unsigned)c) >> (32 - (31 - __clz(L))));
+    return q * so.n_chan + a + 16 * r;
+}
 
 // floats a pair contributes per (bin, channel): 2 (mode 0) or 4 (mode 1)
 __device__ __forceinline__ float4 detect_pair(c2 z, int mode) {
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
         wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
         SpecCursor cur;
-        if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, n2, S, sp, npair);
+        if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, N2, so), S, sp, npair);
         if constexpr (SPEC && DET) {
             // Detection + integration instead of storing spectra.  The workgroup
             // holds, for each of its FCOL channels, every (N2 / n_chan)-th of
@@ -488,6 +501,56 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                 const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
                     st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
+            }
+        }
+    }
+}
+
+// Column pass, N1 == 4096 (blocks longer than 2^20 as 4096 x N2, N2 = 512 ..
+// 4096): one 4096-point transform is 256 threads x 16 points; a 1024-thread
+// workgroup runs four of them interleaved in LDS (136 KiB), the four lanes of a
+// row being PP stream pairs x 4 / PP neighbouring columns:
+//   PP == 1: 64-byte runs of the work buffer (16-byte pieces of the stream,
+//            merged in L2 with the other pairs' workgroups, which run beside it)
+//   PP == 4: 64-byte runs of the stream (one complete sample of 4 pairs), 16-byte
+//            pieces of four work buffers
+template <bool FIRST, bool SPEC, int PP>
+__global__ __launch_bounds__(1024) void k_osm_col4096(const float2* __restrict__ in,
+                                                      float2* __restrict__ out,
+                                                      float2* __restrict__ work, OsmChunk ch, int S,
+                                                      int N2, const cf* __restrict__ tw0,
+                                                      const cf* __restrict__ tw1, SpecOut so) {
+    typedef FftGeo<4096> G;
+    constexpr int F = 4, T = 256, CPT = F / PP;
+    extern __shared__ v2 col4096_lds[];                  // G::LDS_ELEMS * F elements
+    const int f = threadIdx.x % F, tau = threadIdx.x / F;
+    const int npair = S >> 1, npg = npair / PP;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n2 = (vb / npg) * CPT + f / PP;
+    const int b = blockIdx.y, sp = (vb % npg) * PP + f % PP;
+    const OsmBlock blk = ch.b[b];
+    float2* w = work + (((long long)(b * npair + sp) * 4096 + tau) * N2 + n2) * 2;
+    c2 v[16];
+    if (FIRST) {
+        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * N2 * S);
+        wg_fft<4096, -1, F>(v, col4096_lds, tau, f, tw0, tw1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st_int(w + (long long)T * j * N2 * 2, v[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)T * j * N2 * 2);
+        wg_fft<4096, +1, F>(v, col4096_lds, tau, f, tw0, tw1);
+        SpecCursor cur;
+        if (SPEC) cur = spec_cursor(out, so, blk, tau, T, N2, small_channel_slot(n2, N2, so), S, sp, npair);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (SPEC) {
+                emit_spectrum(v[j], cur, j);
+            } else {
+                const long long r = (long long)(tau + T * j) * N2 + n2 - blk.valid_start;
+                if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
             }
         }
     }
@@ -578,12 +641,18 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
         sincospif(ang, &s, &c);
         base = make_float2(c, s);
     }
-    const int M = 16 * N1;          // <= 4096
-    const int rstride = 4096 / M;
+    // W_{16 N1}^{k1 j}: from the W_4096 table for N1 <= 256, else (N1 = 4096: blocks longer
+    // than 2^20 as 4096 x N2) as W_65536^x = W_256^{x >> 8} W_65536^{x & 255}
+    const int M = 16 * N1;
+    const int rstride = M <= 4096 ? 4096 / M : 0;
+    auto wrow = [&](int j) -> cf {
+        const int x = (k1 * j) & (M - 1);
+        if (M <= 4096) return wroot[x * rstride];
+        return cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
+    };
     if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            v[j] = twmul<-1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
+        for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, wrow(j)));
     }
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
@@ -623,23 +692,76 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
         for (int j = 0; j < 16; ++j) {
             const int x = k1o * j;                          // < 4096
             const cf wo = cmul(wroot[(x >> 8) * 16], wfine[x & 255]);     // W_65536^x
-            const cf wi = wroot[((k1 * j) & (M - 1)) * rstride];
+            const cf wi = wrow(j);
             v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
         }
     } else if (N1 > 1) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            v[j] = twmul<+1>(v[j], cmul(base, wroot[((k1 * j) & (M - 1)) * rstride]));
+        for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(base, wrow(j)));
     }
     if constexpr (NCH == 0) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(row + (long long)(tau + T * j) * 2, v[j]);
+    } else if constexpr (NCH < 256) {
+        // Few channels, NCH = 16 L (L = 1, 2, 4, 8): a group of NCH consecutive
+        // samples n2 is spread over the lanes (register j of thread tau is
+        // n2 = tau + T j), so one more exchange through LDS hands thread
+        // t' = L q + c the 16 samples c + L i (i < 16) of group q; radix-16 over
+        // i on registers, twiddle W_NCH^{c a}, then the radix-L step over c
+        // across L neighbouring lanes with wavefront shuffles.  Lane c ends up
+        // with channels a + 16 bitrev_L(c); they are stored at row position
+        // t' + T a (coalesced), which the column pass maps back
+        // (small_channel_slot below).  LDS pitch: L extra slots per group, so the
+        // strided reads are conflict free.
+        constexpr int L = NCH / 16;
+        static_assert(NCH == 16 * L && (L == 1 || L == 2 || L == 4 || L == 8), "NCH must be 16..128");
+        static_assert(N2 + N2 / 16 <= G::LDS_ELEMS, "exchange area too small");
+        const int q = tau / L, c = tau % L;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n2 = tau + T * j;
+                lds[n2 + (n2 >> 4)] = half ? v[j].im : v[j].re;        // L (n2 / (16 L)) + n2 % ... == n2 + n2 / 16 rounded per group
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n2 = NCH * q + c + L * i;
+                const v2 x = lds[n2 + (n2 >> 4)];
+                if (half) v[i].im = x; else v[i].re = x;
+            }
+        }
+        radix16<-1>(v);
+        if constexpr (L > 1) {
+#pragma unroll
+            for (int a = 1; a < 16; ++a) v[a] = twmul<-1>(v[a], wroot[(c * a) * (4096 / NCH)]);
+            // DIF over the lane digit c: mask h = L/2, L/4, ..., 1
+#pragma unroll
+            for (int h = L / 2; h >= 1; h >>= 1) {
+                const bool upper = (c & h) != 0;
+                const cf w = wroot[((c & (h - 1)) * (L / (2 * h))) * (4096 / L)];     // W_{2h}^{c mod h}
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    c2 o;
+                    o.re.x = __shfl_xor(v[a].re.x, h);
+                    o.re.y = __shfl_xor(v[a].re.y, h);
+                    o.im.x = __shfl_xor(v[a].im.x, h);
+                    o.im.y = __shfl_xor(v[a].im.y, h);
+                    if (upper) v[a] = twmul<-1>(csub(o, v[a]), w);
+                    else v[a] = cadd(v[a], o);
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) st_int(row + (long long)(tau + T * a) * 2, v[a]);
     } else {
         // channelizer: thread tau holds n2 = tau + T j: group q = j / P, element
         // m = tau + T (j % P) of the NCH = P * T point transform.
         constexpr int NG = (NCH > 0) ? N2 / NCH : 1;     // groups per row
         constexpr int P = 16 / NG;                       // points per thread per group
-        static_assert(NCH == 0 || (NG * NCH == N2 && P * NG == 16), "NCH must divide N2, N2/NCH <= 16");
+        static_assert(NCH < 256 || (NG * NCH == N2 && P * NG == 16), "NCH must divide N2, N2/NCH <= 16");
         // stage 0: radix-P over the P points of each group, twiddle W_NCH^{tau c} = tw0[(c NG) T + tau]
 #pragma unroll
         for (int q = 0; q < NG; ++q) {

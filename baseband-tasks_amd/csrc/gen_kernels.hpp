@@ -151,4 +151,47 @@ __global__ __launch_bounds__(1024) void k_gen_fft_rows(const float2* __restrict_
     }
 }
 
+// Splice the spectrum that straddles a block seam (see k_seam_fix) for any
+// channel count n = g.n: both blocks' versions go through the inverse transform
+// side by side (tile of two), samples [0, split) are taken from the earlier
+// block, the rest from the later one, and the result is transformed again.
+// One workgroup per (seam, pair); 2 n elements of dynamic LDS.
+__global__ __launch_bounds__(1024) void k_seam_fix_gen(const float2* __restrict__ seam,
+                                                       float2* __restrict__ out, SeamJobs jobs, int S,
+                                                       int npair, GenGeo g,
+                                                       const cf* __restrict__ wn, SpecOut so) {
+    extern __shared__ f4 gen_lds[];
+    const int n = g.n, tid = threadIdx.x, nthr = blockDim.x, sp = blockIdx.y;
+    const SeamJob job = jobs.j[blockIdx.x];
+    const float2* za = seam + ((((long long)job.first_block * 2 + 1) * npair + sp) * n) * 2;
+    const float2* zb = seam + ((((long long)(job.first_block + 1) * 2 + 0) * npair + sp) * n) * 2;
+    for (int i = tid; i < n; i += nthr) {
+        gen_lds[2 * i] = ld_ext_f4(za + 2 * i);
+        gen_lds[2 * i + 1] = ld_ext_f4(zb + 2 * i);
+    }
+    __syncthreads();
+    gen_fft<+1>(gen_lds, g, 2, wn, tid, nthr);
+    const float scale = 1.0f / (float)n;
+    for (int i = tid; i < n; i += nthr) gen_lds[2 * i] = gen_lds[2 * i + (i < job.split ? 0 : 1)] * scale;
+    __syncthreads();
+    gen_fft<-1>(gen_lds, g, 2, wn, tid, nthr);
+    if (so.det) {
+        const long long bin = job.spectrum / so.det_step;
+        if (bin >= so.n_out / so.det_step) return;
+        for (int i = tid; i < n; i += nthr) {
+            const float4 pw = detect_pair(f4_to_c2(gen_lds[2 * i]), so.det_mode);
+            float* dst = so.det + detect_index(bin, i, sp, so.lg_chan, npair, so.det_mode);
+            unsafeAtomicAdd(dst + 0, pw.x * so.det_scale);
+            unsafeAtomicAdd(dst + 1, pw.y * so.det_scale);
+            if (so.det_mode) {
+                unsafeAtomicAdd(dst + 2, pw.z * so.det_scale);
+                unsafeAtomicAdd(dst + 3, pw.w * so.det_scale);
+            }
+        }
+        return;
+    }
+    float2* dst = out + ((job.spectrum * n) * S + 2 * sp);
+    for (int i = tid; i < n; i += nthr) st_ext_f4(dst + (long long)i * S, gen_lds[2 * i]);
+}
+
 }  // namespace bbt

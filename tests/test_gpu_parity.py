@@ -143,10 +143,12 @@ def test_fused_and_unfused_channelizer_agree(golden, monkeypatch):
     nh = noise(60000, (2,), 20000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,
                sideband=np.array([1, -1]))
     xs = orc.noise_stream(11, 0, 60000, 20000, (2,))
+    pow2 = HipFFTMaker(power_of_two=True)         # (the fused route needs power-of-two blocks)
     ys, info = orc.dedisperse(xs, 1e6, 300., np.array([1, -1]), 5., ih_samples_per_frame=20000,
-                              fast_len=HipFFTMaker.next_fast_len)
+                              fast_len=pow2.next_fast_len)
     monkeypatch.setattr(chmod, 'FUSE_WITH_OVERLAP_SAVE', True)
-    ch = bt.Channelize(bt.Dedisperse(nh, 5.), 256, samples_per_frame=5)
+    with bt.fft_maker.set(pow2):
+        ch = bt.Channelize(bt.Dedisperse(nh, 5.), 256, samples_per_frame=5)
     assert ch._fusable_input() is not None and info['ih_spf'] == 32768
     z = ch.read()
     assert_parity(z, orc.channelize(ys[:z.shape[0] * 256], 256), 'fused small')
@@ -198,7 +200,7 @@ def test_reference_default_geometry_golden(golden, tag, kw):
 
 
 @pytest.mark.parametrize('n_fft', [6, 60, 210, 1000, 2187, 6174, 7203, 8192,           # one workgroup
-                                   8232, 19200, 19324 + 6404, 2 * 3**9, 131250, 1049760])  # two factors
+                                   8232, 19200, 25725, 2 * 3**9, 131250, 1049760])  # two factors
 def test_block_lengths_that_are_not_powers_of_two(n_fft):
     """Overlap-save blocks of every kind of 2^a 3^b 5^c 7^d length against the
     oracle (random response, so every bin matters; three streams)."""
@@ -259,7 +261,7 @@ def test_channel_counts_that_are_not_powers_of_two(n):
 @pytest.mark.parametrize('ref_mhz', [None, 300.4, 300.7, 299.2])
 def test_small_dedisperse_reference_frequencies(ref_mhz):
     """Reference frequency inside, at and outside the band (sample_offset != 0),
-    default block size of the hip engine (power of two)."""
+    default block size (the reference's rule: 6174 or 5880 samples here)."""
     nh = noise(10000, (2,), 4000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,
                sideband=np.array([1, -1]))
     rf = None if ref_mhz is None else ref_mhz * u.MHz
@@ -416,8 +418,8 @@ def test_short_channelizer(n):
 
 def test_config4_subband_block_2_24():
     """Config 4 (SURVEY 8d restatement), ONE sub-band: 6.25 MHz at 403.125 MHz,
-    DM 557, blocks of 2^24 samples (three-level transform), then Channelize(64);
-    plain and fused-capable channel counts."""
+    DM 557, blocks of 2^24 samples (4096 x 4096), then Channelize(64) and
+    Channelize(4096), both folded into the row pass."""
     n_fft, spf = 2**24, 2**24 - 2756522
     n_in = n_fft + 3 * 2**20              # one full block and a re-aligned final one
     rng = np.random.default_rng(4)
@@ -433,7 +435,7 @@ def test_config4_subband_block_2_24():
     for n in (64, 4096):
         dd.seek(0)
         ch = bt.Channelize(dd, n, samples_per_frame=16)
-        assert (ch._fusable_input() is not None) == (n == 4096)
+        assert ch._fusable_input() is dd
         z = ch.read()
         assert_parity(z, orc.channelize(want[:z.shape[0] * n], n), f'channelize {n}')
 
@@ -1163,21 +1165,96 @@ def test_convolve_equals_numpy_convolve():
         assert abs((cv.start_time - nh.start_time) * 1e3 - (n_tap - 1 - offset)) < 1e-9
 
 
-def test_three_level_blocks_with_sixteen_streams():
-    """2^21-sample blocks (three-level transform) x 16 streams: plain and
-    fused-channelizer outputs, pair-grouped column passes."""
+@pytest.mark.parametrize('three_level', [False, True])
+def test_blocks_longer_than_2_20_with_sixteen_streams(three_level, monkeypatch):
+    """2^21-sample blocks x 16 streams: plain and fused-channelizer outputs (256
+    and 64 channels), pair-grouped column passes.  Default: two levels,
+    4096 x 512; BBT_OSM_THREE_LEVEL=1: the older 256 x 16 x 512 scheme."""
+    if three_level:
+        monkeypatch.setenv('BBT_OSM_THREE_LEVEL', '1')
     n_fft = 2**21
     freq = (400. + 6.25 * np.arange(8)).reshape(8, 1) * u.MHz
     nh = noise(n_fft + 300000, (8, 2), 2**19, seed=63, fs=6.25 * u.MHz, frequency=freq, sideband=1)
     x = nh.read()
     dm = 60.
+    pow2 = HipFFTMaker(power_of_two=True)
     want, info = orc.dedisperse(x, 6.25e6, np.asarray(freq) / 1e6, 1, dm,
                                 reference_frequency_mhz=np.asarray(freq) / 1e6,
-                                ih_samples_per_frame=2**19, fast_len=HipFFTMaker.next_fast_len)
-    dd = bt.Dedisperse(nh, dm, reference_frequency=freq)
-    assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
-    assert_parity(dd.read(), want, 'three-level dedisperse, 16 streams')
-    ch = bt.Channelize(bt.Dedisperse(nh, dm, reference_frequency=freq), 256, 8)
-    assert ch._fusable_input() is not None
+                                ih_samples_per_frame=2**19, fast_len=pow2.next_fast_len)
+    with bt.fft_maker.set(pow2):
+        dd = bt.Dedisperse(nh, dm, reference_frequency=freq)
+        assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
+        assert dd._get_plan().info()['n1'] == (16 if three_level else 4096)
+        assert_parity(dd.read(), want, 'dedisperse, 16 streams')
+        for n in (256, 64) if not three_level else (256,):
+            ch = bt.Channelize(bt.Dedisperse(nh, dm, reference_frequency=freq), n, 8)
+            assert ch._fusable_input() is not None
+            z = ch.read()
+            assert_parity(z, orc.channelize(want[:z.shape[0] * n], n), f'fused channelizer {n}, 16 streams')
+
+
+@pytest.mark.parametrize('n_chan', [16, 32, 64, 128])
+@pytest.mark.parametrize('sample_shape', [(2,), (4, 2)])
+def test_fused_channelizer_with_few_channels(n_chan, sample_shape, monkeypatch):
+    """Channelize(n < 256) folded into the overlap-save plan (an extra exchange
+    plus wavefront shuffles in the row pass): equal to the oracle and to the
+    unfused route, seam spectra included; 2^17-sample blocks (256 x 512)."""
+    from baseband_tasks_amd import channelize as chmod
+    n = 2**17
+    nh0 = noise(4 * n, sample_shape, n, seed=91, fs=2 * u.MHz, frequency=400 * u.MHz, sideband=1)
+    spf = n - (lambda d: d._pad_start + d._pad_end)(bt.Dedisperse(nh0, 30.))
+    length = 3 * spf + n + 777
+    nh = noise(length, sample_shape, n, seed=91, fs=2 * u.MHz, frequency=400 * u.MHz, sideband=1)
+    x = orc.noise_stream(91, 0, length, n, sample_shape)
+    want_y, info = orc.dedisperse(x, 2e6, 400., 1, 30., samples_per_frame=spf, ih_samples_per_frame=n)
+    assert info['ih_spf'] == n
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(chmod, 'FUSE_WITH_OVERLAP_SAVE', fuse)
+        ch = bt.Channelize(bt.Dedisperse(nh, 30., samples_per_frame=spf), n_chan, samples_per_frame=37)
+        assert (ch._fusable_input() is not None) == fuse
+        z = ch.read()
+        assert_parity(z, orc.channelize(want_y[:z.shape[0] * n_chan], n_chan), f'fuse={fuse}')
+        k = spf // n_chan
+        ch.seek(k - 2)
+        assert np.array_equal(ch.read(5), z[k - 2:k + 3])
+        res[fuse] = z
+    assert rel_l2(res[True], res[False]) < 3e-7
+
+
+def test_config4_share_of_one_rank():
+    """Config 4 at its real size on one GPU: 8 sub-bands x 2 pol,
+    6.25 MHz each, DM 557, one 2^24-sample block plus a re-aligned final one,
+    Channelize(64) fused; three of the sub-bands against the oracle (float64
+    FFTs of 2^24 points take seconds each)."""
+    from baseband_tasks_amd import sharding
+    n_fft, spf = 2**24, 2**24 - 2756522
+    n_in = n_fft + 2**20
+    rng = np.random.default_rng(44)
+    x = rng.standard_normal((n_in, 8, 4), dtype=np.float32).view(np.complex64)       # (n, 8, 2)
+    band = (403.125e6 + 6.25e6 * np.arange(64)).reshape(64, 1)
+    freq = band[:8]
+    ds = bt.DeviceStream(x, T0, 6.25 * u.MHz, frequency=freq, sideband=1)
+    dd = sharding.SubbandDedisperse(ds, 557., band_frequency=band, band_reference_frequency=band,
+                                    reference_frequency=freq, samples_per_frame=spf)
+    assert (dd._pad_start, dd._pad_end, dd._ih_samples_per_frame) == (1362235, 1394287, n_fft)
+    assert dd._get_plan().info()['n1'] == 4096
+    ch = bt.Channelize(dd, 64, samples_per_frame=1024)
+    assert ch._fusable_input() is dd
     z = ch.read()
-    assert_parity(z, orc.channelize(want[:z.shape[0] * 256], 256), 'three-level fused channelizer, 16 streams')
+    assert z.shape == ((n_in - 2756522) // 64 // 1024 * 1024, 64, 8, 2)
+    for k in (0, 3, 7):
+        f0 = float(freq[k, 0]) / 1e6
+        want, info = orc.dedisperse(np.ascontiguousarray(x[:, k]), 6.25e6, f0, 1, 557.,
+                                    reference_frequency_mhz=f0, samples_per_frame=spf,
+                                    ih_samples_per_frame=2**20)
+        if k == 0:
+            assert (info['pad_start'], info['ih_spf']) == (1362235, n_fft)
+            wy = want
+        else:                  # the whole band's padding, not the sub-band's own
+            g = dict(pad_start=1362235, pad_end=1394287, ih_spf=n_fft, spf=spf,
+                     n_out=n_in - 2756522)
+            h = orc.chirp(n_fft, 6.25e6, f0, 1, -557., f0)
+            wy = orc.overlap_save(np.ascontiguousarray(x[:, k]), g,
+                                  lambda blk: orc.disperse_block(blk, h, 1362235, spf))
+        assert_parity(z[:, :, k], orc.channelize(wy[:z.shape[0] * 64], 64), f'sub-band {k}')
