@@ -1,6 +1,8 @@
 // libbbt_hip.so -- host side of the C ABI declared in include/bbt_hip.h.
 // Plans, twiddle tables, launch geometry; the kernels are in bbt_kernels.hpp.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1652,3 +1654,122 @@ extern "C" int bbt_fir_execute(bbt_fir_plan* p, const void* in_dev, void* out_de
     HIP_TRY(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// multi-GPU: one process per GPU, RCCL over xGMI.  The path
+// has no data-path collective; these are the two it uses around it: the
+// broadcast of the response (chirp) at plan time and the optional all-gather
+// of the outputs.  librccl is loaded on first use (dlopen), so the library
+// itself loads on hosts without it.
+struct bbt_comm {
+    ncclComm_t nccl = nullptr;
+    int rank = 0, world = 1;
+};
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return 0;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail("bbt_comm: cannot load librccl: %s", dlerror());
+    RcclApi api;
+    api.handle = h;
+    api.get_unique_id = (decltype(api.get_unique_id))dlsym(h, "ncclGetUniqueId");
+    api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(h, "ncclCommInitRank");
+    api.comm_destroy = (decltype(api.comm_destroy))dlsym(h, "ncclCommDestroy");
+    api.broadcast = (decltype(api.broadcast))dlsym(h, "ncclBroadcast");
+    api.all_gather = (decltype(api.all_gather))dlsym(h, "ncclAllGather");
+    api.error_string = (decltype(api.error_string))dlsym(h, "ncclGetErrorString");
+    if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.broadcast ||
+        !api.all_gather || !api.error_string)
+        return fail("bbt_comm: librccl lacks a required symbol");
+    g_rccl = api;
+    return 0;
+}
+}  // namespace
+
+#define RCCL_TRY(expr)                                                                         \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.error_string(r_));   \
+    } while (0)
+
+extern "C" {
+
+int bbt_comm_unique_id(void* id_out, size_t id_bytes) {
+    ARG_TRY(id_out && id_bytes >= sizeof(ncclUniqueId), "bbt_comm_unique_id: need a buffer of %zu bytes",
+            sizeof(ncclUniqueId));
+    if (rccl_load()) return 1;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.get_unique_id(&id));
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int bbt_comm_init(bbt_comm** comm, int n_ranks, int rank, const void* id, size_t id_bytes) {
+    ARG_TRY(comm && id, "bbt_comm_init: null argument");
+    *comm = nullptr;
+    ARG_TRY(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bbt_comm_init: rank %d of %d", rank, n_ranks);
+    ARG_TRY(id_bytes >= sizeof(ncclUniqueId), "bbt_comm_init: the id must hold %zu bytes",
+            sizeof(ncclUniqueId));
+    if (rccl_load()) return 1;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    bbt_comm* c = new bbt_comm;
+    c->rank = rank;
+    c->world = n_ranks;
+    ncclResult_t r = g_rccl.comm_init_rank(&c->nccl, n_ranks, uid, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail("ncclCommInitRank failed: %s", g_rccl.error_string(r));
+    }
+    *comm = c;
+    return 0;
+}
+
+int bbt_comm_destroy(bbt_comm* comm) {
+    if (!comm) return 0;
+    if (comm->nccl) g_rccl.comm_destroy(comm->nccl);
+    delete comm;
+    return 0;
+}
+
+int bbt_bcast_chirp(bbt_comm* comm, void* resp_dev, int64_t n_complex, int root, bbt_stream stream) {
+    ARG_TRY(comm && resp_dev, "bbt_bcast_chirp: null argument");
+    ARG_TRY(n_complex >= 0 && root >= 0 && root < comm->world, "bbt_bcast_chirp: bad count or root");
+    if (n_complex == 0) return 0;
+    RCCL_TRY(g_rccl.broadcast(resp_dev, resp_dev, (size_t)n_complex * 2, ncclFloat32, root, comm->nccl,
+                              (hipStream_t)stream));
+    return 0;
+}
+
+int bbt_gather_output(bbt_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes_per_rank,
+                      bbt_stream stream) {
+    ARG_TRY(comm && send_dev && recv_dev, "bbt_gather_output: null argument");
+    ARG_TRY(bytes_per_rank >= 0, "bbt_gather_output: negative size");
+    if (bytes_per_rank == 0) return 0;
+    if (bytes_per_rank % 4 == 0)
+        RCCL_TRY(g_rccl.all_gather(send_dev, recv_dev, (size_t)bytes_per_rank / 4, ncclFloat32,
+                                   comm->nccl, (hipStream_t)stream));
+    else
+        RCCL_TRY(g_rccl.all_gather(send_dev, recv_dev, (size_t)bytes_per_rank, ncclUint8, comm->nccl,
+                                   (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

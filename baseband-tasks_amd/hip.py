@@ -86,6 +86,11 @@ SIGNATURES = {
     'bbt_fir_execute': [_vp, _vp, _vp, _i64, _vp],
     'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
     'bbt_scale_streams': [_vp, _vp, _i64, _int, _vp, _vp],
+    'bbt_comm_unique_id': [_vp, _sz],
+    'bbt_comm_init': [_pvp, _int, _int, _vp, _sz],
+    'bbt_comm_destroy': [_vp],
+    'bbt_bcast_chirp': [_vp, _vp, _i64, _int, _vp],
+    'bbt_gather_output': [_vp, _vp, _vp, _i64, _vp],
 }
 
 _lib = None
@@ -607,3 +612,38 @@ class ShiftPlan(_Plan):
 
     def execute(self, in_dev, out_dev, n_out):
         check(lib().bbt_shift_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_out), _stream))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """The id rank 0 creates and hands to the other ranks (bytes)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().bbt_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class Comm(_Plan):
+    """RCCL communicator behind the C ABI (one process per GPU; call after
+    `set_device`).  ``uid``: the bytes of `comm_unique_id()` made on rank 0."""
+    _destroy = 'bbt_comm_destroy'
+
+    def __init__(self, n_ranks, rank, uid):
+        super().__init__()
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        uid = bytes(uid)
+        check(lib().bbt_comm_init(C.byref(self._h), self.n_ranks, self.rank, uid, len(uid)))
+
+    def bcast_chirp(self, resp_dev, root=0):
+        """In-place broadcast of a complex64 DeviceArray from ``root``."""
+        assert resp_dev.dtype == np.complex64
+        check(lib().bbt_bcast_chirp(self._h, resp_dev.ptr, resp_dev.size, int(root), _stream))
+        return resp_dev
+
+    def gather_output(self, local, out=None):
+        """All-gather equally sized DeviceArrays along axis 0, in rank order."""
+        if out is None:
+            out = DeviceArray((self.n_ranks * local.shape[0],) + local.shape[1:], local.dtype)
+        check(lib().bbt_gather_output(self._h, local.ptr, out.ptr, local.nbytes, _stream))
+        return out

@@ -19,10 +19,13 @@ def sinc_hamming(n_tap, n_sample, sinc_scale=1.):
     return (np.sinc(x) * np.hamming(n)).reshape(n_tap, n_sample)
 
 
-class _NoHostTask(PaddedTaskBase):
+class _PaddedSource(PaddedTaskBase):
+    """The inner padded stream of a filter bank (reference pfb.py:80-82): its
+    ``task`` is the owning filter bank's ``ppf``."""
+    _owner = None
+
     def task(self, data):
-        raise NotImplementedError("the polyphase filter is evaluated on the GPU inside "
-                                  "PolyphaseFilterBank; its padded stream has no host path.")
+        return self._owner.ppf(data)
 
 
 class PolyphaseFilterBank(_RowFFTTask):
@@ -59,8 +62,9 @@ class PolyphaseFilterBank(_RowFFTTask):
         assert pad % 2 == 0
         if samples_per_frame is not None:
             samples_per_frame = samples_per_frame * n
-        self.padded = _NoHostTask(ih, pad_start=pad // 2, pad_end=pad // 2,
-                                  samples_per_frame=samples_per_frame)
+        self.padded = _PaddedSource(ih, pad_start=pad // 2, pad_end=pad // 2,
+                                    samples_per_frame=samples_per_frame)
+        self.padded._owner = self
         if self.padded._ih_samples_per_frame % n:
             raise ValueError("the input block of the polyphase filter "
                              f"({self.padded._ih_samples_per_frame} samples) must be a "
@@ -117,13 +121,59 @@ class PolyphaseFilterBank(_RowFFTTask):
         if self._real:
             hip.keep_half_spectrum(flat, n, s, final)
 
+    def _spectra_of_frame(self, data):
+        """Filter bank spectra (device) of one padded input frame given on the host."""
+        n, n_tap = self._n, self._response.shape[0]
+        data = np.ascontiguousarray(data, dtype=np.complex64)      # real input: zero imaginary part
+        rows = data.shape[0] // n
+        n_spectra = rows + 1 - n_tap
+        s, se = self._n_stream, self._n_stream_even
+        x = hip.DeviceArray.from_host(data.reshape(rows * n, s))
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+        z = hip.DeviceArray((n_spectra * n, se), np.complex64)
+        self._get_plan().execute(x, z, n_spectra)
+        return z, n_spectra
+
     def ppf(self, data):
-        raise NotImplementedError("the filter and the FFT are one GPU kernel here; "
-                                  "use read().")
+        """Apply the polyphase filter to one padded input frame given on the
+        host (the reference's hook, pfb.py:91-100 / 145-154): the filtered time
+        stream, ``samples_per_frame * n`` samples.  The filter and the FFT are
+        one kernel on the GPU, so this is that kernel followed by the inverse
+        channelizer transform."""
+        n = self._n
+        z, n_spectra = self._spectra_of_frame(data)
+        se = self._n_stream_even
+        y = hip.DeviceArray((n_spectra * n, se), np.complex64)
+        if getattr(self, '_ppf_inverse', None) is None:
+            self._ppf_inverse = hip.ChanPlan(n, se, +1)
+        self._ppf_inverse.execute(z, y, n_spectra)
+        res = y.to_host()[:, :self._n_stream].reshape((n_spectra * n,) + tuple(self.sample_shape[1:]))
+        return np.ascontiguousarray(res.real if self._real else res)
+
+    def task(self, data):
+        """Channelize one filtered frame given on the host (what
+        `Channelize.task` does for the reference's class, channelize.py:73-74)."""
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        n, s, se = self._n, self._n_stream, self._n_stream_even
+        n_spectra = data.shape[0] // n
+        x = hip.DeviceArray.from_host(data.reshape(n_spectra * n, s))
+        if se != s:
+            x = hip.pad_streams_to_even(x, s)
+        if getattr(self, '_task_forward', None) is None:
+            self._task_forward = hip.ChanPlan(n, se, -1)
+        y = hip.DeviceArray((n_spectra * n, se), np.complex64)
+        self._task_forward.execute(x, y, n_spectra)
+        z = y.to_host()[:, :s].reshape((n_spectra, n) + tuple(self.sample_shape[1:]))
+        return np.ascontiguousarray(z[:, :n // 2 + 1] if self._real else z)
 
     def close(self):
         super().close()
         self.__dict__.pop('_source', None)
+        for name in ('_ppf_inverse', '_task_forward'):
+            plan = self.__dict__.pop(name, None)
+            if plan is not None:
+                plan.close()
 
 
 #: The GPU evaluates the time-domain definition directly, so both reference
@@ -229,7 +279,21 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
             flat[o:o + int(cnt)].copy_from_device(tmp[int(t0) * n + off:int(t0) * n + off + int(cnt)])
 
     def task(self, data):
-        raise NotImplementedError("frames are deconvolved on the GPU; use read().")
+        """Deconvolve one input frame given on the host (the reference's hook,
+        pfb.py:255-269): ``_ih_samples_per_frame`` dechannelized samples in,
+        ``samples_per_frame`` out, padding removed."""
+        plan = self._get_plan()
+        n, s, spf, n_in = self._n, self._n_stream, self.samples_per_frame, self._ih_samples_per_frame
+        data = np.ascontiguousarray(data, dtype=np.complex64)
+        assert data.shape[0] == n_in
+        keep = self._pad_start
+        off = keep % n
+        n_blk = -(-(off + spf) // n)
+        x = hip.DeviceArray.from_host(data.reshape(n_in // n, n * s))
+        tmp = hip.DeviceArray((n_blk, n * s), np.complex64)
+        plan.execute(x, tmp, [0], [0], [keep // n], [n_blk])
+        res = tmp.to_host().reshape((n_blk * n,) + tuple(self.sample_shape))
+        return np.ascontiguousarray(res[off:off + spf])
 
     def close(self):
         super().close()

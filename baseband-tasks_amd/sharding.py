@@ -9,13 +9,16 @@ them with its own chirp columns (`SubbandShard`) and the results are
 concatenated along that axis (`gather_subbands`, the role
 `combining.Concatenate` plays on the host, combining.py:176-211).  The only
 collectives are one broadcast of the response (chirp) at plan time and an
-optional gather of the outputs; both go through ``torch.distributed``
-(backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).
+optional gather of the outputs.  They go through ``torch.distributed``
+(backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests) or, with a
+`hip.Comm` (`make_comm`), through the library's own C-ABI entry points
+``bbt_bcast_chirp`` / ``bbt_gather_output`` (RCCL, include/bbt_hip.h), which
+is what a host without torch would bind.
 """
 import numpy as np
 
-__all__ = ['frame_range', 'share_response', 'gather_frames', 'SubbandShard', 'SubbandDedisperse',
-           'gather_subbands']
+__all__ = ['frame_range', 'make_comm', 'share_response', 'gather_frames', 'SubbandShard',
+           'SubbandDedisperse', 'gather_subbands']
 
 
 def frame_range(n_frames, rank, world):
@@ -26,7 +29,18 @@ def frame_range(n_frames, rank, world):
     return first, first + base + (1 if rank < extra else 0)
 
 
-def share_response(task, torch, dist, device, src=0):
+def make_comm(dist, src=0):
+    """A `hip.Comm` (RCCL communicator behind the C ABI) for this process
+    group: rank ``src`` creates the id, ``dist`` (any backend; only a small
+    object broadcast) carries it to the others.  Call after `hip.set_device`."""
+    from . import hip
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [hip.comm_unique_id() if rank == src else None]
+    dist.broadcast_object_list(box, src)
+    return hip.Comm(world, rank, box[0])
+
+
+def share_response(task, torch, dist, device, src=0, comm=None):
     """Give every rank's overlap-save task the SAME response: rank ``src``
     evaluates it (float64 on the host), the others receive it with a
     broadcast, and each rank builds its plan from the device copy.
@@ -56,7 +70,10 @@ def share_response(task, torch, dist, device, src=0):
     else:
         resp = torch.empty((ncol, n, 2), dtype=torch.float32, device=device)
         idx = torch.empty(n_plan, dtype=torch.int32, device=device)
-    dist.broadcast(resp, src)
+    if comm is not None:               # the C ABI's own collective (bbt_bcast_chirp)
+        comm.bcast_chirp(hip.DeviceArray((ncol, n), np.complex64, resp.data_ptr(), resp), src)
+    else:
+        dist.broadcast(resp, src)
     dist.broadcast(idx, src)
     if device.type == 'cuda':
         dev_resp = hip.DeviceArray((ncol, n), np.complex64, resp.data_ptr(), resp)
@@ -66,12 +83,18 @@ def share_response(task, torch, dist, device, src=0):
     return torch.view_as_complex(resp), idx
 
 
-def gather_frames(local, torch, dist):
-    """All-gather equally sized per-rank outputs in rank (= stream) order."""
+def gather_frames(local, torch, dist, comm=None):
+    """All-gather equally sized per-rank outputs in rank (= stream) order;
+    through ``comm`` (bbt_gather_output) if given, else torch.distributed."""
     world = dist.get_world_size()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
                       device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
+    local = local.contiguous()
+    if comm is not None:
+        from . import hip
+        comm.gather_output(hip.as_device_array(local), hip.as_device_array(out))
+    else:
+        dist.all_gather_into_tensor(out, local)
     return out
 
 
@@ -148,11 +171,11 @@ def SubbandDedisperse(ih, dm, *, band_frequency, band_reference_frequency=None,
                               samples_per_frame=samples_per_frame, **kwargs)
 
 
-def gather_subbands(local, torch, dist):
+def gather_subbands(local, torch, dist, comm=None):
     """Concatenate equally shaped per-rank results ``(n, k, ...)`` along the
     sub-band axis, in rank order: ``(n, world * k, ...)`` on every rank."""
     world = dist.get_world_size()
-    flat = gather_frames(local, torch, dist)                       # (world * n, k, ...)
+    flat = gather_frames(local, torch, dist, comm)                 # (world * n, k, ...)
     n = local.shape[0]
     stacked = flat.reshape((world, n) + tuple(local.shape[1:]))
     order = (1, 0) + tuple(range(2, stacked.dim()))

@@ -349,6 +349,12 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # BBT_BENCH_COMM=cabi: chirp broadcast and output gather through the library's own RCCL entry
+    # points (bbt_bcast_chirp / bbt_gather_output) instead of torch.distributed's
+    comm = None
+    if world > 1 and os.environ.get('BBT_BENCH_COMM') == 'cabi' and backend == 'nccl':
+        comm = sharding.make_comm(dist)
+
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345 + rank)
 
@@ -363,7 +369,7 @@ def run_rank(args):
         assert (dd._ih_samples_per_frame, dd.samples_per_frame) == (N_FFT, spf)
         n_chan, ch_spf = N_CHAN, 512
         # chirp: rank 0 computes, everyone receives it (RCCL broadcast; no-op for one rank)
-        sharding.share_response(dd, torch, dist if world > 1 else None, dev)
+        sharding.share_response(dd, torch, dist if world > 1 else None, dev, comm=comm)
         sharding_note = ('independent time blocks per rank, chirp broadcast over '
                          f'{"RCCL" if backend == "nccl" else backend}') if world > 1 else 'single GPU'
         alg_bytes = ALG_BYTES_PER_SAMPLE
@@ -515,8 +521,8 @@ def run_rank(args):
             if backend != 'nccl':
                 t_ = t_.cpu()
             if args.workload == 'config4':
-                return sharding.gather_subbands(t_, torch, dist)
-            return sharding.gather_frames(t_, torch, dist)
+                return sharding.gather_subbands(t_, torch, dist, comm)
+            return sharding.gather_frames(t_, torch, dist, comm)
         gathered_step()
         fence()
         t0 = time.perf_counter()
@@ -531,7 +537,8 @@ def run_rank(args):
                            steps=n_g, ms_per_step=round(dt / n_g * 1e3, 4),
                            gathered_shape=list(g_out.shape),
                            bytes_received_per_rank_per_step=int(zt.numel() * 4 * (world - 1)),
-                           collective='all_gather_into_tensor over ' + ('RCCL/xGMI' if backend == 'nccl' else backend))
+                           collective=('bbt_gather_output (C ABI, RCCL)' if comm is not None else
+                                       'all_gather_into_tensor over ' + ('RCCL/xGMI' if backend == 'nccl' else backend)))
         del g_out
 
     cpu = None

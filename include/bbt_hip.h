@@ -44,6 +44,7 @@ typedef struct bbt_chan_plan bbt_chan_plan;
 typedef struct bbt_pfb_plan bbt_pfb_plan;
 typedef struct bbt_shift_plan bbt_shift_plan;
 typedef struct bbt_fir_plan bbt_fir_plan;
+typedef struct bbt_comm bbt_comm;
 
 /* ---- library / device ------------------------------------------------- */
 const char* bbt_last_error(void);
@@ -270,6 +271,31 @@ int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream, const void
 int bbt_fir_plan_destroy(bbt_fir_plan* plan);
 int bbt_fir_execute(bbt_fir_plan* plan, const void* in_dev, void* out_dev, int64_t n_out,
                     bbt_stream stream);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------
+ * The reference has no distributed code; these are what SURVEY 8(b)/(e) ask a
+ * replacement to export for the way this path shards (independent overlap-save
+ * blocks, base.py:783-790, or independent sub-bands; results concatenated as
+ * combining.Concatenate would, combining.py:176-211).  No data-path
+ * collective exists: only the response broadcast at plan time and the optional
+ * gather of outputs.  librccl is loaded on first use.
+ *   bbt_comm_unique_id  rank 0 makes the 128-byte id and hands it to the other
+ *                       ranks by any side channel (file, socket, a torch
+ *                       store); then every rank calls bbt_comm_init after
+ *                       bbt_set_device
+ *   bbt_bcast_chirp     in place broadcast of n_complex complex64 from `root`
+ *                       (the C x N response later given to
+ *                       bbt_osm_plan_create(..., resp_on_device = 1, ...))
+ *   bbt_gather_output   all-gather: rank r's bytes_per_rank bytes land at
+ *                       recv_dev + r * bytes_per_rank on every rank
+ */
+#define BBT_COMM_ID_BYTES 128
+int bbt_comm_unique_id(void* id_out, size_t id_bytes);
+int bbt_comm_init(bbt_comm** comm, int n_ranks, int rank, const void* id, size_t id_bytes);
+int bbt_comm_destroy(bbt_comm* comm);
+int bbt_bcast_chirp(bbt_comm* comm, void* resp_dev, int64_t n_complex, int root, bbt_stream stream);
+int bbt_gather_output(bbt_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes_per_rank,
+                      bbt_stream stream);
 
 #ifdef __cplusplus
 }

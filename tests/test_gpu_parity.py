@@ -312,6 +312,15 @@ def test_small_pfb_golden(golden):
     z1 = bt.PolyphaseFilterBankSamples(nh1, resp, samples_per_frame=8).read()
     assert_parity(z1, golden['sg_pfb_samples_1d'], 'samples form')
     assert_parity(z1, golden['sg_pfb_fourier_1d'], 'fourier form')
+    # the reference's host hooks (pfb.py:91-100, channelize.py:73-74): ppf of one
+    # padded input frame, then task of the filtered frame
+    x = orc.noise_stream(14, 0, 40 * 256, 2560, (2,))
+    frame = x[:p.padded._ih_samples_per_frame]
+    filtered = p.ppf(frame)
+    assert filtered.shape == (p.samples_per_frame * 256, 2)
+    assert_parity(filtered, orc.ppf_samples(frame, resp).astype(np.complex64), 'ppf hook')
+    assert_parity(p.padded.task(frame), filtered, 'padded.task is ppf')
+    assert_parity(p.task(filtered), golden['sg_pfb'][:p.samples_per_frame], 'task hook')
 
 
 def test_small_convolve_resample_and_chain_golden(golden):
@@ -640,6 +649,9 @@ def test_inverse_polyphase_filter_bank_golden(golden):
     assert_parity(y, golden['sm_ipfb'], 'inverse pfb')
     ipfb.seek(7000)
     assert np.array_equal(ipfb.read(200), y[7000:7200])             # across a frame seam
+    # the reference's host hook (pfb.py:255-269): one dechannelized frame in, one frame out
+    frame = ipfb.dechannelized.read(ipfb._ih_samples_per_frame) if ipfb.dechannelized.seek(0) == 0 else None
+    assert_parity(ipfb.task(frame), y[:ipfb.samples_per_frame], 'ipfb task hook')
 
 
 def test_time_delay_golden(golden):
@@ -1258,3 +1270,24 @@ def test_config4_share_of_one_rank():
             wy = orc.overlap_save(np.ascontiguousarray(x[:, k]), g,
                                   lambda blk: orc.disperse_block(blk, h, 1362235, spf))
         assert_parity(z[:, :, k], orc.channelize(wy[:z.shape[0] * 64], 64), f'sub-band {k}')
+
+
+def test_rccl_entry_points_of_the_c_abi():
+    """bbt_comm_* / bbt_bcast_chirp / bbt_gather_output: a
+    one-rank communicator on this GPU (more ranks need more GPUs; the call
+    sequence is the same)."""
+    uid = bt.hip.comm_unique_id()
+    assert len(uid) == bt.hip.COMM_ID_BYTES
+    comm = bt.hip.Comm(1, 0, uid)
+    rng = np.random.default_rng(3)
+    h = (rng.standard_normal((2, 4096)) + 1j * rng.standard_normal((2, 4096))).astype(np.complex64)
+    d = bt.hip.DeviceArray.from_host(h)
+    comm.bcast_chirp(d, root=0)
+    assert np.array_equal(d.to_host(), h)
+    out = comm.gather_output(d)
+    assert out.shape == (2, 4096) and np.array_equal(out.to_host(), h)
+    odd = bt.hip.DeviceArray.from_host(np.arange(7, dtype=np.uint8))
+    assert np.array_equal(comm.gather_output(odd).to_host(), np.arange(7, dtype=np.uint8))
+    comm.close()
+    with pytest.raises(bt.hip.HipError):
+        bt.hip.Comm(2, 5, uid)
