@@ -21,6 +21,7 @@ from .pfb import (sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples,
                   InversePolyphaseFilterBank)
 from .functions import Square, Power
 from .integration import Integrate
+from .ingest import RawFrameStream, open_vdif, open_dada
 from . import hip
 
 __version__ = '0.1.0'

@@ -431,6 +431,16 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms) {
 
 // ---------------------------------------------------------------------------
 // overlap-save spectral multiply
+// short-response convolution in the time domain (entry points further down)
+struct bbt_fir_plan {
+    int n_tap = 0, S = 0, npair = 0;
+    int n_chunks = 0, pitch = 0, tap_pitch = 0;
+    bool cplx = false;
+    float2* tre = nullptr;
+    float2* tim = nullptr;
+};
+static constexpr int BBT_FIR_R = 8;
+
 #define BBT_MAX_LANES 8
 struct bbt_osm_plan {
     // One call at a time per plan: the lanes' work buffers, the seam buffer,
@@ -466,6 +476,11 @@ struct bbt_osm_plan {
     cf* tlo = nullptr;          // W_N^i, i < 4096        (owned)
     cf* thi = nullptr;          // W_N^{4096 j}           (owned)
     int gen_ct = 1;             // columns per tile of the column passes
+    // bbt_osm_execute_prefiltered: a direct FIR in front of every block, into
+    // per-lane staging buffers (chunk x N x S complex64), allocated on first use
+    const bbt_fir_plan* pre = nullptr;      // set for the duration of such a call
+    float2* lane_stage[BBT_MAX_LANES] = {};
+    int stage_lane = 0;                     // lane of the chunk being enqueued
     // fused channelizer
     float2* seam = nullptr;     // [blocks][2][npair][n_chan] float4
     size_t seam_bytes = 0;
@@ -638,7 +653,7 @@ static int launch_col4096(bbt_osm_plan* p, const float2* in, float2* out, float2
     return 0;
 }
 
-static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
+static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch_arg,
                          const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -653,6 +668,31 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         }
         HIP_TRY(hipEventRecord(e[0], st));
     }
+    OsmChunk staged;
+    const OsmChunk* chp = &ch_arg;
+    if (p->pre) {
+        // filter every block of the chunk into this lane's staging buffer; the
+        // first column pass then reads block i at staging[i * N]
+        const bbt_fir_plan* f = p->pre;
+        constexpr int R = BBT_FIR_R;
+        float2* stage = p->lane_stage[p->stage_lane];
+        const long long tiles = (p->n + 256 * R - 1) / (256 * R);
+        const size_t lds = (size_t)R * f->pitch * sizeof(float4);
+        const dim3 grid((unsigned)(tiles * p->npair), ch_arg.nblk);
+        if (f->cplx)
+            hipLaunchKernelGGL((k_fir_blocks<R, true>), grid, dim3(256), lds, st, in, stage, ch_arg,
+                               (long long)p->n, f->n_tap, p->S, f->tre, f->tim, f->tap_pitch,
+                               f->n_chunks, f->pitch);
+        else
+            hipLaunchKernelGGL((k_fir_blocks<R, false>), grid, dim3(256), lds, st, in, stage, ch_arg,
+                               (long long)p->n, f->n_tap, p->S, f->tre, f->tim, f->tap_pitch,
+                               f->n_chunks, f->pitch);
+        staged = ch_arg;
+        for (int i = 0; i < ch_arg.nblk; ++i) staged.b[i].in_off = (long long)i * p->n;
+        chp = &staged;
+        in = stage;
+    }
+    const OsmChunk& ch = *chp;         // (block i of a prefiltered chunk reads staging[i * N])
     if (p->generic) {
         if (nch) return fail("osm: the fused channelizer needs a power-of-two block length");
         if (p->n1 == 1) {
@@ -770,6 +810,7 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
         ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
         for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
         const int l = fork ? (int)(c % p->lanes) : 0;
+        p->stage_lane = l;
         if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : st))
             return 1;
     }
@@ -857,13 +898,20 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         p->n1 = 16;
     } else if (n_fft <= (1 << 20)) {
         p->n1 = 256;
-    } else if (const char* env = getenv("BBT_OSM_THREE_LEVEL"); env && atoi(env)) {
-        p->outer = 256;          // the older three-level scheme 256 x 16 x N2, kept for comparison
+    } else if (const char* env = getenv("BBT_OSM_TWO_LEVEL"); env && atoi(env)) {
+        // 4096 x N2 (N2 = 512 .. 4096): three passes instead of five, but a
+        // 4096-point column transform fills the LDS of a CU with four columns, so
+        // its runs of the stream and of the work buffer are 64 bytes and one
+        // workgroup per CU hides no latency: measured on MI355X (config 4's share,
+        // 16 streams) 1.9 / 1.6 / 2.2 ms per block for the three passes against
+        // 1.85 / 1.1 / 2.0 ms for the five of the three-level scheme (256-byte
+        // and longer runs) -- no gain, so it is not the default.
+        p->n1 = 4096;
+    } else {
+        p->outer = 256;          // three levels, 256 x 16 x N2
         p->n1 = 16;
         if (n_stream / 2 > 255)
             return bail(fail("bbt_osm_plan_create: blocks longer than 2^20 support at most 510 streams"));
-    } else {
-        p->n1 = 4096;            // 4096 x N2, N2 = 512 .. 4096
     }
     p->n2 = (int)(n_fft / p->n1 / p->outer);
     if (p->generic) {
@@ -968,6 +1016,7 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
         }
         if (p->ev_join[l]) hipEventDestroy(p->ev_join[l]);
         if (p->lane_work[l]) hipFree(p->lane_work[l]);
+        if (p->lane_stage[l]) hipFree(p->lane_stage[l]);
     }
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->seam) hipFree(p->seam);
@@ -989,7 +1038,7 @@ int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     // can bbt_osm_execute_channelized take Channelize(n_chan) into the row pass?
     if (!p || p->generic || (p->n1 == 1 && p->outer == 1)) return 0;
     if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
-        return p->outer == 1 && (p->n1 == 256 || p->n1 == 4096);            // exchange in the row pass
+        return p->n1 == 256 || p->n1 == 4096 || p->outer == 256;            // exchange in the row pass
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
 }
 
@@ -1013,6 +1062,35 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
                        });
 }
 
+int bbt_osm_execute_prefiltered(bbt_osm_plan* p, const bbt_fir_plan* fir, const void* in_dev,
+                                void* out_dev, int64_t n_blocks, const int64_t* in_off,
+                                const int64_t* out_off, const int32_t* valid_start,
+                                const int32_t* valid_count, bbt_stream stream) {
+    const char* who = "bbt_osm_execute_prefiltered";
+    ARG_TRY(p && fir && in_dev && out_dev, "%s: null argument", who);
+    ARG_TRY(fir->S == p->S, "%s: the filter has %d streams, the plan %d", who, fir->S, p->S);
+    ARG_TRY(p->n >= 256 * BBT_FIR_R, "%s: blocks of %lld samples are too short", who, (long long)p->n);
+    if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(p->mu);
+    const size_t bytes = (size_t)p->chunk * p->n * p->S * sizeof(float2);
+    for (int l = 0; l < p->lanes; ++l)
+        if (!p->lane_stage[l]) HIP_TRY(hipMalloc((void**)&p->lane_stage[l], bytes));
+    SpecOut so = {};
+    p->pre = fir;
+    const int rc = osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+                               [&](OsmBlock& blk, int64_t b) {
+                                   blk.in_off = in_off[b];
+                                   blk.out_off = out_off[b];
+                                   blk.valid_start = valid_start[b];
+                                   blk.valid_count = valid_count[b];
+                                   blk.shift = 0;
+                                   blk.index = (int)b;
+                               });
+    p->pre = nullptr;
+    return rc;
+}
+
 // Channelize(overlap-save task) as one call; with det_step > 0 the spectra are
 // detected and integrated instead of stored (out_dev = float32 bins).
 static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev, void* out_dev,
@@ -1026,8 +1104,8 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
     ARG_TRY(p->n1 > 1 || p->outer > 1, "%s: block length %lld is too short to fuse", who,
             (long long)p->n);
     ARG_TRY(bbt_osm_plan_fusable(p, n_chan),
-            "%s: n_chan=%d must be a power of two in [256, %d] (or 16..128 for blocks of two levels "
-            "with 256 or 4096 columns)", who, n_chan, p->n2);
+            "%s: n_chan=%d must be a power of two in [256, %d] (or 16..128 for blocks with 256 or "
+            "4096 columns or of three levels)", who, n_chan, p->n2);
     const bool small = n_chan < 256;
     ARG_TRY(!(small && det_step > 0), "%s: fused detection needs n_chan >= 256", who);
     ARG_TRY(first_spectrum >= 0 && n_spectra >= 0, "%s: bad spectrum range", who);
@@ -1073,6 +1151,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
     while ((1 << so.lg_chan) < n_chan) ++so.lg_chan;
     so.n_fft = (int)p->n;
     so.small_l = small ? n_chan / 16 : 0;
+    so.small_row = p->n2;
     if (det_step > 0) {
         so.det = (float*)out_dev;
         so.det_step = det_step;
@@ -1580,14 +1659,6 @@ extern "C" int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_sa
 
 // ---------------------------------------------------------------------------
 // short-response convolution in the time domain
-struct bbt_fir_plan {
-    int n_tap = 0, S = 0, npair = 0;
-    int n_chunks = 0, pitch = 0, tap_pitch = 0;
-    bool cplx = false;
-    float2* tre = nullptr;
-    float2* tim = nullptr;
-};
-static constexpr int BBT_FIR_R = 8;
 
 extern "C" int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream,
                                    const void* response_host) {
@@ -1651,6 +1722,35 @@ extern "C" int bbt_fir_execute(bbt_fir_plan* p, const void* in_dev, void* out_de
         hipLaunchKernelGGL((k_fir<R, false>), grid, dim3(256), lds, (hipStream_t)stream,
                            (const float2*)in_dev, (float2*)out_dev, n_in, (long long)n_out, p->S,
                            p->tre, p->tim, p->tap_pitch, p->n_chunks, p->pitch);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// sampler frames -> float32 / complex64 (k_unpack)
+extern "C" int bbt_unpack(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
+                          int header_bytes, int bits, int samples_per_frame, int n_thread,
+                          int n_elem, int code, bbt_stream stream) {
+    ARG_TRY(raw_dev && out_dev, "bbt_unpack: null argument");
+    ARG_TRY(n_frames >= 0 && n_thread >= 1 && n_frames % n_thread == 0,
+            "bbt_unpack: %lld frames are not whole sets of %d threads", (long long)n_frames, n_thread);
+    ARG_TRY(code == 0 || code == 1, "bbt_unpack: code must be 0 (VDIF levels) or 1 (two's complement)");
+    ARG_TRY(code == 0 ? (bits == 1 || bits == 2 || bits == 4 || bits == 8 || bits == 16)
+                      : (bits == 8 || bits == 16),
+            "bbt_unpack: %d bits per component are not supported for code %d", bits, code);
+    ARG_TRY(frame_bytes > header_bytes && header_bytes >= 0 && frame_bytes % 4 == 0 &&
+                header_bytes % 4 == 0,
+            "bbt_unpack: frame of %d bytes with a header of %d", frame_bytes, header_bytes);
+    ARG_TRY(samples_per_frame >= 1 && n_elem >= 1 &&
+                (int64_t)samples_per_frame * n_elem * bits <= (int64_t)(frame_bytes - header_bytes) * 8,
+            "bbt_unpack: %d samples of %d components at %d bits do not fit the payload",
+            samples_per_frame, n_elem, bits);
+    const long long total = (long long)n_frames * samples_per_frame * n_elem;
+    if (total == 0) return 0;
+    ARG_TRY((total + 255) / 256 < (1ll << 31), "bbt_unpack: too many samples for one call");
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)raw_dev, (float*)out_dev, total, frame_bytes, header_bytes,
+                       bits, samples_per_frame, n_thread, n_elem, code);
     HIP_TRY(hipGetLastError());
     return 0;
 }

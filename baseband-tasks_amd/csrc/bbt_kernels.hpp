@@ -184,16 +184,19 @@ struct SpecOut {
     // n_chan < 256: the row pass leaves channel a + 16 bitrev_L(c) of group q at
     // row position (L q + c) + T a, L = n_chan / 16, T = N2 / 16 (k_osm_rowpass)
     int small_l;         // 0: natural order (position == q * n_chan + channel)
+    int small_row;       // row length N2 of the row pass (a column pass of a three-level
+                         // transform sees 16 such rows side by side)
 };
 
-// Row position -> q * n_chan + channel for the small-channel-count layout.
-__device__ __forceinline__ int small_channel_slot(int pos, int N2, const SpecOut& so) {
+// Column position -> q * n_chan + channel for the small-channel-count layout.
+__device__ __forceinline__ int small_channel_slot(int pos, const SpecOut& so) {
     if (!so.small_l) return pos;
-    const int L = so.small_l, T = N2 >> 4;
-    const int a = pos / T, t = pos - a * T;
+    const int L = so.small_l, N2 = so.small_row, T = N2 >> 4;
+    const int row = pos / N2, p = pos - row * N2;
+    const int a = p / T, t = p - a * T;
     const int q = t / L, c = t - q * L;
     const int r = L == 1 ? 0 : (int)(__brev((unsigned)c) >> (32 - (31 - __clz(L))));
-    return q * so.n_chan + a + 16 * r;
+    return row * N2 + q * so.n_chan + a + 16 * r;
 }
 
 // floats a pair contributes per (bin, channel): 2 (mode 0) or 4 (mode 1)
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
         wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
         SpecCursor cur;
-        if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, N2, so), S, sp, npair);
+        if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, so), S, sp, npair);
         if constexpr (SPEC && DET) {
             // Detection + integration instead of storing spectra.  The workgroup
             // holds, for each of its FCOL channels, every (N2 / n_chan)-th of
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_osm_col4096(const float2* __restrict__
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)T * j * N2 * 2);
         wg_fft<4096, +1, F>(v, col4096_lds, tau, f, tw0, tw1);
         SpecCursor cur;
-        if (SPEC) cur = spec_cursor(out, so, blk, tau, T, N2, small_channel_slot(n2, N2, so), S, sp, npair);
+        if (SPEC) cur = spec_cursor(out, so, blk, tau, T, N2, small_channel_slot(n2, so), S, sp, npair);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (SPEC) {
@@ -1187,24 +1190,19 @@ __global__ __launch_bounds__(256) void k_scale_streams(const float2* __restrict_
 //   tre/tim : [npair][tap_pitch] float2 (g_A, g_B) real / imaginary parts,
 //             R-1 zeros in front and >= R zeros behind the n_tap taps.
 template <int R, bool CPLX>
-__global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, float2* __restrict__ out,
-                                             long long n_in, long long n_out, int S,
-                                             const float2* __restrict__ tre,
-                                             const float2* __restrict__ tim, int tap_pitch,
-                                             int n_chunks, int pitch) {
+__device__ __forceinline__ void fir_tile(const float2* __restrict__ in, float2* __restrict__ out,
+                                         long long n_in, long long n_out, int S, int sp,
+                                         long long base, const float2* __restrict__ tre,
+                                         const float2* __restrict__ tim, int tap_pitch,
+                                         int n_chunks, int pitch, float4* __restrict__ fir_tile_lds) {
     constexpr int T = 256;
-    extern __shared__ float4 fir_tile[];
-    const int t = threadIdx.x, npair = S >> 1;
-    // the pairs of one tile share cache lines: consecutive virtual ids, one XCD
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int sp = vb % npair;
-    const long long base = (long long)(vb / npair) * (T * R);
+    const int t = threadIdx.x;
     const int n_tile = R * (T + n_chunks);
     for (int s = t; s < n_tile; s += T) {
         const long long g = base + s;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g < n_in) x = *reinterpret_cast<const float4*>(in + (g * S + 2 * sp));
-        fir_tile[(s % R) * pitch + s / R] = x;
+        fir_tile_lds[(s % R) * pitch + s / R] = x;
     }
     __syncthreads();
     const float2* gre = tre + (long long)sp * tap_pitch;
@@ -1216,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, floa
         c2 x[R];
 #pragma unroll
         for (int p = 0; p < R; ++p) {
-            const float4 v = fir_tile[p * pitch + t + q];
+            const float4 v = fir_tile_lds[p * pitch + t + q];
             x[p] = c2{v2{v.x, v.z}, v2{v.y, v.w}};
         }
         v2 wr[2 * R - 1], wi[2 * R - 1];
@@ -1245,12 +1243,94 @@ __global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, floa
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        fir_tile[r * pitch + t] = make_float4(acc[r].re.x, acc[r].im.x, acc[r].re.y, acc[r].im.y);
+        fir_tile_lds[r * pitch + t] = make_float4(acc[r].re.x, acc[r].im.x, acc[r].re.y, acc[r].im.y);
     __syncthreads();
     for (int s = t; s < T * R; s += T) {
         const long long g = base + s;
-        if (g < n_out) *reinterpret_cast<float4*>(out + (g * S + 2 * sp)) = fir_tile[(s % R) * pitch + s / R];
+        if (g < n_out) *reinterpret_cast<float4*>(out + (g * S + 2 * sp)) = fir_tile_lds[(s % R) * pitch + s / R];
     }
+}
+
+template <int R, bool CPLX>
+__global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, float2* __restrict__ out,
+                                             long long n_in, long long n_out, int S,
+                                             const float2* __restrict__ tre,
+                                             const float2* __restrict__ tim, int tap_pitch,
+                                             int n_chunks, int pitch) {
+    extern __shared__ float4 fir_tile_mem[];
+    const int npair = S >> 1;
+    // the pairs of one tile share cache lines: consecutive virtual ids, one XCD
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    fir_tile<R, CPLX>(in, out, n_in, n_out, S, vb % npair, (long long)(vb / npair) * (256 * R), tre, tim,
+                      tap_pitch, n_chunks, pitch, fir_tile_mem);
+}
+
+// The same filter as the first stage of an overlap-save chunk
+// (bbt_osm_execute_prefiltered): block b of the chunk reads its N + n_tap - 1
+// input samples at ch.b[b].in_off and leaves N filtered samples in
+// staging[b * N ...], which the first column pass then reads -- on the plan's
+// lane stream, so the filter (VALU bound) of one chunk runs beside the memory
+// bound passes of the other lane, and the filtered blocks never leave the
+// Infinity Cache.  grid (tiles * npair, blocks).
+template <int R, bool CPLX>
+__global__ __launch_bounds__(256) void k_fir_blocks(const float2* __restrict__ in,
+                                                    float2* __restrict__ staging, OsmChunk ch,
+                                                    long long n_fft, int n_tap, int S,
+                                                    const float2* __restrict__ tre,
+                                                    const float2* __restrict__ tim, int tap_pitch,
+                                                    int n_chunks, int pitch) {
+    extern __shared__ float4 fir_tile_mem[];
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = blockIdx.y;
+    fir_tile<R, CPLX>(in + ch.b[b].in_off * S, staging + (long long)b * n_fft * S, n_fft + n_tap - 1, n_fft,
+                      S, vb % npair, (long long)(vb / npair) * (256 * R), tre, tim, tap_pitch, n_chunks,
+                      pitch, fir_tile_mem);
+}
+
+// ---------------------------------------------------------------------------
+// Unpacking of sampler frames (the decode step of the
+// `baseband` readers in front of the path -- VDIF / DADA payloads).  The
+// reference itself holds no decoder (it takes `baseband` stream readers, a
+// package that is not in this image) and no sample files: this follows the
+// published formats (VDIF 1.1.1: little-endian 32-bit words, the first sample
+// in the least significant bits, channels of a complete sample adjacent, I
+// before Q; DADA: signed 8-bit).  PARITY UNPINNED -- see ingest.py.
+//   raw   : n_frames frames of frame_bytes, payload after header_bytes
+//   out   : float32 [(set * spf + t) * n_thread + thread][e], e < E; frame f
+//           belongs to set f / n_thread, thread f % n_thread
+//   code 0: VDIF levels -- 1 bit {-1, +1}; 2 bits {-3.3359, -1, +1, +3.3359};
+//           4 bits (v - 8) / 2.95; 8 / 16 bits offset binary v - 2^(bits-1)
+//   code 1: two's complement integers (8 or 16 bits)
+__global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict__ raw,
+                                                float* __restrict__ out, long long n_total,
+                                                int frame_bytes, int header_bytes, int bits, int spf,
+                                                int n_thread, int E, int code) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_total) return;
+    const int e = (int)(idx % E);
+    const long long r = idx / E;
+    const int thr = (int)(r % n_thread);
+    const long long s = r / n_thread;
+    const long long set = s / spf;
+    const int t = (int)(s - set * spf);
+    const unsigned char* payload = raw + (set * n_thread + thr) * (long long)frame_bytes + header_bytes;
+    const long long bit = ((long long)t * E + e) * bits;
+    const unsigned word = reinterpret_cast<const unsigned*>(payload)[bit >> 5];
+    const unsigned v = (word >> (bit & 31)) & (bits == 32 ? 0xffffffffu : ((1u << bits) - 1u));
+    float x;
+    if (code == 1) {
+        x = bits == 8 ? (float)(signed char)v : (float)(short)v;
+    } else if (bits == 1) {
+        x = v ? 1.f : -1.f;
+    } else if (bits == 2) {
+        x = v == 0 ? -3.3359f : (v == 1 ? -1.f : (v == 2 ? 1.f : 3.3359f));
+    } else if (bits == 4) {
+        x = ((float)v - 8.f) / 2.95f;
+    } else {
+        x = (float)v - (float)(1u << (bits - 1));
+    }
+    out[idx] = x;
 }
 
 }  // namespace bbt

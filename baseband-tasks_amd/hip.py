@@ -63,6 +63,7 @@ SIGNATURES = {
     'bbt_osm_plan_info': [_vp, _pi64, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
     'bbt_osm_plan_fusable': [_vp, _int],
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
+    'bbt_osm_execute_prefiltered': [_vp, _vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
     'bbt_osm_execute_channelized_detect': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int,
@@ -86,6 +87,7 @@ SIGNATURES = {
     'bbt_fir_execute': [_vp, _vp, _vp, _i64, _vp],
     'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
     'bbt_scale_streams': [_vp, _vp, _i64, _int, _vp, _vp],
+    'bbt_unpack': [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp],
     'bbt_comm_unique_id': [_vp, _sz],
     'bbt_comm_init': [_pvp, _int, _int, _vp, _sz],
     'bbt_comm_destroy': [_vp],
@@ -503,6 +505,18 @@ class OsmPlan(_Plan):
                                     in_off.ctypes.data_as(_pi64), out_off.ctypes.data_as(_pi64),
                                     valid_start.ctypes.data_as(_pi32),
                                     valid_count.ctypes.data_as(_pi32), _stream))
+
+    def execute_prefiltered(self, fir, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
+        """`execute` on blocks that first pass through the direct filter
+        ``fir`` (a `FirPlan`): block b reads ``N + n_tap - 1`` input samples."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
+        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
+        check(lib().bbt_osm_execute_prefiltered(
+            self._h, fir._h, in_dev.ptr, out_dev.ptr, in_off.shape[0], in_off.ctypes.data_as(_pi64),
+            out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
+            valid_count.ctypes.data_as(_pi32), _stream))
 
     def execute_channelized(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count,
                             n_chan, first_spectrum, n_spectra):

@@ -4,6 +4,8 @@ Base of `Disperse`/`Dedisperse` (reference dispersion.py:135-139) and
 `Convolve` (convolution.py:116-120): the geometry is `PaddedTaskBase`'s, the
 arithmetic is one `bbt_osm_execute` call for a whole run of frames.
 """
+import os
+
 import numpy as np
 
 from . import hip
@@ -139,10 +141,36 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         in0 = int(starts[0])
         return in0, int(starts[-1]) + n - in0, starts, frames * spf, self._keep_from + skips, counts
 
+    #: When the input is a `Convolve` (`Resample`, `ShiftAndResample`) that
+    #: filters directly in the time domain, run that filter inside this task's
+    #: plan, block by block (libbbt_hip: bbt_osm_execute_prefiltered): the
+    #: filtered stream is never stored and the filter overlaps the transform
+    #: passes.  The result is the same (the direct filter is block independent).
+    FUSE_PREFILTER = os.environ.get('BBT_FUSE_PREFILTER', '1') != '0'
+
+    def _prefilter_input(self):
+        """The upstream direct-FIR task whose filter this task can absorb, else None."""
+        from .convolution import Convolve
+        up = self.ih
+        if not (self.FUSE_PREFILTER and isinstance(up, Convolve)) or up.closed:
+            return None
+        if self._real or up._real or self._n_stream % 2 or up._n_stream != self._n_stream:
+            return None
+        if self._ih_samples_per_frame < 2048 or not up._use_fir():
+            return None
+        return up
+
     def _compute_frames(self, first, last, out):
         in0, in_len, starts, out_abs, keep, counts = self._block_descriptors(first, last)
-        x = fetch_device(self.ih, in0, in_len)
         out_off = out_abs - first * self.samples_per_frame
+        up = self._prefilter_input()
+        if up is not None:
+            # sample i of the filtered stream is made of input samples [i, i + taps - 1]
+            taps_less_one = up._pad_start + up._pad_end
+            x = fetch_device(up.ih, in0, in_len + taps_less_one)
+            self._get_plan().execute_prefiltered(up._fir, x, out, starts - in0, out_off, keep, counts)
+            return
+        x = fetch_device(self.ih, in0, in_len)
         self._run_plan(x, out, in_len, out.shape[0], starts - in0, out_off, keep, counts)
 
     def close(self):

@@ -139,6 +139,19 @@ int bbt_osm_plan_fusable(const bbt_osm_plan* plan, int n_chan);
 int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
                     const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
                     const int32_t* valid_count, bbt_stream stream);
+/* The same with a short FIR in front of every block (Resample / Convolve with a
+ * short response feeding Dedisperse): block b reads input
+ * samples [in_off[b], in_off[b] + N + n_tap - 1) of `in_dev`, the filter
+ * (bbt_fir_plan, same stream count) turns them into the N samples
+ * sum_k response[k] in[i + n_tap - 1 - k] in a staging buffer of the plan, and
+ * the block transform runs on those.  Equal to filtering the whole stream first
+ * (convolution.py:116-120 is block independent) but the filtered stream never
+ * reaches HBM and the filter (VALU bound) of one chunk overlaps the memory
+ * bound passes of another. */
+int bbt_osm_execute_prefiltered(bbt_osm_plan* plan, const bbt_fir_plan* fir, const void* in_dev,
+                                void* out_dev, int64_t n_blocks, const int64_t* in_off,
+                                const int64_t* out_off, const int32_t* valid_start,
+                                const int32_t* valid_count, bbt_stream stream);
 /* Fused Channelize(Dedisperse(...), n_chan): as bbt_osm_execute, but instead
  * of the dedispersed samples it writes their channelization
  * (Channelize.task, channelize.py:73-74): spectrum s is the unnormalised FFT
@@ -271,6 +284,21 @@ int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream, const void
 int bbt_fir_plan_destroy(bbt_fir_plan* plan);
 int bbt_fir_execute(bbt_fir_plan* plan, const void* in_dev, void* out_dev, int64_t n_out,
                     bbt_stream stream);
+
+/* ---- sampler frames ----------------------------------
+ * Device-side decode of packed VDIF / DADA payloads in front of the path (what
+ * the `baseband` readers the reference is fed with do on the host; the
+ * reference itself has no decoder and no sample files: parity unpinned).
+ * Frame f (frame_bytes each, payload after header_bytes) belongs to thread
+ * f % n_thread of frame set f / n_thread and holds samples_per_frame complete
+ * samples of n_elem components (channels x 1 or 2) of `bits` bits, first
+ * sample in the least significant bits of little-endian 32-bit words.
+ * out: float32 [(set * samples_per_frame + t), thread, component] -- complex64
+ * when the components are (I, Q) pairs.  code 0: VDIF levels (1, 2, 4 bits;
+ * 8, 16 bits offset binary); code 1: two's complement (8, 16 bits; DADA). */
+int bbt_unpack(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
+               int header_bytes, int bits, int samples_per_frame, int n_thread, int n_elem,
+               int code, bbt_stream stream);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------
  * The reference has no distributed code; these are what SURVEY 8(b)/(e) ask a
