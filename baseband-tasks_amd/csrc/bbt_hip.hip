@@ -496,7 +496,13 @@ struct bbt_osm_plan {
 
 template <int N2, int NCH>
 static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, hipStream_t st) {
-    hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>), dim3(p->n1, ch.nblk * p->npair * p->outer),
+    // BBT_ROWPASS_REMAP=0: the older (rows, blocks * pairs) grid
+    static const bool remap = [] { const char* e = getenv("BBT_ROWPASS_REMAP"); return !(e && atoi(e) == 0); }();
+    const bool flat = remap && p->outer == 1 && ch.nblk * p->npair > 1 &&
+                      (long long)p->n1 * ch.nblk * p->npair < (1ll << 31);
+    hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>),
+                       flat ? dim3(p->n1 * ch.nblk * p->npair, 1)
+                            : dim3(p->n1, ch.nblk * p->npair * p->outer),
                        dim3(N2 / 16), 0,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
                        p->wroot, p->wroot + 4096, ch, p->outer);

@@ -1209,8 +1209,9 @@ def test_blocks_longer_than_2_20_with_sixteen_streams(three_level, monkeypatch):
         assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
         assert dd._get_plan().info()['n1'] == (16 if three_level else 4096)
         assert_parity(dd.read(), want, 'dedisperse, 16 streams')
-        for n in (256, 64, 16):
-            ch = bt.Channelize(bt.Dedisperse(nh, dm, reference_frequency=freq), n, 8)
+        ds = bt.DeviceStream(x, T0, 6.25 * u.MHz, frequency=freq, sideband=1)     # (re-reading the noise
+        for n in (256, 64, 16):                                                      # generator per call is slow)
+            ch = bt.Channelize(bt.Dedisperse(ds, dm, reference_frequency=freq), n, 2048 // n * 8)
             assert ch._fusable_input() is not None
             z = ch.read()
             assert_parity(z, orc.channelize(want[:z.shape[0] * n], n), f'fused channelizer {n}, 16 streams')
