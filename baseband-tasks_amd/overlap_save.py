@@ -142,11 +142,16 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         return in0, int(starts[-1]) + n - in0, starts, frames * spf, self._keep_from + skips, counts
 
     #: When the input is a `Convolve` (`Resample`, `ShiftAndResample`) that
-    #: filters directly in the time domain, run that filter inside this task's
-    #: plan, block by block (libbbt_hip: bbt_osm_execute_prefiltered): the
-    #: filtered stream is never stored and the filter overlaps the transform
-    #: passes.  The result is the same (the direct filter is block independent).
-    FUSE_PREFILTER = os.environ.get('BBT_FUSE_PREFILTER', '1') != '0'
+    #: filters directly in the time domain, that filter can run inside this
+    #: task's plan, block by block (libbbt_hip: bbt_osm_execute_prefiltered): the
+    #: filtered stream is then never stored (the result is the same, the direct
+    #: filter being block independent).  Off by default: measured on MI355X for
+    #: config 5 (8 streams, 129 taps) it is 9 % SLOWER than the two tasks in
+    #: turn, 5.06 against 5.59 G complete samples/s -- the overlap of the blocks
+    #: is filtered twice (+25 % filter work) and the VALU-bound filter does not
+    #: overlap the other lane's passes (no room for its waves beside a row
+    #: pass's 150-200 VGPRs); set BBT_FUSE_PREFILTER=1 to save the memory.
+    FUSE_PREFILTER = os.environ.get('BBT_FUSE_PREFILTER', '0') == '1'
 
     def _prefilter_input(self):
         """The upstream direct-FIR task whose filter this task can absorb, else None."""

@@ -464,6 +464,8 @@ def test_config5_resample_dedisperse_8_streams():
     assert (dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame) == \
         (104963, 107513, 2**20, 836100)
     assert abs((dd.start_time - ds.start_time) * 16e6 - (64 + 0.25 + 104963)) < 1e-6
+    assert dd._prefilter_input() is None            # two tasks by default (measured faster)
+    dd.FUSE_PREFILTER = True                        # the filter inside the dedispersion plan
     y = dd.read()
     r, rinfo = orc.resample(x, 0.25, pad=64, samples_per_frame=2**20 - 128,
                             ih_samples_per_frame=2**20)
@@ -1330,8 +1332,8 @@ def test_vdif_frames_are_unpacked_on_the_device(bits, complex_data):
     assert np.array_equal(fh.read_device(700).to_host(), data[1000:1700])
     # feeds the path without touching the host again
     if complex_data and bits == 2:
-        dd = bt.Dedisperse(fh, 0.3, samples_per_frame=2048 - 200)
-        want, _ = orc.dedisperse(data, fs, 300., 1, 0.3, samples_per_frame=2048 - 200, ih_samples_per_frame=spf)
+        dd = bt.Dedisperse(fh, 0.003, samples_per_frame=1024)
+        want, _ = orc.dedisperse(data, fs, 300., 1, 0.003, samples_per_frame=1024, ih_samples_per_frame=spf)
         assert_parity(dd.read(), want, 'Dedisperse(open_vdif(...))')
     hdr = ingest.vdif_header(np.frombuffer(raw[:32], '<u4'))
     assert (hdr['bits'], hdr['n_chan'], hdr['complex_data'], hdr['frame_nr'], hdr['edv']) == \
