@@ -613,8 +613,15 @@ __global__ __launch_bounds__(256) void k_osm_mid16(float2* __restrict__ work, in
 #ifndef BBT_ROWPASS_MINWAVES
 #define BBT_ROWPASS_MINWAVES 1
 #endif
+// The plain row pass (no channelizer) of 1024+ points compiles to 190-208 VGPRs
+// when left alone, i.e. 2 waves per SIMD, which made plain Dedisperse slower
+// than the fused Dedisperse -> Channelize pipeline (150 VGPRs, 3 waves).  Asking
+// for 3 waves caps it at 168 VGPRs at the price of 20-38 spilled dwords.
+#ifndef BBT_ROWPASS_PLAIN_MINWAVES
+#define BBT_ROWPASS_PLAIN_MINWAVES 3
+#endif
 template <int N2, int NCH>
-__global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
+__global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MINWAVES : ((NCH == 0 && N2 >= 1024) ? BBT_ROWPASS_PLAIN_MINWAVES : 1))) void k_osm_rowpass(
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
     const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
@@ -676,7 +683,11 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
     const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
     const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
     wg_fft<N2, -1, 0, IMOFF>(v, lds, tau, 0, tw0, tw1);
+    // keep the response and second-transform table loads from being hoisted above
+    // the first transform (they were for NCH == 0: 199 VGPRs, 2 waves per SIMD)
+    __builtin_amdgcn_sched_barrier(0);
     apply_resp<T>(v, h0, h1, c0 == c1);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (NCH > 0) {
         const int shift = ch.b[bp / npair].shift;
         if (shift != 0) {
@@ -714,8 +725,21 @@ __global__ __launch_bounds__(N2 / 16, BBT_ROWPASS_MINWAVES) void k_osm_rowpass(
             v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
         }
     } else if (N1 > 1) {
+        // Evaluate the twiddles again instead of keeping the 16 products of the
+        // forward step alive through both transforms (the compiler did: 199
+        // VGPRs / 2 waves per SIMD for the plain row pass): the row index goes
+        // through an opaque move so the two evaluations are not merged.
+        int k1b = k1;
+        asm volatile("" : "+s"(k1b));
+        float s2, c2v;
+        sincospif(-2.0f * (float)(k1b * tau) / ((float)N1 * (float)N2), &s2, &c2v);
+        const cf base2 = make_float2(c2v, s2);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(base, wrow(j)));
+        for (int j = 0; j < 16; ++j) {
+            const int x = (k1b * j) & (M - 1);
+            const cf wj = M <= 4096 ? wroot[x * rstride] : cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
+            v[j] = twmul<+1>(v[j], cmul(base2, wj));
+        }
     }
     if constexpr (NCH == 0) {
 #pragma unroll
