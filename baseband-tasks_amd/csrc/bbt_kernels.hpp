@@ -613,12 +613,11 @@ __global__ __launch_bounds__(256) void k_osm_mid16(float2* __restrict__ work, in
 #ifndef BBT_ROWPASS_MINWAVES
 #define BBT_ROWPASS_MINWAVES 1
 #endif
-// The plain row pass (no channelizer) of 1024+ points compiles to 190-208 VGPRs
-// when left alone, i.e. 2 waves per SIMD, which made plain Dedisperse slower
-// than the fused Dedisperse -> Channelize pipeline (150 VGPRs, 3 waves).  Asking
-// for 3 waves caps it at 168 VGPRs at the price of 20-38 spilled dwords.
+// (Capping the plain row pass at 168 VGPRs with launch bounds spilled 34 dwords
+// and was 12 % slower, 35.7 against 40.7 Gsamples/s for config 2; the register
+// count was brought down at the source instead, see the end of the kernel.)
 #ifndef BBT_ROWPASS_PLAIN_MINWAVES
-#define BBT_ROWPASS_PLAIN_MINWAVES 3
+#define BBT_ROWPASS_PLAIN_MINWAVES 1
 #endif
 template <int N2, int NCH>
 __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MINWAVES : ((NCH == 0 && N2 >= 1024) ? BBT_ROWPASS_PLAIN_MINWAVES : 1))) void k_osm_rowpass(
@@ -708,7 +707,16 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
             }
         }
     }
-    wg_fft<N2, +1, 0, IMOFF>(v, lds, tau, 0, tw0, tw1);
+    {
+        // The second transform reads the same twiddle tables as the first: passed
+        // through an opaque move, or the compiler keeps all 30 table values of the
+        // first alive in registers across the whole kernel instead of reloading
+        // them from L1.
+        const cf* tw0b = tw0;
+        const cf* tw1b = tw1;
+        asm volatile("" : "+s"(tw0b), "+s"(tw1b));
+        wg_fft<N2, +1, 0, IMOFF>(v, lds, tau, 0, tw0b, tw1b);
+    }
     if (NCH > 0 && outer > 1) {
         // Three-level + fused channelizer: the outer four-step twiddle
         // W_N^{(N2 a + n2) k1o} has a factor that depends on n2; it must act
@@ -741,9 +749,16 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
             v[j] = twmul<+1>(v[j], cmul(base2, wj));
         }
     }
+    // (Stores that go back to the addresses the row was loaded from take the row
+    // pointer through an opaque move: otherwise the 16 load addresses, 32 VGPRs,
+    // stay alive from the first instruction to the last -- that, with the tables
+    // above, is what made the plain row pass 199 VGPRs / 2 waves per SIMD and
+    // plain Dedisperse slower than the fused pipeline; now 148 / 3.)
     if constexpr (NCH == 0) {
+        float2* row2 = row;
+        asm volatile("" : "+s"(row2));
 #pragma unroll
-        for (int j = 0; j < 16; ++j) st_int(row + (long long)(tau + T * j) * 2, v[j]);
+        for (int j = 0; j < 16; ++j) st_int(row2 + (long long)(tau + T * j) * 2, v[j]);
     } else if constexpr (NCH < 256) {
         // Few channels, NCH = 16 L (L = 1, 2, 4, 8): a group of NCH consecutive
         // samples n2 is spread over the lanes (register j of thread tau is
@@ -796,8 +811,10 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
                 }
             }
         }
+        float2* row2 = row;
+        asm volatile("" : "+s"(row2));
 #pragma unroll
-        for (int a = 0; a < 16; ++a) st_int(row + (long long)(tau + T * a) * 2, v[a]);
+        for (int a = 0; a < 16; ++a) st_int(row2 + (long long)(tau + T * a) * 2, v[a]);
     } else {
         // channelizer: thread tau holds n2 = tau + T j: group q = j / P, element
         // m = tau + T (j % P) of the NCH = P * T point transform.
