@@ -34,7 +34,7 @@ def main():
     dev = torch.device('cuda', 0)
     bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
     streams = 8 if args.config == 'config5' else 2
-    nblk = args.blocks or (12 if streams == 8 else 96)
+    nblk = args.blocks or (24 if streams == 8 else 384)
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     x = torch.view_as_complex(torch.randn((nblk * 2**20, streams, 2), generator=g, device=dev,
