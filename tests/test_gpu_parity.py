@@ -1358,3 +1358,67 @@ def test_dada_samples_are_unpacked_on_the_device():
     assert np.array_equal(got, want[:got.shape[0]])
     assert fh.sample_rate == 16e6
     assert abs((fh.start_time - bt.Time('2020-01-01T00:00:00')) - 1600 / 16e6) < 1e-12
+
+
+def test_random_overlap_save_geometries():
+    """Randomised block lengths (powers of two and other 2^a 3^b 5^c 7^d), response
+    lengths and offsets, stream shapes and ragged stream ends against the oracle."""
+    rng = np.random.default_rng(2024)
+    lengths = [64, 128, 256, 512, 1024, 4096, 8192, 16384, 65536, 300, 1000, 1536, 2187, 6174, 7000, 8192 * 3,
+               10000, 30000, 46080]
+    shapes = [(2,), (3,), (2, 2), (), (4,)]
+    limit_r, limit_c = bt.Convolve.FIR_MAX_TAPS, bt.Convolve.FIR_MAX_TAPS_COMPLEX
+    bt.Convolve.FIR_MAX_TAPS = bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0          # always the block transform
+    try:
+        for case in range(24):
+            n_fft = int(rng.choice(lengths))
+            shape = shapes[case % len(shapes)]
+            n_tap = int(rng.integers(2, max(3, n_fft // 3)))
+            offset = int(rng.integers(0, n_tap))
+            n_in = int(n_fft * rng.integers(1, 4) + rng.integers(0, n_fft))
+            resp = (rng.standard_normal((n_tap,) + shape) + 1j * rng.standard_normal((n_tap,) + shape)) / np.sqrt(n_tap)
+            resp = resp.astype(np.complex64)
+            x = (rng.standard_normal((n_in,) + shape) + 1j * rng.standard_normal((n_in,) + shape)).astype(np.complex64)
+            ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=min(n_in, 1000))
+            cv = bt.Convolve(ds, resp, offset=offset, samples_per_frame=n_fft - n_tap + 1)
+            assert cv._ih_samples_per_frame == n_fft, (case, n_fft, n_tap)
+            want, info = orc.convolve(x, resp, offset=offset, samples_per_frame=n_fft - n_tap + 1,
+                                      ih_samples_per_frame=min(n_in, 1000))
+            got = cv.read()
+            assert_parity(got, want, f'case {case}: n_fft {n_fft} taps {n_tap} offset {offset} shape {shape} n_in {n_in}')
+            # a read from the middle equals the whole
+            if got.shape[0] > 10:
+                a = int(rng.integers(0, got.shape[0] - 5))
+                cv.seek(a)
+                assert np.array_equal(cv.read(5), got[a:a + 5])
+    finally:
+        bt.Convolve.FIR_MAX_TAPS, bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit_r, limit_c
+
+
+def test_random_fused_channelizer_geometries():
+    """Randomised block length / channel count / framing for Channelize on top of
+    Dedisperse (fused route), against the oracle: every spectrum, seams included."""
+    rng = np.random.default_rng(77)
+    for case in range(16):
+        n_fft = int(2 ** rng.integers(13, 18))
+        n_chan = int(rng.choice([16, 32, 64, 128, 256, 512, 1024, 2048, 4096]))
+        fs = 2e6
+        dm = float(rng.uniform(2., 8.))
+        g = orc.disperse_geometry(fs, 400., 1, -dm)
+        pad = g['pad_start'] + g['pad_end']
+        if pad >= n_fft // 2 or n_chan > n_fft - pad:
+            continue
+        spf = n_fft - pad
+        n_in = int(spf * rng.integers(2, 5) + pad + rng.integers(0, spf))
+        sample_shape = (2,) if case % 3 else (2, 2)
+        x = (rng.standard_normal((n_in,) + sample_shape) + 1j * rng.standard_normal((n_in,) + sample_shape)).astype(np.complex64)
+        ds = bt.DeviceStream(x, T0, fs, frequency=400 * u.MHz, sideband=1)
+        dd = bt.Dedisperse(ds, dm, samples_per_frame=spf)
+        assert dd._ih_samples_per_frame == n_fft
+        ch = bt.Channelize(dd, n_chan, samples_per_frame=int(rng.integers(1, 40)))
+        plan = dd._get_plan()
+        y, _ = orc.dedisperse(x, fs, 400., 1, dm, samples_per_frame=spf, ih_samples_per_frame=min(n_in, 4096))
+        z = ch.read()
+        want = orc.channelize(y[:z.shape[0] * n_chan], n_chan)
+        assert_parity(z, want, f'case {case}: n_fft {n_fft} n_chan {n_chan} fused={plan.fusable(n_chan)} '
+                               f'frames of {ch.samples_per_frame} n_in {n_in} shape {sample_shape}')
