@@ -1415,7 +1415,7 @@ def test_random_fused_channelizer_geometries():
         ds = bt.DeviceStream(x, T0, fs, frequency=400 * u.MHz, sideband=1)
         dd = bt.Dedisperse(ds, dm, samples_per_frame=spf)
         assert dd._ih_samples_per_frame == n_fft
-        ch = bt.Channelize(dd, n_chan, samples_per_frame=int(rng.integers(1, 40)))
+        ch = bt.Channelize(dd, n_chan, samples_per_frame=int(min(rng.integers(1, 40), dd.shape[0] // n_chan)))
         plan = dd._get_plan()
         y, _ = orc.dedisperse(x, fs, 400., 1, dm, samples_per_frame=spf, ih_samples_per_frame=min(n_in, 4096))
         z = ch.read()
