@@ -979,7 +979,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (chunk > BBT_MAX_CHUNK) chunk = BBT_MAX_CHUNK;
     if (p->outer > 1) {                       // grid.y = blocks * pairs * 256 must fit
         while (chunk > 1 && (long long)chunk * p->npair * p->outer > 65535) --chunk;
-        if (chunk * per_block * lanes > (768u << 20)) lanes = 1;
+        // BBT_OSM_BIG_LANES=1: one lane for work buffers beyond 768 MiB (round 1's rule)
+        static const bool one = [] { const char* e = getenv("BBT_OSM_BIG_LANES"); return e && atoi(e) == 1; }();
+        if (one && chunk * per_block * lanes > (768u << 20)) lanes = 1;
     }
     while (chunk > 1 && (long long)chunk * p->npair > 65535) --chunk;      // grid.y of the row pass
     if ((double)chunk * per_block * lanes > 16.0 * (1u << 30)) lanes = 1;   // (config 4: 2 x 2 GiB)
