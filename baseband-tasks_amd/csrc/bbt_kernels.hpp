@@ -1258,7 +1258,9 @@ __device__ __forceinline__ void fir_tile(const float2* __restrict__ in, float2* 
         const long long g = base + s;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g < n_in) x = *reinterpret_cast<const float4*>(in + (g * S + 2 * sp));
-        fir_tile_lds[(s % R) * pitch + s / R] = x;
+        // the tile holds register order (re_A re_B im_A im_B): the swizzle is done once per
+        // sample here instead of once per use in the tap loop (3 v_mov per input, 15 % of its VALU)
+        fir_tile_lds[(s % R) * pitch + s / R] = make_float4(x.x, x.z, x.y, x.w);
     }
     __syncthreads();
     const float2* gre = tre + (long long)sp * tap_pitch;
@@ -1271,7 +1273,7 @@ __device__ __forceinline__ void fir_tile(const float2* __restrict__ in, float2* 
 #pragma unroll
         for (int p = 0; p < R; ++p) {
             const float4 v = fir_tile_lds[p * pitch + t + q];
-            x[p] = c2{v2{v.x, v.z}, v2{v.y, v.w}};
+            x[p] = c2{v2{v.x, v.y}, v2{v.z, v.w}};
         }
         v2 wr[2 * R - 1], wi[2 * R - 1];
 #pragma unroll
