@@ -292,6 +292,37 @@ def verify_config4(x, z, freq_mhz, n_blocks, n_spec, spf):
 
 
 # ---------------------------------------------------------------------------
+def _timed_gather(args, torch, dist, sharding, comm, backend, dev, coll_dev, world, step, fence, z,
+                  samples_per_step):
+    """Steps that end with the collective (outputs gathered)."""
+    zt = torch.view_as_real(torch.as_tensor(z, device=dev))
+    n_g = max(2, args.steps // 4)
+
+    def gathered_step():
+        zz = step()
+        t_ = torch.view_as_real(torch.as_tensor(zz, device=dev))
+        if backend != 'nccl':
+            t_ = t_.cpu()
+        if args.workload == 'config4':
+            return sharding.gather_subbands(t_, torch, dist, comm)
+        return sharding.gather_frames(t_, torch, dist, comm)
+    g_out = gathered_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(n_g):
+        g_out = gathered_step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    return dict(value=round(world * samples_per_step * n_g / dt / 1e6, 1), unit='Msamples/s',
+                steps=n_g, ms_per_step=round(dt / n_g * 1e3, 4), gathered_shape=list(g_out.shape),
+                bytes_received_per_rank_per_step=int(zt.numel() * 4 * (world - 1)),
+                collective=('bbt_gather_output (C ABI, RCCL)' if comm is not None else
+                            'all_gather_into_tensor over ' + ('RCCL/xGMI' if backend == 'nccl' else backend)))
+
+
 def dry_run_rank():
     """BBT_BENCH_DRYRUN=1: exercise only the launch / rendezvous / exit-code
     plumbing (gloo on the CPU, no GPU, no kernels); used by the CPU tests.
