@@ -1,0 +1,55 @@
+"""Throughput of the generic (non power-of-two) overlap-save path next to the
+power-of-two one (dev tool): Dedisperse at 800 / 1000 / 1400 MHz, default block
+(the reference's rule) and `power_of_two=True`."""
+import gc
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import baseband_tasks_amd as bt
+from baseband_tasks_amd.fourier import HipFFTMaker
+
+dev = torch.device('cuda', 0)
+bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+x = torch.view_as_complex(torch.randn((96 * 2**20, 2, 2), generator=g, device=dev, dtype=torch.float32))
+
+
+def rate(task, reps=5):
+    task.max_frames_per_call = 10**6
+    n = task.shape[0]
+
+    def step():
+        task.invalidate_cache()
+        task.seek(0)
+        return task.read_device(n)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    gc.disable()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    gc.enable()
+    return n * reps / (time.perf_counter() - t0) / 1e6
+
+
+for fc in (800e6, 1000e6, 1400e6, 600e6):
+    ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
+    dd = bt.Dedisperse(ds, 100.)
+    info = dd._get_plan().info()
+    line = f"{fc / 1e6:6.0f} MHz default block {dd._ih_samples_per_frame:8d} = {info['n1']} x {info['n2']}: {rate(dd):9.1f} Msamples/s"
+    with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
+        d2 = bt.Dedisperse(ds, 100.)
+    line += f"   | power of two {d2._ih_samples_per_frame:8d}: {rate(d2):9.1f} Msamples/s"
+    print(line, flush=True)
+    del dd, d2
+for n in (1000, 1536, 3000, 6561, 8192):
+    ds = bt.DeviceStream(x[:16 * 2**20], '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    ch = bt.Channelize(ds, n, 64)
+    print(f"Channelize({n}): {rate(ch) * n:9.1f} Msamples/s", flush=True)

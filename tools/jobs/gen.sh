@@ -1,0 +1,5 @@
+#!/bin/bash
+OUT=$GRAFT_REPO_ROOT/gpurun_out/gen
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python3 tools/bench_generic.py 2>&1 | grep -v amdgpu.ids | tee $OUT/generic.txt
