@@ -1422,3 +1422,28 @@ def test_random_fused_channelizer_geometries():
         want = orc.channelize(y[:z.shape[0] * n_chan], n_chan)
         assert_parity(z, want, f'case {case}: n_fft {n_fft} n_chan {n_chan} fused={plan.fusable(n_chan)} '
                                f'frames of {ch.samples_per_frame} n_in {n_in} shape {sample_shape}')
+
+
+def test_bench_two_ranks_share_this_gpu():
+    """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
+    ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
+    rank runs and verifies its own blocks against the oracle, outputs are
+    gathered, rank 0 prints one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBT_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+                        '--warmup', '1', '--blocks', '24', '--no-cpu'], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['verified']['ok'] and d['verified']['all_ranks_ok']
+    assert d['with_gather'] and 'error' not in d['with_gather'], d['with_gather']
+    assert d['with_gather']['gathered_shape'][0] == 2 * (24 * 836100 // 1024 // 512) * 512
