@@ -350,6 +350,33 @@ def main():
     out['c5_dd_geo'] = g
     out['c5_dd_shift'] = np.array([((dd.start_time - nh.start_time) * nh.sample_rate).to_value(u.one)])
 
+    # ---- default arguments at full scale: the reference's own (non power-of-two) blocks
+    # (a) Dedisperse(DM=100) of a 16 MHz band at 800 MHz: block next_fast_len(4 * pad) = 1 666 980
+    nh = noise((4 * 2**20, 2), 16 * u.MHz, 2**20, 800. * u.MHz, 1)
+    dd = Dedisperse(nh, 100.)
+    g, shift = geometry(dd, nh)
+    out['d8_geo'] = g
+    out['d8_shift'] = shift
+    spf = dd.samples_per_frame
+    y = dd.read()
+    out['d8_head'] = y[:1024]
+    out['d8_seam1'] = y[spf - 512:spf + 512]
+    out['d8_tail'] = y[-1024:]
+    out['d8_stats_blocks'] = np.stack([stats(y[i * spf:(i + 1) * spf]) for i in range(-(-y.shape[0] // spf))])
+    # (b) config 5's first stage with default arguments: Resample picks blocks of 1 049 760 samples
+    nh = noise((3 * 2**20, 2), 16 * u.MHz, 2**20, 1000. * u.MHz, 1)
+    rs = Resample(nh, 0.25, pad=64)
+    g, shift = geometry(rs, nh)
+    out['r5_geo'] = g
+    out['r5_shift'] = shift
+    rs.seek(0)
+    r = rs.read()
+    spf = rs.samples_per_frame
+    out['r5_head'] = r[:1024]
+    out['r5_seam1'] = r[spf - 512:spf + 512]
+    out['r5_tail'] = r[-1024:]
+    out['r5_stats'] = stats(r)
+
     np.savez_compressed('reference_vectors.npz', **out)
     total = sum(v.nbytes for v in out.values())
     print('wrote reference_vectors.npz with %d arrays, %.2f MB raw' % (len(out), total / 1e6))

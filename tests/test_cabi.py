@@ -111,3 +111,33 @@ def test_sanitized_host_build_passes_the_abi_checks():
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert '3 passed' in r.stdout
+
+
+def build_c_example():
+    """gcc build of tests/cabi_example.c against include/bbt_hip.h and the in-tree library."""
+    import subprocess
+    exe = os.path.join(ROOT, 'build', 'cabi_example')
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.join(ROOT, 'baseband-tasks_amd', 'lib')
+    hip.lib()                                            # (builds nothing: raises if the library is missing)
+    subprocess.check_call(['gcc', '-std=c99', '-D_DEFAULT_SOURCE', '-Wall', '-Wextra', '-Werror',
+                           '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'cabi_example.c'),
+                           '-L', libdir, '-lbbt_hip', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib',
+                           '-lm', '-o', exe])
+    return exe
+
+
+def test_plain_c_program_links_against_the_abi():
+    """The header is C (not C++) and the library needs nothing but itself: a gcc
+    -Wall -Wextra -Werror build of a C host program links; without a GPU it
+    stops at the first call with the library's own error text."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    exe = build_c_example()
+    if hip.available():
+        pytest.skip('a GPU is present: the program is run by the -m gpu suite')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and 'bbt_device_count' in r.stderr and 'hipGetDeviceCount' in r.stderr

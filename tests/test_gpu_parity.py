@@ -1447,3 +1447,46 @@ def test_bench_two_ranks_share_this_gpu():
     assert d['verified']['ok'] and d['verified']['all_ranks_ok']
     assert d['with_gather'] and 'error' not in d['with_gather'], d['with_gather']
     assert d['with_gather']['gathered_shape'][0] == 2 * (24 * 836100 // 1024 // 512) * 512
+
+
+def test_default_arguments_at_full_scale_golden(golden):
+    """Default-argument tasks on full-size streams against the REAL reference's
+    output (tests/golden/make_golden.py): Dedisperse(DM 100) at 800 MHz picks
+    1 666 980-sample blocks (1260 x 1323 on the generic path), Resample 1 049 760."""
+    nh = noise(4 * 2**20, (2,), 2**20, frequency=800 * u.MHz, sideband=1)
+    ds = bt.DeviceStream(nh, T0, 16 * u.MHz)
+    dd = bt.Dedisperse(ds, 100.)
+    assert [dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame, dd.shape[0],
+            dd._sample_offset] == list(golden['d8_geo'])
+    y = dd.read()
+    spf = dd.samples_per_frame
+    assert_parity(y[:1024], golden['d8_head'], 'head')
+    assert_parity(y[spf - 512:spf + 512], golden['d8_seam1'], 'seam')
+    assert_parity(y[-1024:], golden['d8_tail'], 'tail')
+    nh = noise(3 * 2**20, (2,), 2**20, frequency=1000 * u.MHz, sideband=1)
+    ds = bt.DeviceStream(nh, T0, 16 * u.MHz)
+    limit = bt.Convolve.FIR_MAX_TAPS
+    for taps_limit in (limit, 0):                   # the direct filter, and the 1 049 760-sample block transform
+        bt.Convolve.FIR_MAX_TAPS = taps_limit
+        try:
+            rs = bt.Resample(ds, 0.25, pad=64)
+            assert [rs._pad_start, rs._pad_end, rs._ih_samples_per_frame, rs.samples_per_frame,
+                    rs.shape[0]] == list(golden['r5_geo'][:5])
+            rs.seek(0)
+            r = rs.read()
+        finally:
+            bt.Convolve.FIR_MAX_TAPS = limit
+        spf = rs.samples_per_frame
+        assert_parity(r[:1024], golden['r5_head'], 'head')
+        assert_parity(r[spf - 512:spf + 512], golden['r5_seam1'], 'seam')
+        assert_parity(r[-1024:], golden['r5_tail'], 'tail')
+
+
+def test_plain_c_program_on_the_abi():
+    """tests/cabi_example.c: a C (gcc) host program on include/bbt_hip.h -- an
+    overlap-save delay filter over two blocks and a channelizer -- runs on the GPU."""
+    import subprocess
+    from test_cabi import build_c_example
+    r = subprocess.run([build_c_example()], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'C ABI example OK' in r.stdout and 'expected error' in r.stdout

@@ -348,3 +348,30 @@ def test_time_delay(golden):
     y = orc.time_delay_stream(x, 1.234e-6, 300e6, np.array([1, -1]))
     assert np.abs(y - golden['st_delay']).max() < 2e-6
     assert abs(golden['st_delay_shift'][0] - 1.234) < 1e-6
+
+
+def test_default_arguments_at_full_scale(golden):
+    """The reference's own block choices for full-size streams (not powers of
+    two): Dedisperse(DM 100) at 800 MHz -> 1 666 980-sample blocks; Resample at
+    2^20-sample source frames -> 1 049 760."""
+    x = orc.noise_stream(12345, 0, 4 * 2**20, 2**20, (2,))
+    y, info = orc.dedisperse(x, 16e6, 800., 1, 100., ih_samples_per_frame=2**20)
+    assert [info['pad_start'], info['pad_end'], info['ih_spf'], info['spf'], info['n_out'],
+            info['sample_offset']] == list(golden['d8_geo'])
+    assert info['ih_spf'] == 1666980
+    spf = info['spf']
+    for name, sl in (('d8_head', slice(0, 1024)), ('d8_seam1', slice(spf - 512, spf + 512)),
+                     ('d8_tail', slice(-1024, None))):
+        assert rel_l2(y[sl], golden[name]) < TIGHT, name
+    nblk = -(-y.shape[0] // spf)
+    np.testing.assert_allclose(np.stack([stats(y[i * spf:(i + 1) * spf]) for i in range(nblk)]),
+                               golden['d8_stats_blocks'], rtol=1e-5, atol=1.0)
+    x = orc.noise_stream(12345, 0, 3 * 2**20, 2**20, (2,))
+    r, rinfo = orc.resample(x, 0.25, pad=64, ih_samples_per_frame=2**20)
+    assert [rinfo['pad_start'], rinfo['pad_end'], rinfo['ih_spf'], rinfo['spf'], rinfo['n_out']] == \
+        list(golden['r5_geo'][:5])
+    assert abs(rinfo['start_shift_samples'] - golden['r5_shift'][0]) < 1e-4
+    spf = rinfo['spf']
+    for name, sl in (('r5_head', slice(0, 1024)), ('r5_seam1', slice(spf - 512, spf + 512)),
+                     ('r5_tail', slice(-1024, None))):
+        assert rel_l2(r[sl], golden[name]) < TIGHT, name
