@@ -594,6 +594,32 @@ __global__ __launch_bounds__(256) void k_osm_mid16(float2* __restrict__ work, in
     for (int a = 0; a < 16; ++a) st_int(w + (long long)a * N2 * 2, v[a]);
 }
 
+// value of lane (id ^ H) for H = 1, 2 (DPP quad_perm) or 4 (ds_swizzle bit mode)
+template <int H>
+__device__ __forceinline__ float lane_xor(float x) {
+    int i = __float_as_int(x);
+    if constexpr (H == 1) i = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (H == 2) i = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else i = __builtin_amdgcn_ds_swizzle(i, (H << 10) | 0x1F);                                 // xor H within 32 lanes
+    return __int_as_float(i);
+}
+// one radix-2 DIF stage over the lane digit c (mask H) of an L-point transform spread over L lanes
+template <int H, int L>
+__device__ __forceinline__ void lane_radix2_stage(c2 (&v)[16], int c, const cf* __restrict__ wroot) {
+    const bool upper = (c & H) != 0;
+    const cf w = wroot[((c & (H - 1)) * (L / (2 * H))) * (4096 / L)];     // W_{2H}^{c mod H}
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        c2 o;
+        o.re.x = lane_xor<H>(v[a].re.x);
+        o.re.y = lane_xor<H>(v[a].re.y);
+        o.im.x = lane_xor<H>(v[a].im.x);
+        o.im.y = lane_xor<H>(v[a].im.y);
+        if (upper) v[a] = twmul<-1>(csub(o, v[a]), w);
+        else v[a] = cadd(v[a], o);
+    }
+}
+
 // Row pass: for row k1 of a (block, pair): four-step twiddle, forward FFT
 // over n2, multiply by the response, inverse FFT over k2, conjugate twiddle.
 //   wroot : W_4096^m, m in [0, 4096)
@@ -619,8 +645,13 @@ __global__ __launch_bounds__(256) void k_osm_mid16(float2* __restrict__ work, in
 #ifndef BBT_ROWPASS_PLAIN_MINWAVES
 #define BBT_ROWPASS_PLAIN_MINWAVES 1
 #endif
+// The few-channel variants (32..128 channels) sit at 170-176 VGPRs; asking for
+// 3 waves per SIMD costs 2-11 spilled dwords.
+#ifndef BBT_ROWPASS_SMALL_MINWAVES
+#define BBT_ROWPASS_SMALL_MINWAVES 3
+#endif
 template <int N2, int NCH>
-__global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MINWAVES : ((NCH == 0 && N2 >= 1024) ? BBT_ROWPASS_PLAIN_MINWAVES : 1))) void k_osm_rowpass(
+__global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MINWAVES : ((NCH == 0 && N2 >= 1024) ? BBT_ROWPASS_PLAIN_MINWAVES : ((NCH > 16 && NCH < 256) ? BBT_ROWPASS_SMALL_MINWAVES : 1)))) void k_osm_rowpass(
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
     const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
@@ -777,39 +808,33 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             __syncthreads();
+            // element n2 sits at n2 + (n2 >> 4); written out so that both address sets are one
+            // per-thread base plus compile-time offsets (T and 16 L are multiples of 16, c < L)
+            static_assert(T % 16 == 0, "row threads must be a multiple of 16");
+            const int wbase = tau + (tau >> 4), rbase = 17 * L * q + c;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int n2 = tau + T * j;
-                lds[n2 + (n2 >> 4)] = half ? v[j].im : v[j].re;        // L (n2 / (16 L)) + n2 % ... == n2 + n2 / 16 rounded per group
-            }
+            for (int j = 0; j < 16; ++j) lds[wbase + T * j + (T * j) / 16] = half ? v[j].im : v[j].re;
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int n2 = NCH * q + c + L * i;
-                const v2 x = lds[n2 + (n2 >> 4)];
+                const v2 x = lds[rbase + L * i + (L * i) / 16];
                 if (half) v[i].im = x; else v[i].re = x;
             }
         }
         radix16<-1>(v);
         if constexpr (L > 1) {
+            // (unsigned index: scalar base + 32-bit lane offset, no 64-bit address per load;
+            // four loads in flight at a time instead of fifteen)
 #pragma unroll
-            for (int a = 1; a < 16; ++a) v[a] = twmul<-1>(v[a], wroot[(c * a) * (4096 / NCH)]);
-            // DIF over the lane digit c: mask h = L/2, L/4, ..., 1
-#pragma unroll
-            for (int h = L / 2; h >= 1; h >>= 1) {
-                const bool upper = (c & h) != 0;
-                const cf w = wroot[((c & (h - 1)) * (L / (2 * h))) * (4096 / L)];     // W_{2h}^{c mod h}
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    c2 o;
-                    o.re.x = __shfl_xor(v[a].re.x, h);
-                    o.re.y = __shfl_xor(v[a].re.y, h);
-                    o.im.x = __shfl_xor(v[a].im.x, h);
-                    o.im.y = __shfl_xor(v[a].im.y, h);
-                    if (upper) v[a] = twmul<-1>(csub(o, v[a]), w);
-                    else v[a] = cadd(v[a], o);
-                }
+            for (int a = 1; a < 16; ++a) {
+                v[a] = twmul<-1>(v[a], wroot[(unsigned)(c * a) * (unsigned)(4096 / NCH)]);
+                if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            // DIF over the lane digit c: masks L/2, ..., 2, 1 -- within a quad by DPP
+            // quad_perm moves, across quads (L = 8) by ds_swizzle; no address registers
+            if constexpr (L >= 8) lane_radix2_stage<4, L>(v, c, wroot);
+            if constexpr (L >= 4) lane_radix2_stage<2, L>(v, c, wroot);
+            lane_radix2_stage<1, L>(v, c, wroot);
         }
         float2* row2 = row;
         asm volatile("" : "+s"(row2));
