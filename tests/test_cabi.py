@@ -62,6 +62,25 @@ def test_argument_validation_reports_errors():
                                                   0, 0, 64, 1, 1, None) != 0
     assert lib.bbt_osm_detect_bins_max(None, 1024, 64) == -1
     assert lib.bbt_free(C.c_void_p(12345)) != 0 and b'not allocated' in lib.bbt_last_error()
+    # entry points added in round 2
+    assert lib.bbt_osm_execute_prefiltered(None, None, None, None, 0, None, None, None, None, None) != 0
+    assert lib.bbt_osm_plan_fusable(None, 1024) == 0
+    raw = np.zeros(64, np.uint8)
+    assert lib.bbt_unpack(raw.ctypes.data, raw.ctypes.data, 3, 64, 32, 2, 128, 2, 1, 0, None) != 0
+    assert b'whole sets' in lib.bbt_last_error()
+    assert lib.bbt_unpack(raw.ctypes.data, raw.ctypes.data, 2, 64, 32, 3, 8, 1, 1, 0, None) != 0
+    assert b'bits per component' in lib.bbt_last_error()
+    assert lib.bbt_unpack(raw.ctypes.data, raw.ctypes.data, 2, 64, 32, 2, 129, 1, 1, 0, None) != 0
+    assert b'do not fit' in lib.bbt_last_error()
+    assert lib.bbt_unpack(raw.ctypes.data, raw.ctypes.data, 2, 64, 32, 8, 8, 1, 1, 7, None) != 0
+    assert lib.bbt_comm_unique_id(None, 128) != 0
+    assert lib.bbt_comm_unique_id(raw.ctypes.data, 16) != 0 and b'128' in lib.bbt_last_error()
+    comm = C.c_void_p()
+    assert lib.bbt_comm_init(C.byref(comm), 2, 5, raw.ctypes.data, 128) != 0 and b'rank 5 of 2' in lib.bbt_last_error()
+    assert lib.bbt_comm_init(C.byref(comm), 1, 0, raw.ctypes.data, 8) != 0
+    assert lib.bbt_bcast_chirp(None, None, 0, 0, None) != 0 and lib.bbt_gather_output(None, None, None, 0, None) != 0
+    assert lib.bbt_comm_destroy(None) == 0
+    assert lib.bbt_pool_set_stream(None) == 0
     # destroying null plans is harmless
     assert lib.bbt_osm_plan_destroy(None) == 0 and lib.bbt_chan_plan_destroy(None) == 0
     assert lib.bbt_pfb_plan_destroy(None) == 0 and lib.bbt_fir_plan_destroy(None) == 0
