@@ -1490,3 +1490,35 @@ def test_plain_c_program_on_the_abi():
     r = subprocess.run([build_c_example()], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'C ABI example OK' in r.stdout and 'expected error' in r.stdout
+
+
+@pytest.mark.parametrize('n_fft', [1000, 2187, 3125, 2401 * 3, 6174, 12000])
+def test_real_streams_on_block_lengths_that_are_not_powers_of_two(n_fft):
+    """float32 streams (the reference's rfft / irfft engine paths,
+    fourier/numpy.py:41-49) with even and ODD block lengths, paired and
+    unpaired streams, through the generic transform."""
+    assert HipFFTMaker.next_fast_len(n_fft) == n_fft
+    rng = np.random.default_rng(n_fft)
+    n_tap = 37
+    limit = bt.Convolve.FIR_MAX_TAPS
+    bt.Convolve.FIR_MAX_TAPS = 0
+    try:
+        for shape, per_stream in (((2,), False), ((3,), True), ((4,), True)):
+            resp = rng.standard_normal((n_tap,) + (shape if per_stream else (1,))).astype(np.float32)
+            n_in = 2 * n_fft + 321
+            x = rng.standard_normal((n_in,) + shape).astype(np.float32)
+            src = bt.StreamGenerator(lambda fh: x[fh.tell():fh.tell() + fh.samples_per_frame], x.shape, T0, 1e6,
+                                     samples_per_frame=n_in, dtype=np.float32)
+            cv = bt.Convolve(src, resp, samples_per_frame=n_fft - n_tap + 1)
+            assert cv._ih_samples_per_frame == n_fft and cv.dtype == np.float32
+            got = cv.read()
+            # truth: the exact linear convolution (which is what Convolve keeps, block independent)
+            full = np.broadcast_to(resp, (n_tap,) + shape).astype(np.float64)
+            want = np.stack([np.convolve(x[:, i].astype(np.float64), full[:, i], mode='valid')
+                             for i in range(shape[0])], axis=1)
+            assert got.dtype == np.float32 and got.shape == want.shape
+            err = np.linalg.norm((got - want).ravel()) / np.linalg.norm(want.ravel())
+            assert err < REL_L2_TOL and np.abs(got - want).max() < MAX_TOL * np.sqrt(np.mean(want ** 2)), \
+                (n_fft, shape, err)
+    finally:
+        bt.Convolve.FIR_MAX_TAPS = limit
