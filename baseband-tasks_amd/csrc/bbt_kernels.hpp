@@ -796,7 +796,8 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         // n2 = tau + T j), so one more exchange through LDS hands thread
         // t' = L q + c the 16 samples c + L i (i < 16) of group q; radix-16 over
         // i on registers, twiddle W_NCH^{c a}, then the radix-L step over c
-        // across L neighbouring lanes with wavefront shuffles.  Lane c ends up
+        // across L neighbouring lanes with wavefront butterflies (DPP quad_perm /
+        // ds_swizzle moves, lane_radix2_stage).  Lane c ends up
         // with channels a + 16 bitrev_L(c); they are stored at row position
         // t' + T a (coalesced), which the column pass maps back
         // (small_channel_slot below).  LDS pitch: L extra slots per group, so the
