@@ -8,7 +8,7 @@ raises if that library is missing -- there is no CPU fallback.
 """
 from . import units
 from .units import Time
-from .base import (Base, BaseTaskBase, TaskBase, PaddedTaskBase, Task, SetAttribute)
+from .base import (Base, BaseTaskBase, TaskBase, PaddedTaskBase, Task, SetAttribute, SinglePrecision)
 from .generators import (StreamGenerator, EmptyStreamGenerator, Noise, NoiseGenerator,
                          DeviceStream)
 from .dm import DispersionMeasure

@@ -23,7 +23,7 @@ import numpy as np
 from . import units as u
 from .units import Time
 
-__all__ = ['Base', 'BaseTaskBase', 'TaskBase', 'PaddedTaskBase', 'Task',
+__all__ = ['SinglePrecision', 'Base', 'BaseTaskBase', 'TaskBase', 'PaddedTaskBase', 'Task',
            'SetAttribute', 'META_ATTRIBUTES']
 
 META_ATTRIBUTES = ('frequency', 'sideband', 'polarization')
@@ -492,6 +492,24 @@ class Task(TaskBase):
                 raise
         self.task = types.MethodType(task, self) if method else task
         super().__init__(ih, **kwargs)
+
+
+class SinglePrecision(TaskBase):
+    """float64 / complex128 stream -> float32 / complex64, frame by frame on the
+    host.  The kernels of this package compute in single precision (like the
+    reference on its usual float32 / complex64 `baseband` data); the reference
+    also accepts double-precision streams (its PFB tests use them), so a chain
+    written for such a stream becomes ``Dedisperse(SinglePrecision(fh), dm)``.
+    Streams that are already single precision pass through unchanged."""
+
+    def __init__(self, ih, **kwargs):
+        kind = np.dtype(ih.dtype).kind
+        if kind not in 'fc':
+            raise TypeError(f"cannot convert a stream of {ih.dtype} to single precision.")
+        super().__init__(ih, dtype=np.complex64 if kind == 'c' else np.float32, **kwargs)
+
+    def task(self, data):
+        return np.ascontiguousarray(data, dtype=self.dtype)
 
 
 class SetAttribute(TaskBase):

@@ -128,7 +128,7 @@ class Channelize(_RowFFTTask):
         samples_per_frame = operator.index(samples_per_frame)
         if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
             raise TypeError("the accelerated channelizer handles complex64 and float32 streams; "
-                            f"got {ih.dtype}.")
+                            f"got {ih.dtype} (wrap the stream in SinglePrecision(...)).")
         _check_n(n)
         # real streams: n // 2 + 1 channels (rfft); computed as the complex
         # transform of the zero-extended stream, upper half dropped

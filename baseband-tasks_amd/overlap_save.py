@@ -38,7 +38,7 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
     def __init__(self, ih, pad_start, pad_end, *, samples_per_frame=None, **kwargs):
         if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
             raise TypeError("the accelerated path handles complex64 and float32 streams; got "
-                            f"{ih.dtype}.")
+                            f"{ih.dtype} (wrap the stream in SinglePrecision(...)).")
         # float32 streams run through the same complex kernels with the
         # Hermitian-extended response (what rfft -> multiply -> irfft computes
         # in the reference).  Its impulse response is real, so it acts on real

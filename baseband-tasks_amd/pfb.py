@@ -55,7 +55,7 @@ class PolyphaseFilterBank(_RowFFTTask):
         _check_n(n, minimum=256)
         if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
             raise TypeError("the accelerated filter bank handles complex64 and float32 streams; "
-                            f"got {ih.dtype}.")
+                            f"got {ih.dtype} (wrap the stream in SinglePrecision(...)).")
         self._real = np.dtype(ih.dtype).kind == 'f'
         n_out = n // 2 + 1 if self._real else n
         pad = (n_tap - 1) * n

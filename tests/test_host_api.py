@@ -393,3 +393,22 @@ def test_integrate_and_channelize_shapes_for_random_sizes():
             assert ch.sample_rate == 1e3 / n_chan
 
     check()
+
+
+def test_single_precision_adapter():
+    """float64 / complex128 streams (the reference accepts them; its PFB tests use
+    them) enter the single-precision path through `SinglePrecision`."""
+    nh = bt.NoiseGenerator((4000, 2), T0, 1e6, 1000, dtype=np.complex128, seed=3, frequency=300e6, sideband=1)
+    with pytest.raises(TypeError, match='SinglePrecision'):
+        bt.Channelize(nh, 64)
+    sp = bt.SinglePrecision(nh)
+    assert sp.dtype == np.complex64 and sp.shape == nh.shape and sp.sample_rate == nh.sample_rate
+    assert sp.start_time == nh.start_time and np.all(sp.frequency == nh.frequency)
+    sp.seek(500)
+    got = sp.read(1700)
+    nh.seek(500)
+    assert got.dtype == np.complex64 and np.array_equal(got, nh.read(1700).astype(np.complex64))
+    assert bt.Channelize(sp, 50).shape == (80, 50, 2)
+    real = bt.NoiseGenerator((3000,), T0, 1e6, 1000, dtype=np.float64, seed=4)
+    assert bt.SinglePrecision(real).dtype == np.float32
+    assert bt.SinglePrecision(bt.SinglePrecision(real)).read(10).dtype == np.float32
