@@ -258,7 +258,11 @@ __device__ __forceinline__ SpecCursor spec_cursor(float2* __restrict__ out, cons
 __device__ __forceinline__ void emit_spectrum(c2 val, const SpecCursor& c, int j) {
     int rel = c.rel + j * c.drel;
     if (rel >= c.wrap_at) {
-        // the one group that wraps around the end of the block: it sits before sample 0
+        // The one group that wraps around the end of the block.  Its leading samples
+        // are the block's last ones, so it can hold the end of the kept range (when
+        // n_chan exceeds the padding); its trailing samples sit before sample 0, so
+        // it can hold the start of the kept range too.  Both are seam spectra.
+        if (rel < c.vc) st_ext(c.seam1, val);
         rel -= c.n_fft;
         if (rel < 0 && rel + c.nch > 0) st_ext(c.seam0, val);
         return;
@@ -454,7 +458,8 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
             for (int j = 0; j < 16; ++j) {
                 int rel = cur.rel + j * cur.drel;
                 bool full = false;
-                if (rel >= cur.wrap_at) {
+                if (rel >= cur.wrap_at) {                        // see emit_spectrum
+                    if (rel < cur.vc) st_ext(cur.seam1, v[j]);
                     rel -= cur.n_fft;
                     if (rel < 0 && rel + cur.nch > 0) st_ext(cur.seam0, v[j]);
                 } else if (rel >= 0 && rel + cur.nch <= cur.vc) {

@@ -1401,7 +1401,7 @@ def test_random_fused_channelizer_geometries():
     """Randomised block length / channel count / framing for Channelize on top of
     Dedisperse (fused route), against the oracle: every spectrum, seams included."""
     rng = np.random.default_rng(77 + int(os.environ.get('BBT_TEST_SEED', '0')))
-    for case in range(16):
+    for case in range(48):
         n_fft = int(2 ** rng.integers(13, 18))
         n_chan = int(rng.choice([16, 32, 64, 128, 256, 512, 1024, 2048, 4096]))
         fs = 2e6
@@ -1424,6 +1424,49 @@ def test_random_fused_channelizer_geometries():
         want = orc.channelize(y[:z.shape[0] * n_chan], n_chan)
         assert_parity(z, want, f'case {case}: n_fft {n_fft} n_chan {n_chan} fused={plan.fusable(n_chan)} '
                                f'frames of {ch.samples_per_frame} n_in {n_in} shape {sample_shape}')
+
+
+@pytest.mark.parametrize('n_fft,n_chan,detect', [
+    (2**14, 1024, False),      # 16 x 1024: one spectrum per row
+    (2**15, 2048, False),      # 16 x 2048: one spectrum per row
+    (2**16, 4096, False),      # 16 x 4096
+    (2**16, 128, False),       # few channels (lane exchange)
+    (2**18, 1024, False),      # 256 x 1024
+    (2**18, 1024, True),       # ... with the powers summed in the last pass
+    (2**20, 4096, False),      # 256 x 4096
+    (2**21, 2048, False),      # three levels
+])
+def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
+    """When n_chan exceeds the block's padding, the last n_chan-aligned group of a
+    block both wraps around the block end and holds the end of the kept range:
+    it is the tail half of a seam spectrum (and, wrapped, possibly the head half
+    of another one).  Every seam spectrum must match the oracle."""
+    rng = np.random.default_rng(n_fft // n_chan)
+    fs, n_tap = 2e6, 57                                  # padding 56 < every n_chan here
+    resp = (rng.standard_normal(n_tap) + 1j * rng.standard_normal(n_tap)).astype(np.complex64)
+    spf = n_fft - n_tap + 1
+    n_in = 3 * spf + n_tap - 1 + 777
+    x = (rng.standard_normal((n_in, 2)) + 1j * rng.standard_normal((n_in, 2))).astype(np.complex64)
+    limit = bt.Convolve.FIR_MAX_TAPS_COMPLEX
+    bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0                 # the Fourier-domain plan, not the direct FIR
+    try:
+        ds = bt.DeviceStream(x, T0, fs)
+        cv = bt.Convolve(ds, resp, samples_per_frame=spf)
+        assert cv._ih_samples_per_frame == n_fft
+        plan = cv._get_plan()
+        assert plan.fusable(n_chan)
+        ch = bt.Channelize(cv, n_chan, samples_per_frame=3)
+        y = np.stack([np.convolve(x[:, k].astype(np.complex128), resp.astype(np.complex128), mode='valid')
+                      for k in range(2)], axis=1)
+        n_spec = y.shape[0] // n_chan
+        want = orc.channelize(y[:n_spec * n_chan].astype(np.complex64), n_chan)
+        if detect:
+            got = bt.Integrate(bt.Power(ch), 64, samples_per_frame=1).read()
+            _close(got, orc.integrate(orc.power(want), 64), rtol=2e-5)
+        else:
+            assert_parity(ch.read(), want, f'n_fft {n_fft} n_chan {n_chan}')
+    finally:
+        bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
 
 
 def test_bench_two_ranks_share_this_gpu():
