@@ -1430,11 +1430,11 @@ def test_random_fused_channelizer_geometries():
     (2**14, 1024, False),      # 16 x 1024: one spectrum per row
     (2**15, 2048, False),      # 16 x 2048: one spectrum per row
     (2**16, 4096, False),      # 16 x 4096
-    (2**16, 128, False),       # few channels (lane exchange)
+    (2**18, 128, False),       # few channels (lane exchange)
     (2**18, 1024, False),      # 256 x 1024
     (2**18, 1024, True),       # ... with the powers summed in the last pass
     (2**20, 4096, False),      # 256 x 4096
-    (2**21, 2048, False),      # three levels
+    (2**21, 512, False),       # three levels, 256 x 16 x 512
 ])
 def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
     """When n_chan exceeds the block's padding, the last n_chan-aligned group of a
@@ -1450,7 +1450,7 @@ def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
     limit = bt.Convolve.FIR_MAX_TAPS_COMPLEX
     bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0                 # the Fourier-domain plan, not the direct FIR
     try:
-        ds = bt.DeviceStream(x, T0, fs)
+        ds = bt.DeviceStream(x, T0, fs, polarization=['X', 'Y'])
         cv = bt.Convolve(ds, resp, samples_per_frame=spf)
         assert cv._ih_samples_per_frame == n_fft
         plan = cv._get_plan()
@@ -1464,7 +1464,9 @@ def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
             got = bt.Integrate(bt.Power(ch), 64, samples_per_frame=1).read()
             _close(got, orc.integrate(orc.power(want), 64), rtol=2e-5)
         else:
-            assert_parity(ch.read(), want, f'n_fft {n_fft} n_chan {n_chan}')
+            got = ch.read()                                # whole frames of three spectra
+            assert n_spec - 3 < got.shape[0] <= n_spec
+            assert_parity(got, want[:got.shape[0]], f'n_fft {n_fft} n_chan {n_chan}')
     finally:
         bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
 
