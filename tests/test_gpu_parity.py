@@ -1471,6 +1471,46 @@ def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
         bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
 
 
+def test_random_windows_of_the_fused_channelizer():
+    """Random (seek, count) reads of Channelize(Dedisperse) and of
+    Integrate(Power(...)) against slices of the oracle's whole result: windows
+    that start and stop inside blocks, single spectra, seams first or last."""
+    rng = np.random.default_rng(5 + int(os.environ.get('BBT_TEST_SEED', '0')))
+    fs = 2e6
+    for n_fft, n_chan, dm in ((2**16, 2048, 3.), (2**18, 256, 6.), (2**18, 64, 2.5), (2**15, 512, 7.)):
+        g = orc.disperse_geometry(fs, 400., 1, -dm)
+        pad = g['pad_start'] + g['pad_end']
+        spf = n_fft - pad
+        n_in = 5 * spf + pad + int(rng.integers(0, spf))
+        x = (rng.standard_normal((n_in, 2)) + 1j * rng.standard_normal((n_in, 2))).astype(np.complex64)
+        ds = bt.DeviceStream(x, T0, fs, frequency=400 * u.MHz, sideband=1, polarization=['X', 'Y'])
+        y, _ = orc.dedisperse(x, fs, 400., 1, dm, samples_per_frame=spf, ih_samples_per_frame=min(n_in, 4096))
+        n_spec = y.shape[0] // n_chan
+        want = orc.channelize(y[:n_spec * n_chan], n_chan)
+        dd = bt.Dedisperse(ds, dm, samples_per_frame=spf)
+        assert dd._get_plan().fusable(n_chan)
+        ch = bt.Channelize(dd, n_chan, samples_per_frame=1)
+        assert ch.shape[0] == n_spec
+        seam_spectra = [(k * spf) // n_chan for k in range(1, 5)]
+        windows = [(s, 1) for s in seam_spectra[:2]] + [(seam_spectra[2], 2), (seam_spectra[3] - 1, 2)]
+        for _ in range(10):
+            a = int(rng.integers(0, n_spec - 1))
+            windows.append((a, int(rng.integers(1, min(n_spec - a, 3 * spf // n_chan) + 1))))
+        for a, count in windows:
+            ch.seek(a)
+            assert_parity(ch.read(count), want[a:a + count], f'n_fft {n_fft} n_chan {n_chan} window {a}+{count}')
+        if n_chan >= 256:
+            step = 16
+            power = orc.integrate(orc.power(want), step)
+            it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds, dm, samples_per_frame=spf), n_chan,
+                                                     samples_per_frame=1)), step, samples_per_frame=1)
+            for _ in range(6):
+                a = int(rng.integers(0, power.shape[0] - 1))
+                count = int(rng.integers(1, power.shape[0] - a + 1))
+                it.seek(a)
+                _close(it.read(count), power[a:a + count], rtol=2e-5)
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
