@@ -1511,6 +1511,62 @@ def test_random_windows_of_the_fused_channelizer():
                 _close(it.read(count), power[a:a + count], rtol=2e-5)
 
 
+def test_random_filter_bank_channelizer_and_resampler_geometries():
+    """Randomised PolyphaseFilterBank (taps, channels, framing, real and complex
+    streams, odd stream counts), Channelize (any 2^a 3^b 5^c 7^d channel count) and
+    Resample (offsets, padding) against the oracle."""
+    rng = np.random.default_rng(303 + int(os.environ.get('BBT_TEST_SEED', '0')))
+    shapes = [(2,), (3,), (2, 2), (), (5,)]
+    for case in range(12):
+        n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        n_tap = int(rng.integers(2, 17))
+        shape = shapes[case % len(shapes)]
+        real = bool(case % 2)
+        n_frames_in = int(rng.integers(8, 14))        # (the padded frame must fit the stream)
+        ih_spf = int(n_chan * rng.integers(n_tap + 1, n_tap + 12))
+        n_in = ih_spf * n_frames_in
+        if real:
+            x = rng.standard_normal((n_in,) + shape).astype(np.float32)
+        else:
+            x = (rng.standard_normal((n_in,) + shape) + 1j * rng.standard_normal((n_in,) + shape)).astype(np.complex64)
+        resp = (orc.sinc_hamming(n_tap, n_chan) * rng.uniform(0.5, 2.)).astype(np.float64)
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=ih_spf)
+        pfb = bt.PolyphaseFilterBank(ds, resp)
+        want, geo = orc.polyphase_filter_bank(x, resp, ih_spf)
+        assert pfb.samples_per_frame == geo['chan_spf']
+        assert_parity(pfb.read(), want.astype(np.complex64), f'pfb case {case}: n {n_chan} taps {n_tap} {shape} real={real}')
+    for case in range(12):
+        n_chan = int(rng.choice([2, 6, 16, 24, 100, 243, 256, 343, 1000, 1536, 4096, 6000, 8192]))
+        shape = shapes[case % len(shapes)]
+        real = bool(case % 2) and n_chan % 2 == 0
+        n_spec = int(rng.integers(3, 40))
+        if real:
+            x = rng.standard_normal((n_spec * n_chan + 3,) + shape).astype(np.float32)
+        else:
+            x = (rng.standard_normal((n_spec * n_chan + 3,) + shape)
+                 + 1j * rng.standard_normal((n_spec * n_chan + 3,) + shape)).astype(np.complex64)
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz)
+        ch = bt.Channelize(ds, n_chan, samples_per_frame=int(rng.integers(1, n_spec + 1)))
+        got = ch.read()
+        want = orc.channelize(x[:got.shape[0] * n_chan], n_chan)
+        assert 0 < got.shape[0] <= n_spec
+        assert_parity(got, want.astype(np.complex64), f'channelize case {case}: n {n_chan} {shape} real={real}')
+    for case in range(8):
+        shape = shapes[case % len(shapes)]
+        pad = int(rng.choice([16, 32, 64]))
+        offset = float(rng.uniform(0., 3.))
+        n_in = int(rng.integers(20000, 60000))
+        ih_spf = int(rng.choice([1000, 4096, 10000]))
+        n_in -= n_in % ih_spf
+        x = (rng.standard_normal((n_in,) + shape) + 1j * rng.standard_normal((n_in,) + shape)).astype(np.complex64)
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=ih_spf)
+        rs = bt.Resample(ds, offset, pad=pad)
+        want, info = orc.resample(x, offset, pad=pad, ih_samples_per_frame=ih_spf)
+        rs.seek(0)
+        assert_parity(rs.read(), want, f'resample case {case}: offset {offset} pad {pad} {shape}')
+        assert abs((rs.start_time - ds.start_time) * 1e6 - info['start_shift_samples']) < 1e-6
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
