@@ -1567,6 +1567,69 @@ def test_random_filter_bank_channelizer_and_resampler_geometries():
         assert abs((rs.start_time - ds.start_time) * 1e6 - info['start_shift_samples']) < 1e-6
 
 
+def test_random_block_descriptors_through_the_c_abi():
+    """bbt_osm_execute / bbt_osm_execute_channelized with descriptors the host
+    classes never produce: every block with its own input offset, first kept
+    sample (0 included: the spectrum before the block start then wraps around the
+    block end) and kept count; the output stream starting anywhere.  Checked
+    against a float64 numpy model of what the header promises."""
+    from baseband_tasks_amd import hip
+    rng = np.random.default_rng(909 + int(os.environ.get('BBT_TEST_SEED', '0')))
+    for case in range(10):
+        n_fft = int(2 ** rng.choice([14, 15, 16, 17, 18]))
+        S = int(rng.choice([2, 4]))
+        n_resp = int(rng.choice([1, S]))
+        resp = np.exp(2j * np.pi * rng.uniform(size=(n_resp, n_fft))) * rng.uniform(0.5, 1.5, size=(n_resp, n_fft))
+        resp = resp.astype(np.complex64)
+        index = None if n_resp == 1 else np.arange(S, dtype=np.int32)
+        plan = hip.OsmPlan(n_fft, S, resp, index)
+        n2 = plan.info()['n2']
+        choices = [c for c in (16, 64, 128, 256, 512, 1024, 2048, 4096) if plan.fusable(c)]
+        n_chan = int(rng.choice(choices))
+        n_blocks = int(rng.integers(2, 7))
+        L = 3 * n_fft
+        x = (rng.standard_normal((L, S)) + 1j * rng.standard_normal((L, S))).astype(np.complex64)
+        in_off = rng.integers(0, L - n_fft + 1, size=n_blocks)
+        vs = rng.integers(0, n_fft // 4, size=n_blocks)
+        vs[rng.integers(0, n_blocks)] = 0
+        vc = np.array([rng.integers(n_chan, n_fft - v + 1) for v in vs])
+        vc[rng.integers(0, n_blocks)] = n_fft - vs[0] if rng.integers(0, 2) else n_chan
+        vc = np.minimum(vc, n_fft - vs)
+        out0 = int(rng.integers(0, 3 * n_chan))
+        out_off = out0 + np.concatenate([[0], np.cumsum(vc)[:-1]])
+        total = int(out_off[-1] + vc[-1])
+        # the model: each block filtered on its own (circularly), kept part placed in the stream
+        stream = np.zeros((total, S), np.complex128)
+        h = resp.astype(np.complex128)[(index if index is not None else np.zeros(S, int))]      # (S, N)
+        for b in range(n_blocks):
+            blk = x[in_off[b]:in_off[b] + n_fft].astype(np.complex128)
+            y = np.fft.ifft(np.fft.fft(blk, axis=0) * h.T, axis=0)
+            stream[out_off[b]:out_off[b] + vc[b]] = y[vs[b]:vs[b] + vc[b]]
+        x_dev = hip.DeviceArray.from_host(x)
+        what = f'case {case}: n_fft {n_fft} S {S} n_chan {n_chan} vs {vs.tolist()} vc {vc.tolist()} out0 {out0}'
+        plain = hip.DeviceArray((total, S), np.complex64).fill_bytes(0)
+        plan.execute(x_dev, plain, in_off, out_off, vs, vc)
+        got = plain.to_host()
+        assert_parity(got[out0:], stream[out0:].astype(np.complex64), 'plain ' + what)
+        assert not got[:out0].any()
+        first = -(-out0 // n_chan)
+        n_spec = total // n_chan - first
+        assert n_spec > 0
+        want = np.fft.fft(stream[first * n_chan:(first + n_spec) * n_chan].reshape(n_spec, n_chan, S), axis=1)
+        spectra = hip.DeviceArray((n_spec, n_chan, S), np.complex64).fill_bytes(0)
+        plan.execute_channelized(x_dev, spectra.reshape(n_spec * n_chan, S), in_off, out_off, vs, vc, n_chan,
+                                 first, n_spec)
+        assert_parity(spectra.to_host(), want.astype(np.complex64), 'channelized ' + what)
+        # a window of the spectra only
+        if n_spec > 3:
+            a = int(rng.integers(1, n_spec - 1))
+            k = int(rng.integers(1, n_spec - a + 1))
+            part = hip.DeviceArray((k, n_chan, S), np.complex64).fill_bytes(0)
+            plan.execute_channelized(x_dev, part.reshape(k * n_chan, S), in_off, out_off, vs, vc, n_chan,
+                                     first + a, k)
+            assert_parity(part.to_host(), want[a:a + k].astype(np.complex64), 'window ' + what)
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
