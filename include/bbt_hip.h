@@ -159,9 +159,11 @@ int bbt_osm_execute_prefiltered(bbt_osm_plan* plan, const bbt_fir_plan* fir, con
  * would have produced.  Spectra first_spectrum .. first_spectrum+n_spectra-1
  * are stored to out_dev as (n_spectra, n_chan, S); blocks must be consecutive
  * in the output stream (out_off[b+1] == out_off[b] + valid_count[b]) wherever a
- * wanted spectrum straddles them.  n_chan: power of two, 256 <= n_chan <=
- * row length (bbt_osm_plan_info n2), n_fft > 4096, valid_count >= n_chan.
- * The dedispersed stream itself never exists in memory. */
+ * wanted spectrum straddles them.  n_chan: whatever bbt_osm_plan_fusable
+ * accepts (a power of two, 256 <= n_chan <= row length n2 of
+ * bbt_osm_plan_info, or 16..128 for blocks with 256 or 4096 columns or of three
+ * levels; power-of-two n_fft > 4096), valid_count >= n_chan; valid_start may be
+ * anything, 0 included.  The dedispersed stream itself never exists in memory. */
 int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
                                 int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
                                 const int32_t* valid_start, const int32_t* valid_count, int n_chan,
