@@ -1575,17 +1575,19 @@ def test_random_block_descriptors_through_the_c_abi():
     against a float64 numpy model of what the header promises."""
     from baseband_tasks_amd import hip
     rng = np.random.default_rng(909 + int(os.environ.get('BBT_TEST_SEED', '0')))
-    for case in range(10):
-        n_fft = int(2 ** rng.choice([14, 15, 16, 17, 18]))
+    lengths = [2**12, 2**13, 2**14, 2**15, 2**16, 2**17, 2**18, 2**19, 2**20, 2**21, 3000, 6174, 30000, 46080,
+               131220]
+    for case in range(12):
+        n_fft = int(rng.choice(lengths))
         S = int(rng.choice([2, 4]))
         n_resp = int(rng.choice([1, S]))
         resp = np.exp(2j * np.pi * rng.uniform(size=(n_resp, n_fft))) * rng.uniform(0.5, 1.5, size=(n_resp, n_fft))
         resp = resp.astype(np.complex64)
         index = None if n_resp == 1 else np.arange(S, dtype=np.int32)
         plan = hip.OsmPlan(n_fft, S, resp, index)
-        n2 = plan.info()['n2']
+        geo = plan.info()
         choices = [c for c in (16, 64, 128, 256, 512, 1024, 2048, 4096) if plan.fusable(c)]
-        n_chan = int(rng.choice(choices))
+        n_chan = int(rng.choice(choices)) if choices else 16          # (not fusable: plain only)
         n_blocks = int(rng.integers(2, 7))
         L = 3 * n_fft
         x = (rng.standard_normal((L, S)) + 1j * rng.standard_normal((L, S))).astype(np.complex64)
@@ -1612,6 +1614,8 @@ def test_random_block_descriptors_through_the_c_abi():
         got = plain.to_host()
         assert_parity(got[out0:], stream[out0:].astype(np.complex64), 'plain ' + what)
         assert not got[:out0].any()
+        if not choices:
+            continue
         first = -(-out0 // n_chan)
         n_spec = total // n_chan - first
         assert n_spec > 0
@@ -1628,6 +1632,27 @@ def test_random_block_descriptors_through_the_c_abi():
             plan.execute_channelized(x_dev, part.reshape(k * n_chan, S), in_off, out_off, vs, vc, n_chan,
                                      first + a, k)
             assert_parity(part.to_host(), want[a:a + k].astype(np.complex64), 'window ' + what)
+        # the powers summed in the last pass instead of stored spectra
+        step = int(rng.integers(1, 40))
+        if (geo['n1'] == 256 and n_fft <= 2**20 and n_chan >= 256 and n_spec >= step
+                and plan.detect_bins_max(n_chan, step) <= 64):
+            n_bins = n_spec // step
+            mode = int(rng.integers(0, 2))
+            z = want[:n_bins * step].reshape(n_bins, step, n_chan, S)
+            if mode:
+                zp = z.reshape(n_bins, step, n_chan, S // 2, 2)
+                xx, yy = zp[..., 0], zp[..., 1]
+                cross = xx * yy.conj()
+                pw = np.stack([np.abs(xx) ** 2, np.abs(yy) ** 2, cross.real, cross.imag], axis=-1).mean(axis=1)
+                shape = (n_bins, n_chan, S // 2, 4)
+            else:
+                pw = (np.abs(z) ** 2).mean(axis=1)
+                shape = (n_bins, n_chan, S)
+            det = hip.DeviceArray(shape, np.float32).fill_bytes(0)
+            plan.execute_channelized_detect(x_dev, det, in_off, out_off, vs, vc, n_chan, first, n_bins, step, mode)
+            d = det.to_host()
+            scale = np.sqrt(np.mean(pw[..., :2] ** 2)) if mode else np.sqrt(np.mean(pw ** 2))
+            assert np.abs(d - pw).max() <= 2e-5 * scale * max(1., np.sqrt(step)), ('detect ' + what, step, mode)
 
 
 def test_bench_two_ranks_share_this_gpu():
