@@ -1579,16 +1579,16 @@ def test_random_block_descriptors_through_the_c_abi():
                131220]
     for case in range(12):
         n_fft = int(rng.choice(lengths))
-        S = int(rng.choice([2, 4]))
-        n_resp = int(rng.choice([1, S]))
+        S = int(rng.choice([2, 4, 6, 16]))
+        n_resp = int(rng.choice([1, S // 2, S]))
         resp = np.exp(2j * np.pi * rng.uniform(size=(n_resp, n_fft))) * rng.uniform(0.5, 1.5, size=(n_resp, n_fft))
         resp = resp.astype(np.complex64)
-        index = None if n_resp == 1 else np.arange(S, dtype=np.int32)
+        index = None if n_resp == 1 else (np.arange(S, dtype=np.int32) * n_resp) // S    # one per stream or per pair
         plan = hip.OsmPlan(n_fft, S, resp, index)
         geo = plan.info()
         choices = [c for c in (16, 64, 128, 256, 512, 1024, 2048, 4096) if plan.fusable(c)]
         n_chan = int(rng.choice(choices)) if choices else 16          # (not fusable: plain only)
-        n_blocks = int(rng.integers(2, 7))
+        n_blocks = int(rng.integers(2, 7 if S * n_fft <= 2**23 else 4))
         L = 3 * n_fft
         x = (rng.standard_normal((L, S)) + 1j * rng.standard_normal((L, S))).astype(np.complex64)
         in_off = rng.integers(0, L - n_fft + 1, size=n_blocks)
