@@ -464,6 +464,8 @@ struct bbt_osm_plan {
     float2* lane_work[BBT_MAX_LANES] = {};
     hipStream_t lane_stream[BBT_MAX_LANES] = {};
     hipEvent_t ev_fork = nullptr, ev_join[BBT_MAX_LANES] = {};
+    hipEvent_t ev_done = nullptr;   // end of the previous execute call (on whatever stream it ran)
+    bool ev_done_set = false;
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     cf* wroot = nullptr;
@@ -800,6 +802,22 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
     return 0;
 }
 
+// One execute call at a time per plan -- on the host (the mutex) and on the
+// device: the work, staging and seam buffers belong to the running call, so a
+// call queued on another stream than the previous one first waits for that
+// call's last kernel.
+struct PlanCall {
+    bbt_osm_plan* p;
+    hipStream_t st;
+    std::lock_guard<std::mutex> lock;
+    PlanCall(bbt_osm_plan* plan, hipStream_t stream) : p(plan), st(stream), lock(plan->mu) {
+        if (p->ev_done_set) (void)hipStreamWaitEvent(st, p->ev_done, 0);
+    }
+    ~PlanCall() {
+        if (hipEventRecord(p->ev_done, st) == hipSuccess) p->ev_done_set = true;
+    }
+};
+
 // Run all chunks, alternating lanes; returns with `st` ordered after every lane.
 template <class FillChunk>
 static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n_blocks,
@@ -1005,6 +1023,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     } else {
         p->lanes = 1;
     }
+    if (hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess)
+        return bail(fail("bbt_osm_plan_create: creating the completion event failed"));
     *plan = p;
     return 0;
 }
@@ -1027,6 +1047,7 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
         if (p->lane_stage[l]) hipFree(p->lane_stage[l]);
     }
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_done) hipEventDestroy(p->ev_done);
     if (p->seam) hipFree(p->seam);
     delete p;
     return 0;
@@ -1058,7 +1079,7 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
         return 1;
     hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
-    std::lock_guard<std::mutex> lock(p->mu);
+    PlanCall call(p, st);
     return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
                        [&](OsmBlock& blk, int64_t b) {
                            blk.in_off = in_off[b];
@@ -1080,7 +1101,7 @@ int bbt_osm_execute_prefiltered(bbt_osm_plan* p, const bbt_fir_plan* fir, const 
     ARG_TRY(p->n >= 256 * BBT_FIR_R, "%s: blocks of %lld samples are too short", who, (long long)p->n);
     if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lock(p->mu);
+    PlanCall call(p, st);
     const size_t bytes = (size_t)p->chunk * p->n * p->S * sizeof(float2);
     for (int l = 0; l < p->lanes; ++l)
         if (!p->lane_stage[l]) HIP_TRY(hipMalloc((void**)&p->lane_stage[l], bytes));
@@ -1122,7 +1143,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
         ARG_TRY(valid_count[b] >= n_chan, "%s: block %lld keeps %d samples < n_chan", who,
                 (long long)b, valid_count[b]);
     if (n_blocks == 0 || n_spectra == 0) return 0;
-    std::lock_guard<std::mutex> lock(p->mu);
+    PlanCall call(p, st);
     FftTables tabc;
     GenGeo gsmall = {};
     cf* wsmall = nullptr;

@@ -112,9 +112,12 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  *               the inverse transform is applied by the library
  *   resp_on_device  0: `resp` is a host pointer; 1: device pointer
  *   resp_index  S ints: response column used by each stream (NULL = all 0)
- * A plan runs one execute call at a time (calls on one plan are serialised by
- * a mutex inside it: its work buffers, seam buffer and events belong to the
- * running call); bbt_osm_plan_create itself synchronises the device when
+ * A plan runs one execute call at a time: its work buffers, seam buffer and
+ * events belong to the running call, so calls on one plan are serialised by a
+ * mutex inside it on the host and, on the device, a call first makes its stream
+ * wait for the end of the previous call (which may have run on another stream).
+ * Calls on different plans are independent.
+ * bbt_osm_plan_create itself synchronises the device when
  * `resp` is a device pointer, so a response still being written on another
  * stream is complete before it is permuted.
  */

@@ -1655,6 +1655,107 @@ def test_random_block_descriptors_through_the_c_abi():
             assert np.abs(d - pw).max() <= 2e-5 * scale * max(1., np.sqrt(step)), ('detect ' + what, step, mode)
 
 
+def test_host_threads_with_their_own_streams_and_plans():
+    """Four host threads on one device, each with its own HIP stream and plans
+    (and the shared twiddle-table caches, created concurrently on first use),
+    plus two threads sharing ONE plan (its mutex serialises them): every result
+    equals the single-threaded one bit for bit."""
+    import ctypes as C
+    import threading
+    from baseband_tasks_amd import hip
+    lib = hip.lib()
+    rng = np.random.default_rng(4)
+    jobs = []
+    for n_fft, n_chan, S in ((2**14, 512, 2), (2**17, 512, 4), (6174, 0, 2), (2**16, 2048, 2)):
+        resp = np.exp(2j * np.pi * rng.uniform(size=(1, n_fft))).astype(np.complex64)
+        x = (rng.standard_normal((4 * n_fft, S)) + 1j * rng.standard_normal((4 * n_fft, S))).astype(np.complex64)
+        vs, vc = n_fft // 8, n_fft - n_fft // 4
+        in_off = np.arange(4, dtype=np.int64) * vc
+        in_off = in_off[in_off + n_fft <= x.shape[0]]
+        nb = len(in_off)
+        jobs.append(dict(n_fft=n_fft, n_chan=n_chan, S=S, resp=resp, x_dev=hip.DeviceArray.from_host(x), nb=nb,
+                         in_off=in_off, out_off=np.arange(nb, dtype=np.int64) * vc,
+                         vs=np.full(nb, vs, np.int32), vc=np.full(nb, vc, np.int32),
+                         out=hip.DeviceArray((nb * vc, S), np.complex64).fill_bytes(0)))
+    p64, p32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+
+    def run(job, plan, stream, reps, results, key, errors):
+        try:
+            for _ in range(reps):
+                out = job['out'] if key != 'shared-b' else job['out_b']
+                args = (job['x_dev'].ptr, out.ptr, job['nb'], job['in_off'].ctypes.data_as(p64),
+                        job['out_off'].ctypes.data_as(p64), job['vs'].ctypes.data_as(p32),
+                        job['vc'].ctypes.data_as(p32))
+                if job['n_chan']:
+                    n_spec = (job['nb'] * int(job['vc'][0])) // job['n_chan']
+                    rc = lib.bbt_osm_execute_channelized(plan, *args, job['n_chan'], 0, n_spec, stream)
+                else:
+                    rc = lib.bbt_osm_execute(plan, *args, stream)
+                if rc:
+                    raise RuntimeError(lib.bbt_last_error().decode())
+                if lib.bbt_stream_sync(stream):
+                    raise RuntimeError(lib.bbt_last_error().decode())
+            results[key] = out.to_host().copy()
+        except Exception as exc:                       # surfaces in the main thread
+            errors.append((key, repr(exc)))
+
+    def make_plan(job):
+        plan = C.c_void_p()
+        rc = lib.bbt_osm_plan_create(C.byref(plan), job['n_fft'], job['S'], 1, job['resp'].ctypes.data, 0, None)
+        assert rc == 0, lib.bbt_last_error()
+        return plan
+
+    # single-threaded truth (fresh plans, default stream)
+    truth, errors = {}, []
+    for k, job in enumerate(jobs):
+        plan = make_plan(job)
+        run(job, plan, None, 1, truth, k, errors)
+        lib.bbt_osm_plan_destroy(plan)
+        job['out'].fill_bytes(0)
+    assert not errors, errors
+    hip.synchronize()
+    # threads: plan creation inside the thread too
+    results = {}
+
+    def worker(k, job):
+        stream = C.c_void_p()
+        assert lib.bbt_stream_create(C.byref(stream)) == 0
+        plan = make_plan(job)
+        run(job, plan, stream, 8, results, k, errors)
+        lib.bbt_osm_plan_destroy(plan)
+        lib.bbt_stream_destroy(stream)
+
+    threads = [threading.Thread(target=worker, args=(k, job)) for k, job in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(len(jobs)):
+        assert np.array_equal(results[k], truth[k]), k
+    # two threads, one plan, two streams
+    job = jobs[1]
+    job['out_b'] = hip.DeviceArray(job['out'].shape, np.complex64).fill_bytes(0)
+    job['out'].fill_bytes(0)
+    hip.synchronize()
+    plan = make_plan(job)
+    streams = [C.c_void_p(), C.c_void_p()]
+    for st in streams:
+        assert lib.bbt_stream_create(C.byref(st)) == 0
+    shared = {}
+    threads = [threading.Thread(target=run, args=(job, plan, streams[i], 8, shared, key, errors))
+               for i, key in enumerate(('shared-a', 'shared-b'))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert np.array_equal(shared['shared-a'], truth[1]) and np.array_equal(shared['shared-b'], truth[1])
+    lib.bbt_osm_plan_destroy(plan)
+    for st in streams:
+        lib.bbt_stream_destroy(st)
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
