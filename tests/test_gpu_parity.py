@@ -1756,6 +1756,97 @@ def test_host_threads_with_their_own_streams_and_plans():
         lib.bbt_stream_destroy(st)
 
 
+def test_random_sizes_of_the_row_kernels_through_the_c_abi():
+    """bbt_chan_execute, bbt_pfb_execute, bbt_fir_execute and bbt_detect_integrate
+    with ragged counts (0, 1, one more or fewer than a tile) and stream counts
+    the pipelines above do not reach, against float64 numpy; guard cells behind
+    every output must stay untouched."""
+    from baseband_tasks_amd import hip
+    rng = np.random.default_rng(1234 + int(os.environ.get('BBT_TEST_SEED', '0')))
+    counts = [0, 1, 2, 3, 5, 15, 16, 17, 63, 64, 65, 127, 255, 257, 1000]
+    GUARD = 64
+
+    def cplx(*shape):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+
+    def guarded(shape, dtype):
+        n = int(np.prod(shape))
+        buf = hip.DeviceArray((n + GUARD,), dtype)
+        buf.copy_from_host(np.full(n + GUARD, 7.5, dtype))
+        return buf, n
+
+    def check_guarded(buf, n, shape, want, what, tol=1.):
+        host = buf.to_host()
+        assert np.all(host[n:] == 7.5), 'wrote past the end: ' + what
+        if n:
+            got, want = host[:n].reshape(shape), want.astype(host.dtype)
+            if host.dtype.kind == 'c':
+                assert_parity(got, want, what)
+            else:
+                assert np.abs(got - want).max() <= 1e-5 * tol * np.abs(want).max(), what
+
+    for case in range(10):
+        S = int(rng.choice([2, 4, 6, 10, 34]))
+        # channelizer, both directions
+        n_chan = int(rng.choice([2, 4, 8, 16, 64, 256, 1024, 4096, 8192, 6, 100, 1029]))
+        n_spec = int(rng.choice(counts if n_chan * S <= 2**14 else counts[:11]))
+        x = cplx(max(n_spec, 1) * n_chan, S)
+        x_dev = hip.DeviceArray.from_host(x)
+        for direction in (-1, 1):
+            out, n = guarded((n_spec, n_chan, S), np.complex64)
+            hip.ChanPlan(n_chan, S, direction).execute(x_dev, out, n_spec)
+            blocks = x[:n_spec * n_chan].reshape(n_spec, n_chan, S).astype(np.complex128)
+            want = np.fft.fft(blocks, axis=1) if direction < 0 else np.fft.ifft(blocks, axis=1)
+            check_guarded(out, n, (n_spec, n_chan, S), want, f'chan case {case}: n {n_chan} S {S} count {n_spec} dir {direction}')
+        # polyphase filter bank
+        n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        n_tap = int(rng.integers(1, 17))
+        n_spec = int(rng.choice(counts[:12]))
+        taps = rng.standard_normal((n_tap, n_chan)).astype(np.float32)
+        x = cplx((max(n_spec, 1) + n_tap - 1) * n_chan, S)
+        out, n = guarded((n_spec, n_chan, S), np.complex64)
+        hip.PfbPlan(taps, S).execute(hip.DeviceArray.from_host(x), out, n_spec)
+        xr = x.reshape(-1, n_chan, S).astype(np.complex128)
+        acc = sum(xr[t:t + n_spec] * taps[t].astype(np.float64)[:, None] for t in range(n_tap))
+        check_guarded(out, n, (n_spec, n_chan, S), np.fft.fft(acc, axis=1) if n_spec else acc,
+                      f'pfb case {case}: n {n_chan} taps {n_tap} S {S} count {n_spec}')
+        # direct FIR, real and complex responses
+        n_tap = int(rng.choice([1, 2, 3, 17, 64, 129, 200]))
+        n_out = int(rng.choice(counts + [4095, 4097, 20000]))
+        resp = cplx(n_tap, S) if case % 2 else rng.standard_normal((n_tap, S)).astype(np.complex64)
+        x = cplx(max(n_out, 1) + n_tap - 1, S)
+        out, n = guarded((n_out, S), np.complex64)
+        hip.FirPlan(resp).execute(hip.DeviceArray.from_host(x), out, n_out)
+        want = np.stack([np.convolve(x[:, k].astype(np.complex128), resp[:, k].astype(np.complex128), mode='valid')
+                         for k in range(S)], axis=1)[:n_out]
+        check_guarded(out, n, (n_out, S), want, f'fir case {case}: taps {n_tap} S {S} count {n_out}')
+        # detection + integration
+        step = int(rng.choice([1, 2, 3, 7, 16, 100]))
+        n_out = int(rng.choice(counts[:12]))
+        n_elem = int(rng.choice([2, 4, 6, 34, 1024, 2050]))
+        z = cplx(max(n_out, 1) * step, n_elem)
+        z_dev = hip.DeviceArray.from_host(z)
+        zz = z[:n_out * step].reshape(n_out, step, n_elem).astype(np.complex128)
+        for mode, average in ((0, True), (1, False), (2, True)):
+            if mode == 0:
+                want, shape, src = (np.abs(zz) ** 2).sum(axis=1), (n_out, n_elem), z_dev
+            elif mode == 1:
+                xx, yy = zz[..., 0::2], zz[..., 1::2]
+                cross = xx * yy.conj()
+                want = np.stack([np.abs(xx) ** 2, np.abs(yy) ** 2, cross.real, cross.imag], axis=-1).sum(axis=1)
+                shape, src = (n_out, n_elem // 2, 4), z_dev
+            else:
+                f = z.view(np.float32)                                  # (.., 2 n_elem) float32 elements
+                want = f[:n_out * step].reshape(n_out, step, 2 * n_elem).astype(np.float64).sum(axis=1)
+                shape, src = (n_out, 2 * n_elem), z_dev
+            if average:
+                want = want / step
+            out, n = guarded(shape, np.float32)
+            hip.detect_integrate(src, out, n_out, step, 2 * n_elem if mode == 2 else n_elem, mode, average)
+            check_guarded(out, n, shape, want, f'detect case {case}: mode {mode} step {step} elem {n_elem} count {n_out}',
+                          tol=10.)
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
