@@ -356,13 +356,17 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
     c2 v[16];
     if (FIRST) {
-        const float2* src = in + ((blk.in_off + n2) * S + 2 * sp);
+        // blk.shift (fused channelizer): the block is read circularly shifted, element
+        // e from sample (e + shift) mod N -- a circular convolution commutes with it.
+        // shift < n_chan <= N2, so only the last row can wrap.
+        const float2* src = in + ((blk.in_off + n2 + blk.shift) * S + 2 * sp);
+        const long long wrap = (n2 + blk.shift >= N2) ? (long long)16 * N2 * S : 0;
         if (S == 2) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_ext_nt(src + (long long)j * N2 * S);
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext_nt(src + (long long)j * N2 * S - (j == 15 ? wrap : 0));
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)j * N2 * S);
+            for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)j * N2 * S - (j == 15 ? wrap : 0));
         }
         radix16<-1>(v);
 #pragma unroll
@@ -415,13 +419,17 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
     c2 v[16];
     if (FIRST) {
-        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
+        // read circularly shifted by blk.shift (see k_osm_col16): row 255 can wrap
+        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);
+        const long long wrap = (tau == 15 && n2 + blk.shift >= N2) ? (long long)256 * N2 * S : 0;
         if (S == 2) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S);
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)16 * j * N2 * S);
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_ext(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
         }
         wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
@@ -540,9 +548,11 @@ __global__ __launch_bounds__(1024) void k_osm_col4096(const float2* __restrict__
     float2* w = work + (((long long)(b * npair + sp) * 4096 + tau) * N2 + n2) * 2;
     c2 v[16];
     if (FIRST) {
-        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2) * S + 2 * sp);
+        // read circularly shifted by blk.shift (see k_osm_col16): row 4095 can wrap
+        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);
+        const long long wrap = (tau == T - 1 && n2 + blk.shift >= N2) ? (long long)4096 * N2 * S : 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * N2 * S);
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * N2 * S - (j == 15 ? wrap : 0));
         wg_fft<4096, -1, F>(v, col4096_lds, tau, f, tw0, tw1);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(w + (long long)T * j * N2 * 2, v[j]);
@@ -635,9 +645,11 @@ __device__ __forceinline__ void lane_radix2_stage(c2 (&v)[16], int c, const cf* 
 // (column pass) acts along k1: the two commute, so the NCH-point FFT is done
 // here, on registers, and the column pass then emits spectra directly.  To
 // make the groups start at multiples of NCH in n2, the block is circularly
-// shifted by `shift` samples, exactly, by the phase ramp exp(+2 pi i k shift/N)
-// applied with the response.  Spectra that straddle the first / last kept
-// sample of a block are spliced afterwards (k_seam_fix).
+// shifted by `shift` samples: the first column pass reads it that way (a
+// circular convolution commutes with a circular shift), which costs address
+// arithmetic there instead of a phase ramp exp(+2 pi i k shift/N) here.
+// Spectra that straddle the first / last kept sample of a block are spliced
+// afterwards (k_seam_fix).
 #ifndef BBT_ROWPASS_TWO_REGIONS
 #define BBT_ROWPASS_TWO_REGIONS 0
 #endif
@@ -723,26 +735,6 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     __builtin_amdgcn_sched_barrier(0);
     apply_resp<T>(v, h0, h1, c0 == c1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NCH > 0) {
-        const int shift = ch.b[bp / npair].shift;
-        if (shift != 0) {
-            // ramp exp(+2 pi i k shift / N), k = ke + N1e (tau + T j) with
-            // ke = k1o + outer k1, N1e = outer N1, N = N1e N2:
-            //   = exp(2 pi i (shift ke + N1e (shift tau mod N2)) / N) * exp(2 pi i shift j / 16)
-            const unsigned n1e = (unsigned)outer * (unsigned)N1;
-            const unsigned n_fft = n1e * (unsigned)N2;
-            const unsigned a = ((unsigned)shift * (unsigned)tau) & (unsigned)(N2 - 1);
-            const unsigned m = (a * n1e + (unsigned)shift * (unsigned)(k1o + outer * k1)) & (n_fft - 1u);
-            float s, c;
-            sincospif(2.0f * (float)m / (float)n_fft, &s, &c);
-            const cf r0 = make_float2(c, s);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const cf w = wroot[((shift * j) & 15) * 256];          // W_16^{shift j}, forward
-                v[j] = twmul<-1>(v[j], make_float2(r0.x * w.x + r0.y * w.y, r0.y * w.x - r0.x * w.y));
-            }
-        }
-    }
     {
         // The second transform reads the same twiddle tables as the first: passed
         // through an opaque move, or the compiler keeps all 30 table values of the
