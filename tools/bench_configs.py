@@ -10,7 +10,6 @@ import torch
 
 sys.path.insert(0, '.')
 import baseband_tasks_amd as bt
-from baseband_tasks_amd import units as u
 
 dev = torch.device('cuda', 0)
 bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -2,7 +2,6 @@
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, '.')
