@@ -536,7 +536,6 @@ __global__ __launch_bounds__(1024) void k_osm_col4096(const float2* __restrict__
                                                       float2* __restrict__ work, OsmChunk ch, int S,
                                                       int N2, const cf* __restrict__ tw0,
                                                       const cf* __restrict__ tw1, SpecOut so) {
-    typedef FftGeo<4096> G;
     constexpr int F = 4, T = 256, CPT = F / PP;
     extern __shared__ v2 col4096_lds[];                  // G::LDS_ELEMS * F elements
     const int f = threadIdx.x % F, tau = threadIdx.x / F;
