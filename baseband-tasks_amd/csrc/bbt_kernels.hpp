@@ -1158,15 +1158,25 @@ __global__ __launch_bounds__(256) void k_detect_integrate(const void* __restrict
 // Per-stream integer sample shifts (reference sampling.py:380-425,
 // ShiftSamples.task: data[self._indices]): out[i, e] = in[i + offset[e], e]
 // for the E elements of a complete sample, offset[e] = shift.max() - shift[e].
-// Element size 4 or 8 bytes; lanes run along the flattened (i, e) index.
-template <typename T>
+// Element size 4, 8 or 16 bytes (the host merges neighbouring elements with the
+// same offset -- the polarisations of a sub-band -- into one wider element).
+// A workgroup covers 256 / LE rows x LE (a power of two) neighbouring elements
+// per step, ITER steps: no division, 32-bit index arithmetic inside a row.
+template <typename T, int ITER>
 __global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in, T* __restrict__ out,
-                                                       long long n_total, int n_elem,
+                                                       long long n_rows, int n_elem, int lg_le,
                                                        const int* __restrict__ offset) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_total) return;
-    const int e = (int)(t % n_elem);
-    out[t] = in[t + (long long)offset[e] * n_elem];
+    const int le = 1 << lg_le;
+    const int e = blockIdx.y * le + (threadIdx.x & (le - 1));
+    if (e >= n_elem) return;
+    const int rows_per_step = 256 >> lg_le;
+    const long long off = offset[e];
+    // consecutive row chunks on one XCD: a line of the input is wanted by its elements at
+    // different rows (within the span of the offsets), which should find it in that L2
+    long long r = (long long)xcd_remap(blockIdx.x, gridDim.x) * (rows_per_step * ITER) + (threadIdx.x >> lg_le);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it, r += rows_per_step)
+        if (r < n_rows) out[r * n_elem + e] = in[(r + off) * n_elem + e];
 }
 
 // ---------------------------------------------------------------------------
@@ -1382,35 +1392,46 @@ __global__ __launch_bounds__(256) void k_fir_blocks(const float2* __restrict__ i
 //   code 0: VDIF levels -- 1 bit {-1, +1}; 2 bits {-3.3359, -1, +1, +3.3359};
 //           4 bits (v - 8) / 2.95; 8 / 16 bits offset binary v - 2^(bits-1)
 //   code 1: two's complement integers (8 or 16 bits)
+// One frame per blockIdx.x, 256 * G consecutive components of it per
+// blockIdx.y: a thread decodes G (1, 2 or 4, dividing E) components that are
+// adjacent in the payload (G * bits <= 64 of its bits) and in the output, and
+// stores them at once (16 bytes for G == 4).  Index arithmetic is 32-bit
+// inside a frame; no 64-bit division anywhere.
+__device__ __forceinline__ float unpack_level(unsigned v, int bits, int code) {
+    if (code == 1) return bits == 8 ? (float)(signed char)v : (float)(short)v;
+    if (bits == 1) return v ? 1.f : -1.f;
+    if (bits == 2) return v == 0 ? -3.3359f : (v == 1 ? -1.f : (v == 2 ? 1.f : 3.3359f));
+    if (bits == 4) return ((float)v - 8.f) / 2.95f;
+    return (float)v - (float)(1u << (bits - 1));
+}
+template <int G>
 __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict__ raw,
-                                                float* __restrict__ out, long long n_total,
-                                                int frame_bytes, int header_bytes, int bits, int spf,
-                                                int n_thread, int E, int code) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_total) return;
-    const int e = (int)(idx % E);
-    const long long r = idx / E;
-    const int thr = (int)(r % n_thread);
-    const long long s = r / n_thread;
-    const long long set = s / spf;
-    const int t = (int)(s - set * spf);
-    const unsigned char* payload = raw + (set * n_thread + thr) * (long long)frame_bytes + header_bytes;
-    const long long bit = ((long long)t * E + e) * bits;
-    const unsigned word = reinterpret_cast<const unsigned*>(payload)[bit >> 5];
-    const unsigned v = (word >> (bit & 31)) & (bits == 32 ? 0xffffffffu : ((1u << bits) - 1u));
-    float x;
-    if (code == 1) {
-        x = bits == 8 ? (float)(signed char)v : (float)(short)v;
-    } else if (bits == 1) {
-        x = v ? 1.f : -1.f;
-    } else if (bits == 2) {
-        x = v == 0 ? -3.3359f : (v == 1 ? -1.f : (v == 2 ? 1.f : 3.3359f));
-    } else if (bits == 4) {
-        x = ((float)v - 8.f) / 2.95f;
+                                                float* __restrict__ out, int frame_bytes,
+                                                int header_bytes, int bits, int spf, int n_thread,
+                                                int E, int code) {
+    const unsigned frame = blockIdx.x;
+    const unsigned set = frame / (unsigned)n_thread, thr = frame - set * (unsigned)n_thread;
+    const unsigned q = (blockIdx.y * 256u + threadIdx.x) * G;      // component index within the frame
+    if (q >= (unsigned)spf * (unsigned)E) return;
+    const unsigned t = q / (unsigned)E, e = q - t * (unsigned)E;
+    const unsigned* payload =
+        reinterpret_cast<const unsigned*>(raw + (long long)frame * frame_bytes + header_bytes);
+    const unsigned bit = q * (unsigned)bits;                        // G * bits divides 32, or is 64
+    unsigned long long w = payload[bit >> 5];
+    if (G * bits > 32) w |= (unsigned long long)payload[(bit >> 5) + 1] << 32;
+    w >>= (bit & 31);
+    const unsigned mask = (1u << bits) - 1u;                        // bits <= 16
+    float x[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) x[g] = unpack_level((unsigned)(w >> (g * bits)) & mask, bits, code);
+    float* dst = out + (((long long)set * spf + t) * n_thread + thr) * E + e;
+    if (G == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[G > 1 ? 1 : 0], x[G > 2 ? 2 : 0], x[G - 1]);
+    } else if (G == 2) {
+        *reinterpret_cast<float2*>(dst) = make_float2(x[0], x[G - 1]);
     } else {
-        x = (float)v - (float)(1u << (bits - 1));
+        dst[0] = x[0];
     }
-    out[idx] = x;
 }
 
 }  // namespace bbt

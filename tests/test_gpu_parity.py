@@ -1757,8 +1757,8 @@ def test_host_threads_with_their_own_streams_and_plans():
 
 
 def test_random_sizes_of_the_row_kernels_through_the_c_abi():
-    """bbt_chan_execute, bbt_pfb_execute, bbt_fir_execute and bbt_detect_integrate
-    with ragged counts (0, 1, one more or fewer than a tile) and stream counts
+    """bbt_chan_execute, bbt_pfb_execute, bbt_fir_execute, bbt_shift_execute,
+    bbt_unpack and bbt_detect_integrate with ragged counts (0, 1, one more or fewer than a tile) and stream counts
     the pipelines above do not reach, against float64 numpy; guard cells behind
     every output must stay untouched."""
     from baseband_tasks_amd import hip
@@ -1820,6 +1820,59 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         want = np.stack([np.convolve(x[:, k].astype(np.complex128), resp[:, k].astype(np.complex128), mode='valid')
                          for k in range(S)], axis=1)[:n_out]
         check_guarded(out, n, (n_out, S), want, f'fir case {case}: taps {n_tap} S {S} count {n_out}')
+        # per-element sample shifts: 4- and 8-byte elements, neighbours moving together or not
+        n_elem = int(rng.choice([1, 2, 3, 4, 6, 16, 128, 130, 600]))
+        n_out = int(rng.choice(counts + [5000]))
+        group = int(rng.choice([1, 2, 4]))
+        offsets = np.repeat(rng.integers(0, 50, size=-(-n_elem // group)), group)[:n_elem].astype(np.int32)
+        for dtype in (np.float32, np.complex64):
+            src = rng.standard_normal((max(n_out, 1) + 50, n_elem)).astype(dtype)
+            if dtype is np.complex64:
+                src = src + 1j * rng.standard_normal(src.shape).astype(np.float32)
+            out, n = guarded((n_out, n_elem), dtype)
+            hip.ShiftPlan(offsets, np.dtype(dtype).itemsize).execute(hip.DeviceArray.from_host(src), out, n_out)
+            want = np.stack([src[offsets[e]:offsets[e] + n_out, e] for e in range(n_elem)], axis=1)
+            host = out.to_host()
+            assert np.all(host[n:] == 7.5), f'shift case {case} wrote past the end'
+            assert np.array_equal(host[:n].reshape(n_out, n_elem), want), \
+                f'shift case {case}: elem {n_elem} group {group} count {n_out} {dtype}'
+        # sampler frames: bits x components x threads, against a bit-level numpy decoder
+        bits = int(rng.choice([1, 2, 4, 8, 16]))
+        code = int(rng.choice([0, 1])) if bits in (8, 16) else 0
+        E = int(rng.choice([1, 2, 3, 4, 8, 12, 16]))
+        n_thread = int(rng.choice([1, 2, 3]))
+        spf = int(rng.choice([1, 7, 32, 100, 640])) * (32 // np.gcd(32, E * bits))      # whole 32-bit words per frame
+        header = int(rng.choice([0, 16, 32]))
+        n_sets = int(rng.choice([0, 1, 2, 5, 33]))
+        payload_words = spf * E * bits // 32
+        frames = rng.integers(0, 2**32, size=(n_sets * n_thread, header // 4 + payload_words + int(rng.integers(0, 3))),
+                              dtype=np.uint64).astype(np.uint32)
+        frame_bytes = frames.shape[1] * 4
+        raw_dev = hip.DeviceArray.from_host(frames.reshape(-1) if frames.size else np.zeros(1, np.uint32))
+        out, n = guarded((n_sets * spf, n_thread, E), np.float32)
+        hip.check(hip.lib().bbt_unpack(raw_dev.ptr, out.ptr, n_sets * n_thread, frame_bytes, header, bits, spf,
+                                       n_thread, E, code, hip.get_stream()))
+        host = out.to_host()
+        assert np.all(host[n:] == 7.5), f'unpack case {case} wrote past the end'
+        if n:
+            words = frames[:, header // 4:header // 4 + payload_words].astype(np.uint64)
+            shifts = np.arange(0, 32, bits, dtype=np.uint64)
+            v = ((words[:, :, None] >> shifts) & np.uint64((1 << bits) - 1)).reshape(n_sets, n_thread, spf, E)
+            v = v.astype(np.int64)
+            if code == 1:
+                lv = np.where(v >= (1 << (bits - 1)), v - (1 << bits), v).astype(np.float32)
+            elif bits == 1:
+                lv = np.where(v > 0, 1., -1.).astype(np.float32)
+            elif bits == 2:
+                lv = np.array([-3.3359, -1., 1., 3.3359], np.float32)[v]
+            elif bits == 4:
+                lv = ((v.astype(np.float32) - np.float32(8.)) / np.float32(2.95)).astype(np.float32)
+            else:
+                lv = (v - (1 << (bits - 1))).astype(np.float32)
+            want = lv.transpose(0, 2, 1, 3).reshape(n_sets * spf, n_thread, E)
+            got = host[:n].reshape(want.shape)
+            assert np.allclose(got, want, rtol=3e-7, atol=0), \
+                f'unpack case {case}: bits {bits} code {code} E {E} threads {n_thread} spf {spf} sets {n_sets}'
         # detection + integration
         step = int(rng.choice([1, 2, 3, 7, 16, 100]))
         n_out = int(rng.choice(counts[:12]))

@@ -1,0 +1,192 @@
+"""The SURVEY 8(f) "next" rows, HBM-resident, one JSON line each (dev tool).
+
+    python tools/bench_next.py [--reps N] [row ...]
+
+f1_detect   Integrate(Power(stream), 16) on a channelized 2-pol stream  (read 16 B, write 16/16 B per complete sample)
+f1_fused    Integrate(Power(Channelize(Dedisperse, 1024)), 64): the metric pipeline with the powers summed in the
+            last pass (algorithmic: 16 B in per input sample, output negligible)
+f2_shift    ShiftSamples, 64 sub-bands x 2 pol, integer shifts          (read 8 B + write 8 B per element)
+f3_vdif     k_unpack on resident frames, 2-bit complex, 8 channels     (read 0.5 B + write 8 B per complex sample)
+f3_vdif_read  the same through open_vdif(...).read_device, upload of the raw frames included (PCIe-inclusive)
+f3_dada     k_unpack on resident samples, 8-bit complex, 2 pol          (read 2 B + write 8 B per complex sample)
+f4_dechan   Dechannelize(1024), 2 pol                                   (read 16 B + write 16 B per complete sample)
+f4_ipfb     InversePolyphaseFilterBank 4 x 1024, 2 pol                  (Dechannelize + overlap-save along the block axis)
+
+`frac` prices the algorithmic bytes against 8 TB/s.
+"""
+import argparse
+import gc
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import baseband_tasks_amd as bt
+from baseband_tasks_amd import ingest
+from baseband_tasks_amd import units as u
+
+T0 = '2020-01-01T00:00:00'
+DEV = torch.device('cuda', 0)
+
+
+def randn_c64(n, shape, seed=1):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    return torch.view_as_complex(torch.randn((n,) + tuple(shape) + (2,), generator=g, device=DEV, dtype=torch.float32))
+
+
+def timed(step, reps):
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    gc.collect()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def restart(tasks, last, count):
+    for t in tasks:
+        t.max_frames_per_call = 10**6
+        t.invalidate_cache()
+    last.seek(0)
+    return last.read_device(count)
+
+
+def f1_detect(reps):
+    n_spec, n_chan = 2**18, 1024
+    x = randn_c64(n_spec, (n_chan, 2))
+    ds = bt.DeviceStream(x, T0, 16e6 / n_chan, samples_per_frame=2**12, polarization=['X', 'Y'])
+    it = bt.Integrate(bt.Power(ds), 16, samples_per_frame=2**8)
+    dt = timed(lambda: restart([it.ih, it], it, it.shape[0]), reps)
+    units = n_spec * n_chan
+    return dict(units=units, unit='complete samples', bytes_per_unit=16 + 16 / 16, seconds=dt)
+
+
+def f1_fused(reps):
+    nblk = 384
+    x = randn_c64(nblk * 2**20, (2,))
+    ds = bt.DeviceStream(x, T0, 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1, polarization=['X', 'Y'])
+    dd = bt.Dedisperse(ds, 100.)
+    ch = bt.Channelize(dd, 1024, 64)
+    it = bt.Integrate(bt.Power(ch), 64, samples_per_frame=8)
+    dt = timed(lambda: restart([dd, ch, it.ih, it], it, it.shape[0]), reps)
+    units = it.shape[0] * 64 * 1024
+    return dict(units=units, unit='complete samples (of the dedispersed stream)',
+                bytes_per_unit=16 * 2**20 / 836100, seconds=dt)
+
+
+def f2_shift(reps):
+    n = 2**21
+    x = randn_c64(n, (64, 2))
+    ds = bt.DeviceStream(x, T0, 6.25e6, samples_per_frame=2**16)
+    shift = (np.arange(64).reshape(64, 1) * 37) % 1000
+    sh = bt.ShiftSamples(ds, shift, samples_per_frame=2**16)
+    dt = timed(lambda: restart([sh], sh, sh.shape[0]), reps)
+    return dict(units=sh.shape[0] * 128, unit='elements', bytes_per_unit=16, seconds=dt)
+
+
+def _unpack_resident(raw, n_frames, frame_nbytes, header_nbytes, bits, spf, n_thread, n_elem, code, reps):
+    """bbt_unpack on frames already in HBM (the kernel alone)."""
+    hip = bt.hip
+    raw_dev = hip.DeviceArray.from_host(np.frombuffer(raw, np.uint8))
+    out = hip.DeviceArray((n_frames // n_thread * spf, n_thread, n_elem), np.float32)
+
+    def step():
+        hip.check(hip.lib().bbt_unpack(raw_dev.ptr, out.ptr, n_frames, frame_nbytes, header_nbytes, bits, spf,
+                                       n_thread, n_elem, code, hip.get_stream()))
+    return timed(step, reps)
+
+
+def _vdif_frames():
+    spf, n_chan, n_frames = 4000, 8, 4096
+    rng = np.random.default_rng(2)
+    levels = np.array([-3.3359, -1., 1., 3.3359], np.float32)
+    comp = rng.choice(levels, size=(spf * n_frames, 1, n_chan * 2))
+    raw = ingest.encode_vdif_frames(comp.view(np.complex64), 2, seconds=100, ref_epoch=41, frame_nr0=0,
+                                    frames_per_second=8000, samples_per_frame=spf, edv=3, sample_rate=32e6)
+    return raw, spf, n_chan, n_frames
+
+
+def f3_vdif(reps):
+    raw, spf, n_chan, n_frames = _vdif_frames()
+    frame_nbytes = len(raw) // n_frames
+    dt = _unpack_resident(raw, n_frames, frame_nbytes, 32, 2, spf, 1, 2 * n_chan, 0, reps)
+    return dict(units=n_frames * spf * n_chan, unit='complex samples', bytes_per_unit=0.5 + 8 + 32 / (spf * n_chan),
+                seconds=dt, note='k_unpack alone, 2-bit complex x 8 channels, frames resident in HBM')
+
+
+def f3_vdif_read(reps):
+    raw, spf, n_chan, n_frames = _vdif_frames()
+    fh = bt.open_vdif(raw, frequency=300 * u.MHz, sideband=1)
+    n = fh.shape[0]
+    dt = timed(lambda: restart([fh], fh, n), max(reps // 3, 2))
+    return dict(units=n * n_chan, unit='complex samples', bytes_per_unit=0.5 + 8 + 32 / (spf * n_chan), seconds=dt,
+                note='open_vdif(...).read_device: includes the upload of the raw frames from pageable host memory '
+                     'each step (PCIe-inclusive)')
+
+
+def f3_dada(reps):
+    n = 2**26
+    rng = np.random.default_rng(8)
+    samples = rng.integers(-128, 128, size=(n, 2, 2), dtype=np.int8)
+    dt = _unpack_resident(samples.tobytes(), n // 4096, 4096 * 4, 0, 8, 4096, 1, 4, 1, reps)
+    return dict(units=n * 2, unit='complex samples', bytes_per_unit=2 + 8, seconds=dt,
+                note='k_unpack alone, signed 8-bit complex x 2 pol, resident in HBM')
+
+
+def f4_dechan(reps):
+    n_spec, n_chan = 2**18, 1024
+    x = randn_c64(n_spec, (n_chan, 2))
+    ds = bt.DeviceStream(x, T0, 16e6 / n_chan, samples_per_frame=2**12, frequency=1000e6 * np.ones((n_chan, 1)),
+                         sideband=1)
+    dc = bt.Dechannelize(ds, n_chan)
+    dt = timed(lambda: restart([dc], dc, dc.shape[0]), reps)
+    return dict(units=n_spec * n_chan, unit='complete samples', bytes_per_unit=32, seconds=dt)
+
+
+def f4_ipfb(reps):
+    n_spec, n_chan = 2**17, 1024
+    x = randn_c64(n_spec, (n_chan, 2))
+    ds = bt.DeviceStream(x, T0, 16e6 / n_chan, samples_per_frame=2**12, frequency=1000e6 * np.ones((n_chan, 1)),
+                         sideband=1)
+    ipfb = bt.InversePolyphaseFilterBank(ds, bt.sinc_hamming(4, n_chan), sn=10., pad_start=32, pad_end=32,
+                                         samples_per_frame=(4096 - 67) * n_chan)
+    dt = timed(lambda: restart([ipfb.dechannelized, ipfb], ipfb, ipfb.shape[0]), reps)
+    return dict(units=ipfb.shape[0], unit='complete samples', bytes_per_unit=32 * 4096 / (4096 - 67), seconds=dt,
+                note='blocks of 4096 spectra, 64 + 3 padding; algorithmic = channelized stream in + samples out')
+
+
+ROWS = dict(f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
+            f3_dada=f3_dada,
+            f4_dechan=f4_dechan, f4_ipfb=f4_ipfb)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('rows', nargs='*', default=sorted(ROWS))
+    ap.add_argument('--reps', type=int, default=10)
+    args = ap.parse_args()
+    bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    for name in args.rows:
+        try:
+            r = ROWS[name](args.reps)
+        except Exception as exc:                      # one row failing does not hide the others
+            print(json.dumps(dict(row=name, error=repr(exc))), flush=True)
+            continue
+        gbps = r['units'] * r['bytes_per_unit'] / r['seconds'] / 1e9
+        print(json.dumps(dict(row=name, munits_per_s=round(r['units'] / r['seconds'] / 1e6, 1), unit=r['unit'],
+                              ms_per_step=round(r['seconds'] * 1e3, 4), alg_bytes_per_unit=round(r['bytes_per_unit'], 3),
+                              alg_gbps=round(gbps, 1), frac=round(gbps / 8000., 4), note=r.get('note'))), flush=True)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()
