@@ -1815,7 +1815,7 @@ extern "C" int bbt_unpack(const void* raw_dev, void* out_dev, int64_t n_frames, 
             per_frame);
     // components decoded per thread: adjacent in payload and output, 16-byte aligned stores
     const int g = n_elem % 4 == 0 ? 4 : (n_elem % 2 == 0 ? 2 : 1);
-    const long long by = (per_frame / g + 255) / 256;
+    const long long by = (per_frame / g + 256 * BBT_UNPACK_ITER - 1) / (256 * BBT_UNPACK_ITER);
     ARG_TRY(by <= 65535, "bbt_unpack: frames of %lld components are too long", per_frame);
     const dim3 grid((unsigned)n_frames, (unsigned)by);
 #define BBT_UNPACK(G_)                                                                           \

@@ -1404,6 +1404,7 @@ __device__ __forceinline__ float unpack_level(unsigned v, int bits, int code) {
     if (bits == 4) return ((float)v - 8.f) / 2.95f;
     return (float)v - (float)(1u << (bits - 1));
 }
+#define BBT_UNPACK_ITER 4     // groups of G components per thread
 template <int G>
 __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict__ raw,
                                                 float* __restrict__ out, int frame_bytes,
@@ -1411,26 +1412,31 @@ __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict_
                                                 int E, int code) {
     const unsigned frame = blockIdx.x;
     const unsigned set = frame / (unsigned)n_thread, thr = frame - set * (unsigned)n_thread;
-    const unsigned q = (blockIdx.y * 256u + threadIdx.x) * G;      // component index within the frame
-    if (q >= (unsigned)spf * (unsigned)E) return;
-    const unsigned t = q / (unsigned)E, e = q - t * (unsigned)E;
     const unsigned* payload =
         reinterpret_cast<const unsigned*>(raw + (long long)frame * frame_bytes + header_bytes);
-    const unsigned bit = q * (unsigned)bits;                        // G * bits divides 32, or is 64
-    unsigned long long w = payload[bit >> 5];
-    if (G * bits > 32) w |= (unsigned long long)payload[(bit >> 5) + 1] << 32;
-    w >>= (bit & 31);
+    const unsigned n_comp = (unsigned)spf * (unsigned)E;
     const unsigned mask = (1u << bits) - 1u;                        // bits <= 16
-    float x[G];
+    float* frame_out = out + ((long long)set * spf * n_thread + thr) * E;
 #pragma unroll
-    for (int g = 0; g < G; ++g) x[g] = unpack_level((unsigned)(w >> (g * bits)) & mask, bits, code);
-    float* dst = out + (((long long)set * spf + t) * n_thread + thr) * E + e;
-    if (G == 4) {
-        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[G > 1 ? 1 : 0], x[G > 2 ? 2 : 0], x[G - 1]);
-    } else if (G == 2) {
-        *reinterpret_cast<float2*>(dst) = make_float2(x[0], x[G - 1]);
-    } else {
-        dst[0] = x[0];
+    for (int it = 0; it < BBT_UNPACK_ITER; ++it) {
+        const unsigned q = ((blockIdx.y * BBT_UNPACK_ITER + it) * 256u + threadIdx.x) * G;   // component in the frame
+        if (q >= n_comp) return;
+        const unsigned t = q / (unsigned)E, e = q - t * (unsigned)E;
+        const unsigned bit = q * (unsigned)bits;                    // G * bits divides 32, or is 64
+        unsigned long long w = payload[bit >> 5];
+        if (G * bits > 32) w |= (unsigned long long)payload[(bit >> 5) + 1] << 32;
+        w >>= (bit & 31);
+        float x[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) x[g] = unpack_level((unsigned)(w >> (g * bits)) & mask, bits, code);
+        float* dst = frame_out + (long long)t * n_thread * E + e;
+        if (G == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[G > 1 ? 1 : 0], x[G > 2 ? 2 : 0], x[G - 1]);
+        } else if (G == 2) {
+            *reinterpret_cast<float2*>(dst) = make_float2(x[0], x[G - 1]);
+        } else {
+            dst[0] = x[0];
+        }
     }
 }
 
