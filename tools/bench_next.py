@@ -153,14 +153,15 @@ def f4_dechan(reps):
 
 def f4_ipfb(reps):
     n_spec, n_chan = 2**17, 1024
+    rows = int(os.environ.get('IPFB_ROWS', '4096'))                 # block length along the block axis
     x = randn_c64(n_spec, (n_chan, 2))
     ds = bt.DeviceStream(x, T0, 16e6 / n_chan, samples_per_frame=2**12, frequency=1000e6 * np.ones((n_chan, 1)),
                          sideband=1)
     ipfb = bt.InversePolyphaseFilterBank(ds, bt.sinc_hamming(4, n_chan), sn=10., pad_start=32, pad_end=32,
-                                         samples_per_frame=(4096 - 67) * n_chan)
+                                         samples_per_frame=(rows - 67) * n_chan)
     dt = timed(lambda: restart([ipfb.dechannelized, ipfb], ipfb, ipfb.shape[0]), reps)
-    return dict(units=ipfb.shape[0], unit='complete samples', bytes_per_unit=32 * 4096 / (4096 - 67), seconds=dt,
-                note='blocks of 4096 spectra, 64 + 3 padding; algorithmic = channelized stream in + samples out')
+    return dict(units=ipfb.shape[0], unit='complete samples', bytes_per_unit=32 * rows / (rows - 67), seconds=dt,
+                note=f'blocks of {rows} spectra, 64 + 3 padding; algorithmic = channelized stream in + samples out')
 
 
 ROWS = dict(f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
