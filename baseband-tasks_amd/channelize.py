@@ -80,6 +80,21 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
         else:
             self._pair_plan.execute(x, out_flat, n_spectra)
 
+    def _pair_spectra_to_half(self, x, n_spectra, out):
+        """Real streams in pairs: transform (n_rows, S/2) complex ``x`` and write
+        the half spectra (n_spectra, n/2+1, S) of the S real streams to ``out``.
+        An odd number of pairs goes through padded; the split reads the padded
+        spectra directly."""
+        p = self._pairs()
+        pe = p + p % 2
+        if self._pair_plan is None:
+            self._pair_plan = self._make_plan(pe)
+        if pe != p:
+            x = hip.pad_streams_to_even(x, p)
+        z = hip.DeviceArray((n_spectra * self._n, pe), np.complex64)
+        self._pair_plan.execute(x, z, n_spectra)
+        hip.split_real_pair_spectra(z, self._n, self._n_stream, out, padded=pe != p)
+
     def _make_plan(self, n_stream_even):
         return hip.ChanPlan(self._n, n_stream_even, self._direction)
 
@@ -178,10 +193,8 @@ class Channelize(_RowFFTTask):
         x = fetch_device(self.ih, start * n, n_spectra * n).reshape(n_spectra * n, self._n_stream)
         if self._real and self._pairs():
             p = self._pairs()            # (n, S) float32 == (n, S/2) complex64, byte for byte
-            z = hip.DeviceArray((n_spectra * n, p), np.complex64)
-            self._run_pairs(hip.DeviceArray((n_spectra * n, p), np.complex64, ptr=x.ptr, owner=x),
-                            n_spectra, z)
-            hip.split_real_pair_spectra(z, n, self._n_stream, out)
+            self._pair_spectra_to_half(hip.DeviceArray((n_spectra * n, p), np.complex64, ptr=x.ptr, owner=x),
+                                       n_spectra, out)
             return
         if self._real:
             full = hip.DeviceArray((n_spectra * n, self._n_stream), np.complex64)

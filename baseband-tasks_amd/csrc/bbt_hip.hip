@@ -380,7 +380,61 @@ int bbt_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_
     const hipMemcpyKind k = kind == 0   ? hipMemcpyHostToDevice
                             : kind == 1 ? hipMemcpyDeviceToHost
                                         : hipMemcpyDeviceToDevice;
+    if (width == 0 || height == 0) return 0;
+    if (kind == 2) {
+        // on the device: our own copy kernel when everything is a multiple of 4 bytes
+        const uintptr_t all = (uintptr_t)dst | (uintptr_t)src | dpitch | spitch | width;
+        const int eb = all % 16 == 0 ? 16 : (all % 8 == 0 ? 8 : (all % 4 == 0 ? 4 : 0));
+        const long long wpr = eb ? (long long)(width / eb) : 0;
+        int lg_le = 0;
+        while ((1ll << lg_le) < wpr && lg_le < 8) ++lg_le;
+        const long long rows_per_block = (256 >> lg_le) * 4;
+        const long long gx = ((long long)height + rows_per_block - 1) / rows_per_block;
+        const long long gy = (wpr + (1 << lg_le) - 1) >> lg_le;
+        if (eb && wpr < (1ll << 31) && gx < (1ll << 31) && gy <= 65535) {
+            const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+            hipStream_t st = (hipStream_t)s;
+            if (eb == 16)
+                hipLaunchKernelGGL((k_copy2d<float4>), grid, block, 0, st, (const float4*)src, (float4*)dst,
+                                   (long long)height, (int)wpr, (int)wpr, (long long)(spitch / 16),
+                                   (long long)(dpitch / 16), lg_le);
+            else if (eb == 8)
+                hipLaunchKernelGGL((k_copy2d<float2>), grid, block, 0, st, (const float2*)src, (float2*)dst,
+                                   (long long)height, (int)wpr, (int)wpr, (long long)(spitch / 8),
+                                   (long long)(dpitch / 8), lg_le);
+            else
+                hipLaunchKernelGGL((k_copy2d<float>), grid, block, 0, st, (const float*)src, (float*)dst,
+                                   (long long)height, (int)wpr, (int)wpr, (long long)(spitch / 4),
+                                   (long long)(dpitch / 4), lg_le);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, (hipStream_t)s));
+    return 0;
+}
+int bbt_pad_streams(const void* in_dev, void* out_dev, int64_t n_rows, int n_in, int n_out,
+                    int elem_bytes, bbt_stream s) {
+    ARG_TRY(in_dev && out_dev, "bbt_pad_streams: null argument");
+    ARG_TRY(n_rows >= 0 && n_in >= 1 && n_out >= n_in, "bbt_pad_streams: bad sizes");
+    ARG_TRY(elem_bytes == 4 || elem_bytes == 8, "bbt_pad_streams: elem_bytes must be 4 or 8");
+    if (n_rows == 0) return 0;
+    int lg_le = 0;
+    while ((1 << lg_le) < n_out && lg_le < 8) ++lg_le;
+    const long long rows_per_block = (256 >> lg_le) * 4;
+    const long long gx = (n_rows + rows_per_block - 1) / rows_per_block;
+    const long long gy = ((long long)n_out + (1 << lg_le) - 1) >> lg_le;
+    ARG_TRY(gx < (1ll << 31) && gy <= 65535, "bbt_pad_streams: too many elements for one call");
+    const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+    if (elem_bytes == 8)
+        hipLaunchKernelGGL((k_copy2d<float2>), grid, block, 0, (hipStream_t)s, (const float2*)in_dev,
+                           (float2*)out_dev, (long long)n_rows, n_out, n_in, (long long)n_in,
+                           (long long)n_out, lg_le);
+    else
+        hipLaunchKernelGGL((k_copy2d<float>), grid, block, 0, (hipStream_t)s, (const float*)in_dev,
+                           (float*)out_dev, (long long)n_rows, n_out, n_in, (long long)n_in,
+                           (long long)n_out, lg_le);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 int bbt_stream_create(bbt_stream* stream) {
@@ -1682,7 +1736,7 @@ extern "C" int bbt_shift_execute(bbt_shift_plan* p, const void* in_dev, void* ou
 extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
                            int n_stream, bbt_stream stream) {
     ARG_TRY(in_dev && out_dev, "bbt_real_op: null argument");
-    ARG_TRY(op >= 0 && op <= 5, "bbt_real_op: op must be 0..5");
+    ARG_TRY(op >= 0 && op <= 6, "bbt_real_op: op must be 0..6");
     ARG_TRY(n_total >= 0, "bbt_real_op: n_total < 0");
     ARG_TRY(op != 2 || (n_chan >= 2 && n_chan % 2 == 0 && n_stream >= 1),
             "bbt_real_op: half-to-full needs an even n_chan and n_stream >= 1");
@@ -1698,6 +1752,7 @@ extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_
         case 2: hipLaunchKernelGGL((k_real_ops<2>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
         case 3: hipLaunchKernelGGL((k_real_ops<3>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
         case 4: hipLaunchKernelGGL((k_real_ops<4>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
+        case 6: hipLaunchKernelGGL((k_real_ops<4, true>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
         default: hipLaunchKernelGGL((k_real_ops<5>), grid, block, 0, st, in_dev, out_dev, (long long)n_total, n_chan, n_stream); break;
     }
     HIP_TRY(hipGetLastError());

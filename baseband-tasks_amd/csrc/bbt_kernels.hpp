@@ -1179,6 +1179,29 @@ __global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in,
         if (r < n_rows) out[r * n_elem + e] = in[(r + off) * n_elem + e];
 }
 
+// Pitched device-to-device copy: `rows` runs of `wpr` elements of type T (4, 8
+// or 16 bytes), run r from src + r * spitch to dst + r * dpitch (pitches in
+// elements).  hipMemcpy2DAsync moves 8-byte-wide rows -- padding an odd stream
+// count to even -- at 0.16 TB/s; this is a plain coalesced copy.  Lanes run along
+// the flattened (row, element) index; a workgroup covers 256 / LE rows x LE
+// elements (LE a power of two >= wpr, or 256 with the row tiled in blockIdx.y).
+// Columns from `src_wpr` on (bbt_pad_streams) are written as zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy2d(const T* __restrict__ src, T* __restrict__ dst,
+                                                long long rows, int wpr, int src_wpr,
+                                                long long spitch, long long dpitch, int lg_le) {
+    const int le = 1 << lg_le;
+    const int c = blockIdx.y * le + (threadIdx.x & (le - 1));
+    if (c >= wpr) return;
+    const int rows_per_step = 256 >> lg_le;
+    long long r = (long long)blockIdx.x * (rows_per_step * 4) + (threadIdx.x >> lg_le);
+    T zero;
+    __builtin_memset(&zero, 0, sizeof(T));
+#pragma unroll
+    for (int it = 0; it < 4; ++it, r += rows_per_step)
+        if (r < rows) dst[r * dpitch + c] = c < src_wpr ? src[r * spitch + c] : zero;
+}
+
 // ---------------------------------------------------------------------------
 // Glue for real-valued (float32) streams, which run through the complex
 // kernels (reference: the rfft/irfft engine paths, fourier/numpy.py:41-49).
@@ -1188,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in,
 //           channels, as irfft interprets it (imaginary parts of the DC and
 //           Nyquist channels ignored); rows = spectra, `s` streams innermost
 //   MODE 3  x -> x^2 (Square of a real stream)
-template <int MODE>
+template <int MODE, bool PADDED = false>
 __global__ __launch_bounds__(256) void k_real_ops(const void* __restrict__ in_,
                                                   void* __restrict__ out_, long long n_total, int n,
                                                   int s) {
@@ -1205,7 +1228,9 @@ __global__ __launch_bounds__(256) void k_real_ops(const void* __restrict__ in_,
         // spectra of two real streams from the transform of z = a + i b:
         // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2i.
         // in (spectrum, n, s/2) complex, out (spectrum, n/2+1, s); t indexes out
-        const int half = n / 2 + 1, np2 = s >> 1;
+        // (PADDED: the input carries one more, unused, pair stream -- an odd number
+        // of pairs went through the transform padded to even)
+        const int half = n / 2 + 1, np2 = (s >> 1) + (PADDED ? 1 : 0);
         const int st = (int)(t % s);
         const long long r = t / s;
         const int k = (int)(r % half);

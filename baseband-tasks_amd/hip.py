@@ -49,6 +49,7 @@ SIGNATURES = {
     'bbt_memcpy_d2h': [_vp, _vp, _sz, _vp],
     'bbt_memcpy_d2d': [_vp, _vp, _sz, _vp],
     'bbt_memcpy2d': [_vp, _sz, _vp, _sz, _sz, _sz, _int, _vp],
+    'bbt_pad_streams': [_vp, _vp, _i64, _int, _int, _int, _vp],
     'bbt_stream_create': [_pvp],
     'bbt_stream_destroy': [_vp],
     'bbt_stream_sync': [_vp],
@@ -364,11 +365,7 @@ def pad_streams_to_even(dev, n_stream):
     """(n, S) complex64 with odd S -> (n, S+1) with a zero stream appended."""
     n = dev.size // n_stream
     out = DeviceArray((n, n_stream + 1), dev.dtype)
-    out.fill_bytes(0)
-    isz = dev.dtype.itemsize
-    if n:
-        check(lib().bbt_memcpy2d(out.ptr, (n_stream + 1) * isz, dev.ptr, n_stream * isz,
-                                 n_stream * isz, n, 2, _stream))
+    check(lib().bbt_pad_streams(dev.ptr, out.ptr, n, n_stream, n_stream + 1, dev.dtype.itemsize, _stream))
     return out
 
 
@@ -420,10 +417,12 @@ def keep_half_spectrum(z, n_chan, n_stream, out):
     return out
 
 
-def split_real_pair_spectra(z, n_chan, n_stream, out):
+def split_real_pair_spectra(z, n_chan, n_stream, out, padded=False):
     """Spectra ``(n_spec, n_chan, n_stream/2)`` of complex streams z = a + i b
-    -> half spectra ``(n_spec, n_chan/2+1, n_stream)`` of the real streams."""
-    check(lib().bbt_real_op(z.ptr, out.ptr, 4, out.size, int(n_chan), int(n_stream), _stream))
+    -> half spectra ``(n_spec, n_chan/2+1, n_stream)`` of the real streams.
+    ``padded``: z carries one more, unused, complex stream."""
+    check(lib().bbt_real_op(z.ptr, out.ptr, 6 if padded else 4, out.size, int(n_chan), int(n_stream),
+                            _stream))
     return out
 
 

@@ -103,9 +103,8 @@ class PolyphaseFilterBank(_RowFFTTask):
             # the taps are real, so the filter bank too takes two real streams as one complex one
             p = self._pairs()
             rows = (n_spectra + n_tap - 1) * n
-            z = hip.DeviceArray((n_spectra * n, p), np.complex64)
-            self._run_pairs(hip.DeviceArray((rows, p), np.complex64, ptr=x.ptr, owner=x), n_spectra, z)
-            hip.split_real_pair_spectra(z, n, s, out)
+            self._pair_spectra_to_half(hip.DeviceArray((rows, p), np.complex64, ptr=x.ptr, owner=x),
+                                       n_spectra, out)
             return
         if self._real:
             x = hip.real_to_complex(x)

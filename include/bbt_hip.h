@@ -83,6 +83,11 @@ int bbt_memcpy_d2d(void* dst_dev, const void* src_dev, size_t nbytes, bbt_stream
  * Used to pad an odd stream count to even and to strip the pad again. */
 int bbt_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
                  size_t height, int kind, bbt_stream stream);
+/* out[r, c] = c < n_in ? in[r, c] : 0 for rows of n_in -> n_out elements of 4 or 8
+ * bytes: an odd stream count padded to even in one pass (the kernels take
+ * stream pairs). */
+int bbt_pad_streams(const void* in_dev, void* out_dev, int64_t n_rows, int n_in, int n_out,
+                    int elem_bytes, bbt_stream stream);
 int bbt_stream_create(bbt_stream* stream);
 int bbt_stream_destroy(bbt_stream stream);
 int bbt_stream_sync(bbt_stream stream);
@@ -265,7 +270,9 @@ int bbt_shift_execute(bbt_shift_plan* plan, const void* in_dev, void* out_dev, i
  *         n_stream real streams a, b, ... (n_chan/2+1 channels): two real
  *         transforms for the price of one complex one
  *   op 5  its inverse: half spectra of n_stream real streams -> the n_chan-channel
- *         spectra of n_stream/2 complex streams z = a + i b (n_total counts those) */
+ *         spectra of n_stream/2 complex streams z = a + i b (n_total counts those)
+ *   op 6  as op 4 for an input that carries n_stream/2 + 1 complex streams, the
+ *         last one unused (an odd number of pairs transformed padded to even) */
 int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
                 int n_stream, bbt_stream stream);
 

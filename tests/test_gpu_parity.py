@@ -1873,6 +1873,23 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
             got = host[:n].reshape(want.shape)
             assert np.allclose(got, want, rtol=3e-7, atol=0), \
                 f'unpack case {case}: bits {bits} code {code} E {E} threads {n_thread} spf {spf} sets {n_sets}'
+        # pitched device copies (odd stream counts are padded to even with these)
+        unit = int(rng.choice([1, 4, 8, 16]))
+        width = unit * int(rng.choice([1, 2, 3, 5, 64, 300]))
+        rows = int(rng.choice(counts[1:] + [4099]))
+        spitch = width + unit * int(rng.integers(0, 4))
+        dpitch = width + unit * int(rng.integers(0, 4))
+        src = rng.integers(0, 256, size=rows * spitch + 16, dtype=np.uint8)
+        src_dev = hip.DeviceArray.from_host(src)
+        dst_dev = hip.DeviceArray((rows * dpitch + GUARD,), np.uint8)
+        dst_dev.copy_from_host(np.full(rows * dpitch + GUARD, 99, np.uint8))
+        skew = unit * int(rng.integers(0, 2))                       # a source that starts off the 16-byte grid
+        hip.copy_2d(dst_dev, dpitch, src_dev, spitch, skew, width, rows)
+        got = dst_dev.to_host()
+        want = np.full(rows * dpitch + GUARD, 99, np.uint8)
+        for r in range(rows):
+            want[r * dpitch:r * dpitch + width] = src[skew + r * spitch:skew + r * spitch + width]
+        assert np.array_equal(got, want), f'copy_2d case {case}: unit {unit} width {width} rows {rows} {spitch} {dpitch}'
         # detection + integration
         step = int(rng.choice([1, 2, 3, 7, 16, 100]))
         n_out = int(rng.choice(counts[:12]))

@@ -12,6 +12,9 @@ f3_dada     k_unpack on resident samples, 8-bit complex, 2 pol          (read 2 
 f4_dechan   Dechannelize(1024), 2 pol                                   (read 16 B + write 16 B per complete sample)
 f4_ipfb     InversePolyphaseFilterBank 4 x 1024, 2 pol                  (Dechannelize + overlap-save along the block axis)
 
+chan_* / pfb_* / dedisperse_real   variants of the path's own kernels the BASELINE configs do not reach (few and many
+            channels, channel counts that are not powers of two, other tap counts, float32 streams)
+
 `frac` prices the algorithmic bytes against 8 TB/s.
 """
 import argparse
@@ -164,7 +167,100 @@ def f4_ipfb(reps):
                 note=f'blocks of {rows} spectra, 64 + 3 padding; algorithmic = channelized stream in + samples out')
 
 
-ROWS = dict(f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
+def _channelize_row(n_chan, reps, real=False, n_samples=2**28):
+    n_spec = n_samples // n_chan
+    if real:
+        g = torch.Generator(device=DEV)
+        g.manual_seed(3)
+        x = torch.randn((n_spec * n_chan, 2), generator=g, device=DEV, dtype=torch.float32)
+    else:
+        x = randn_c64(n_spec * n_chan, (2,))
+    ds = bt.DeviceStream(x, T0, 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    ch = bt.Channelize(ds, n_chan, 2**20 // n_chan if 2**20 % n_chan == 0 else 1000)
+    dt = timed(lambda: restart([ch], ch, ch.shape[0]), reps)
+    in_b = 8 if real else 16
+    out_b = 16 * (n_chan // 2 + 1) / n_chan if real else 16
+    return dict(units=ch.shape[0] * n_chan, unit='complete samples', bytes_per_unit=in_b + out_b, seconds=dt,
+                note=f'Channelize({n_chan}) of 2 {"float32" if real else "complex64"} streams')
+
+
+def chan_64(reps):
+    return _channelize_row(64, reps)
+
+
+def chan_8(reps):
+    return _channelize_row(8, reps)
+
+
+def chan_1000(reps):
+    return _channelize_row(1000, reps, n_samples=2**27)
+
+
+def chan_6000(reps):
+    return _channelize_row(6000, reps, n_samples=2**27)
+
+
+def chan_8192(reps):
+    return _channelize_row(8192, reps)
+
+
+def chan_real_1024(reps):
+    return _channelize_row(1024, reps, real=True)
+
+
+def _pfb_row(n_tap, n_chan, reps, real=False):
+    nblk = 192
+    if real:
+        g = torch.Generator(device=DEV)
+        g.manual_seed(3)
+        x = torch.randn((nblk * 2**20, 2), generator=g, device=DEV, dtype=torch.float32)
+    else:
+        x = randn_c64(nblk * 2**20, (2,))
+    ds = bt.DeviceStream(x, T0, 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    pfb = bt.PolyphaseFilterBank(ds, bt.sinc_hamming(n_tap, n_chan))
+    dt = timed(lambda: restart([pfb], pfb, pfb.shape[0]), reps)
+    in_b = 8 if real else 16
+    out_b = 16 * (n_chan // 2 + 1) / n_chan if real else 16
+    return dict(units=pfb.shape[0] * n_chan, unit='complete samples', bytes_per_unit=in_b + out_b, seconds=dt,
+                note=f'PolyphaseFilterBank {n_tap} x {n_chan}, 2 {"float32" if real else "complex64"} streams')
+
+
+def pfb_4x1024(reps):
+    return _pfb_row(4, 1024, reps)
+
+
+def pfb_8x2048(reps):
+    return _pfb_row(8, 2048, reps)
+
+
+def pfb_16x4096(reps):
+    return _pfb_row(16, 4096, reps)
+
+
+def pfb_12x256(reps):
+    return _pfb_row(12, 256, reps)
+
+
+def pfb_real_12x1024(reps):
+    return _pfb_row(12, 1024, reps, real=True)
+
+
+def dedisperse_real(reps):
+    nblk = 192
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    x = torch.randn((nblk * 2**20, 2), generator=g, device=DEV, dtype=torch.float32)
+    ds = bt.DeviceStream(x, T0, 32e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    dd = bt.Dedisperse(ds, 100.)
+    dt = timed(lambda: restart([dd], dd, dd.shape[0]), reps)
+    return dict(units=dd.shape[0], unit='complete samples', bytes_per_unit=16 * dd._ih_samples_per_frame / dd.samples_per_frame,
+                seconds=dt, note=f'Dedisperse of 2 float32 streams, blocks of {dd._ih_samples_per_frame}')
+
+
+ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_6000, chan_8192=chan_8192,
+            chan_real_1024=chan_real_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
+            pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
+            f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
             f3_dada=f3_dada,
             f4_dechan=f4_dechan, f4_ipfb=f4_ipfb)
 
