@@ -245,21 +245,62 @@ def pfb_real_12x1024(reps):
     return _pfb_row(12, 1024, reps, real=True)
 
 
-def dedisperse_real(reps):
+def _dedisperse_row(reps, kind):
+    """2^20-sample blocks as in config 2: 'real' = 2 float32 streams (one complex stream, padded
+    to a pair inside), 'single' = 1 complex64 stream (padded), 'default' = 2 complex64 streams with the
+    reference's default block length (not a power of two: the generic kernels)."""
     nblk = 192
     g = torch.Generator(device=DEV)
     g.manual_seed(3)
-    x = torch.randn((nblk * 2**20, 2), generator=g, device=DEV, dtype=torch.float32)
-    ds = bt.DeviceStream(x, T0, 32e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
-    dd = bt.Dedisperse(ds, 100.)
+    if kind == 'real':
+        x = torch.randn((nblk * 2**20, 2), generator=g, device=DEV, dtype=torch.float32)
+        fs, per = 32e6, 8
+    elif kind == 'single':
+        x = randn_c64(nblk * 2**20, ())
+        fs, per = 16e6, 8
+    else:
+        x = randn_c64(nblk * 2**20, (2,))
+        fs, per = 16e6, 16
+    ds = bt.DeviceStream(x, T0, fs, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    if kind == 'default':
+        dd = bt.Dedisperse(ds, 100.)
+    else:
+        probe = bt.Dedisperse(ds, 100.)
+        pad = probe._ih_samples_per_frame - probe.samples_per_frame
+        dd = bt.Dedisperse(ds, 100., samples_per_frame=2**20 - pad)
+        assert dd._ih_samples_per_frame == 2**20
     dt = timed(lambda: restart([dd], dd, dd.shape[0]), reps)
-    return dict(units=dd.shape[0], unit='complete samples', bytes_per_unit=16 * dd._ih_samples_per_frame / dd.samples_per_frame,
-                seconds=dt, note=f'Dedisperse of 2 float32 streams, blocks of {dd._ih_samples_per_frame}')
+    return dict(units=dd.shape[0], unit='complete samples',
+                bytes_per_unit=per * (1 + dd._ih_samples_per_frame / dd.samples_per_frame), seconds=dt,
+                note=f'Dedisperse DM 100, {kind}: blocks of {dd._ih_samples_per_frame}, {dd.samples_per_frame} kept')
+
+
+def dedisperse_real(reps):
+    return _dedisperse_row(reps, 'real')
+
+
+def dedisperse_single(reps):
+    return _dedisperse_row(reps, 'single')
+
+
+def dedisperse_default(reps):
+    return _dedisperse_row(reps, 'default')
+
+
+def chan_single_1024(reps):
+    n_chan, n_spec = 1024, 2**18
+    x = randn_c64(n_spec * n_chan, ())
+    ds = bt.DeviceStream(x, T0, 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    ch = bt.Channelize(ds, n_chan, 1024)
+    dt = timed(lambda: restart([ch], ch, ch.shape[0]), reps)
+    return dict(units=ch.shape[0] * n_chan, unit='complete samples', bytes_per_unit=16, seconds=dt,
+                note='Channelize(1024) of ONE complex64 stream (padded to a pair inside)')
 
 
 ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_6000, chan_8192=chan_8192,
             chan_real_1024=chan_real_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
             pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
+            dedisperse_single=dedisperse_single, dedisperse_default=dedisperse_default, chan_single_1024=chan_single_1024,
             f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
             f3_dada=f3_dada,
             f4_dechan=f4_dechan, f4_ipfb=f4_ipfb)
