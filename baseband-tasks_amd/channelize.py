@@ -47,10 +47,20 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
     _plan = None
     _direction = -1
 
+    #: the plain transform kernels take ONE complex stream as it is (two consecutive
+    #: transforms side by side instead of a stream pair) for power-of-two n in
+    #: [256, 4096]; other odd stream counts are padded to even
+    _SINGLE_STREAM = True
+
+    def _even(self, count):
+        if count == 1 and self._SINGLE_STREAM and 256 <= self._n <= 4096 and not self._n & (self._n - 1):
+            return 1
+        return count + count % 2
+
     def _setup_streams(self, n, n_stream):
         self._n = n
         self._n_stream = n_stream
-        self._n_stream_even = n_stream + (n_stream % 2)
+        self._n_stream_even = self._even(n_stream)
 
     #: Transform two neighbouring real streams as one complex stream a + i b
     #: (one transform for two: the spectra are separated afterwards).
@@ -69,7 +79,7 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
     def _run_pairs(self, x, n_spectra, out_flat):
         """As `_run` for the S/2 complex streams that pairs of real streams form."""
         p = self._pairs()
-        pe = p + p % 2
+        pe = self._even(p)
         if self._pair_plan is None:
             self._pair_plan = self._make_plan(pe)
         if pe != p:
@@ -86,7 +96,7 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
         An odd number of pairs goes through padded; the split reads the padded
         spectra directly."""
         p = self._pairs()
-        pe = p + p % 2
+        pe = self._even(p)
         if self._pair_plan is None:
             self._pair_plan = self._make_plan(pe)
         if pe != p:

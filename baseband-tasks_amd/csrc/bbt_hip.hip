@@ -1391,6 +1391,12 @@ template <int N, int SIGN>
 static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, int64_t n_fft,
                         float scale, hipStream_t st) {
     constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
+    if (p->S == 1) {            // one stream: two consecutive transforms side by side
+        const unsigned gx = (unsigned)(((n_fft + 1) / 2 + FPW - 1) / FPW);
+        hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, true>), dim3(gx), dim3(FPW * N / 16), 0, st, in, out,
+                           (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
+        return;
+    }
     const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
     hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW>), dim3(gx * p->npair), dim3(FPW * N / 16), 0, st, in,
                        out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
@@ -1426,8 +1432,10 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     ARG_TRY(fast || (n_chan >= 2 && n_chan <= BBT_GEN_MAX_LEN && is_7smooth(n_chan)),
             "bbt_chan_plan_create: n_chan=%d must be a power of two in [2, 4096] or a product of "
             "2, 3, 5, 7 up to 8192", n_chan);
-    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
-            "bbt_chan_plan_create: n_stream=%d must be even and >= 2", n_stream);
+    const bool single = n_stream == 1 && fast && n_chan >= 256;
+    ARG_TRY(single || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
+            "bbt_chan_plan_create: n_stream=%d must be even and >= 2 (or 1 for a power-of-two n_chan "
+            "in [256, 4096])", n_stream);
     ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1 or +1");
     bbt_chan_plan* p = new bbt_chan_plan;
     p->n = n_chan;

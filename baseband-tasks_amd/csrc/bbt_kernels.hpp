@@ -38,7 +38,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
 // ---------------------------------------------------------------------------
 // Batched FFT over contiguous groups of N complete samples.
 //   in/out : (n_fft * N, S) complex64 ; pair index = blockIdx.y
-template <int N, int SIGN, int FPW>
+// SINGLE (S == 1): the two transforms a thread carries side by side are two
+// consecutive groups of the one stream instead of the two streams of a pair
+// (8-byte loads and stores, fully coalesced; nothing is padded or wasted).
+template <int N, int SIGN, int FPW, bool SINGLE = false>
 __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restrict__ in,
                                                            float2* __restrict__ out, long long n_fft,
                                                            int S, float scale,
@@ -50,12 +53,31 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
     const int slot = threadIdx.x / T, tau = threadIdx.x % T;
     // pairs of the same samples share cache lines: keep them adjacent in the
     // XCD-contiguous virtual block order
-    const int npair = S >> 1;
+    const int npair = SINGLE ? 1 : S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
     const long long i = (long long)(vb / npair) * FPW + slot;
     const int sp = vb % npair;
-    const bool active = i < n_fft;
     c2 v[16];
+    if constexpr (SINGLE) {
+        const bool act_a = 2 * i < n_fft, act_b = 2 * i + 1 < n_fft;
+        const float2* src = in + (2 * i * N + tau);
+        const float2 zero = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float2 a = act_a ? src[T * j] : zero;
+            const float2 b = act_b ? src[N + T * j] : zero;
+            v[j] = c2{v2{a.x, b.x}, v2{a.y, b.y}};
+        }
+        wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+        float2* dst = out + (2 * i * N + tau);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (act_a) dst[T * j] = make_float2(v[j].re.x * scale, v[j].im.x * scale);
+            if (act_b) dst[N + T * j] = make_float2(v[j].re.y * scale, v[j].im.y * scale);
+        }
+        return;
+    }
+    const bool active = i < n_fft;
     if (active) {
         const float2* src = in + ((i * N + tau) * S + 2 * sp);
         if (S == 2) {

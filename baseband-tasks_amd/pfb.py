@@ -49,6 +49,8 @@ class PolyphaseFilterBank(_RowFFTTask):
     frequency, sideband : optional overrides of the stream metadata.
     """
 
+    _SINGLE_STREAM = False       # the filter bank kernels take stream pairs only
+
     def __init__(self, ih, response, samples_per_frame=None, frequency=None, sideband=None):
         response = np.asanyarray(response)
         n_tap, n = response.shape

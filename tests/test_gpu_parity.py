@@ -1917,6 +1917,33 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
                           tol=10.)
 
 
+@pytest.mark.parametrize('n_chan', [256, 512, 1024, 2048, 4096])
+def test_one_stream_through_the_channelizer_unpadded(n_chan):
+    """A single complex stream (and two float32 streams, which are one complex
+    stream) is transformed as it is -- two consecutive spectra side by side in
+    the registers -- for odd and even numbers of spectra, both directions."""
+    from baseband_tasks_amd import hip
+    rng = np.random.default_rng(n_chan)
+    for n_spec in (1, 2, 7, 64, 129):
+        x = (rng.standard_normal(n_spec * n_chan) + 1j * rng.standard_normal(n_spec * n_chan)).astype(np.complex64)
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz)
+        ch = bt.Channelize(ds, n_chan, samples_per_frame=n_spec)
+        assert ch._n_stream_even == 1                         # no padding
+        z = ch.read()
+        want = np.fft.fft(x.astype(np.complex128).reshape(n_spec, n_chan), axis=1)
+        assert_parity(z, want.astype(np.complex64), f'one stream, {n_spec} spectra of {n_chan}')
+        back = bt.Dechannelize(ch).read()
+        assert_parity(back, x, f'round trip, {n_spec} spectra of {n_chan}')
+        xr = rng.standard_normal((n_spec * n_chan, 2)).astype(np.float32)
+        zr = bt.Channelize(bt.DeviceStream(xr, T0, 1 * u.MHz), n_chan, samples_per_frame=n_spec).read()
+        want = np.fft.rfft(xr.astype(np.float64).reshape(n_spec, n_chan, 2), axis=1)
+        assert_parity(zr, want.astype(np.complex64), f'two real streams, {n_spec} spectra of {n_chan}')
+    # the C ABI says so too, and refuses one stream where the kernels want pairs
+    assert hip.ChanPlan(n_chan, 1, -1) is not None
+    with pytest.raises(RuntimeError):
+        hip.ChanPlan(128, 1, -1)
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
