@@ -503,6 +503,9 @@ struct bbt_osm_plan {
     int device = 0;
     int64_t n = 0;
     int S = 0, npair = 0, C = 0;
+    // one stream (S == 1): pairs are made of two consecutive blocks (see SinglePair);
+    // npair == 1 and the work buffers hold (chunk + 1) / 2 pairs of blocks
+    bool single = false;
     int n1 = 1, n2 = 0;
     int outer = 1;  // 256 for three-level transforms (N > 2^20): N = outer * n1 * n2
     int chunk = 1;
@@ -594,6 +597,11 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
     // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
     constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
     constexpr size_t lds1 = FftGeo<N>::LDS_ELEMS * sizeof(v2);
+    if (p->single) {
+        hipLaunchKernelGGL((k_osm_small<N, 1, true>), dim3((ch.nblk + 1) / 2), dim3(N / 16), lds1, st, in,
+                           out, ch, 1, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
+        return 0;
+    }
     if (p->npair % PP == 0) {
         if (ensure_dyn_lds((const void*)k_osm_small<N, PP>, lds1 * PP)) return 1;
         hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(ch.nblk * (p->npair / PP)), dim3(PP * N / 16),
@@ -638,6 +646,14 @@ template <bool FIRST, bool SPEC>
 static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                           const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
     constexpr size_t lds1 = FftGeo<256>::LDS_ELEMS * sizeof(v2);     // per column of a tile
+    if constexpr (!SPEC) {
+        if (p->single) {
+            hipLaunchKernelGGL((k_osm_col256<FIRST, false, 16, false, 1, true>),
+                               dim3(row_len / 16, (ch.nblk + 1) / 2), dim3(256), 16 * lds1, st, in, out,
+                               work, ch, 1, row_len, p->tab1.tw0, so);
+            return 0;
+        }
+    }
     if constexpr (SPEC && !FIRST) {
         if (so.det) {
             hipLaunchKernelGGL((k_osm_col256<false, true, 16, true>),
@@ -755,6 +771,13 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         in = stage;
     }
     const OsmChunk& ch = *chp;         // (block i of a prefiltered chunk reads staging[i * N])
+    if (p->single && nch) return fail("osm: one-stream plans have no fused channelizer");
+    OsmChunk pairs_view;               // one stream: the work buffers hold pairs of blocks
+    if (p->single) {
+        pairs_view = ch;
+        pairs_view.nblk = (ch.nblk + 1) / 2;
+    }
+    const OsmChunk& chw = p->single ? pairs_view : ch;       // what the row / middle passes count
     if (p->generic) {
         if (nch) return fail("osm: the fused channelizer needs a power-of-two block length");
         if (p->n1 == 1) {
@@ -811,13 +834,12 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         // three levels: outer 256-point column pass over rows of M = 16 * n2, then
         // the two-level machinery in place on every outer row
         const int m_len = 16 * p->n2;
-        const dim3 gout(m_len / 16 * p->npair, ch.nblk);
-        const dim3 gmid(p->n2 / 256, ch.nblk * p->npair * 256);
+        const dim3 gmid(p->n2 / 256, chw.nblk * p->npair * 256);
         if (launch_col256<true, false>(p, in, out, work, ch, m_len, so, st)) return 1;
         hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                            p->wroot, 0);
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        if (launch_rowpass(p, work, ch, nch, st)) return 1;
+        if (launch_rowpass(p, work, chw, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
         hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                            p->wroot, nch ? 1 : 0);
@@ -825,17 +847,23 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
                 : launch_col256<false, false>(p, in, out, work, ch, m_len, so, st))
             return 1;
     } else {
-        const dim3 g16(p->n2 / 256 * p->npair, ch.nblk), g256(p->n2 / 16 * p->npair, ch.nblk);
-        if (p->n1 == 16)
+        const dim3 g16(p->n2 / 256 * p->npair, chw.nblk);
+        if (p->n1 == 16 && p->single)
+            hipLaunchKernelGGL((k_osm_col16<true, false, true>), g16, dim3(256), 0, st, in, out, work, ch,
+                               1, p->n2, so);
+        else if (p->n1 == 16)
             hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
                                p->S, p->n2, so);
         else if (launch_col256<true, false>(p, in, out, work, ch, p->n2, so, st))
             return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        if (launch_rowpass(p, work, ch, nch, st)) return 1;
+        if (launch_rowpass(p, work, chw, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
         if (p->n1 == 16) {
-            if (nch)
+            if (p->single)
+                hipLaunchKernelGGL((k_osm_col16<false, false, true>), g16, dim3(256), 0, st, in, out,
+                                   work, ch, 1, p->n2, so);
+            else if (nch)
                 hipLaunchKernelGGL((k_osm_col16<false, true>), g16, dim3(256), 0, st, in, out,
                                    work, ch, p->S, p->n2, so);
             else
@@ -943,16 +971,19 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^24] or a product of "
             "2, 3, 5, 7 that is <= 8192 or splits into two such factors",
             (long long)n_fft);
-    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
-            "bbt_osm_plan_create: n_stream=%d must be even and >= 2", n_stream);
+    const bool single = n_stream == 1 && fast && !(getenv("BBT_OSM_TWO_LEVEL") && n_fft > (1 << 20));
+    ARG_TRY(single || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
+            "bbt_osm_plan_create: n_stream=%d must be even and >= 2 (or 1 with a power-of-two block "
+            "length)", n_stream);
     ARG_TRY(n_resp >= 1, "bbt_osm_plan_create: n_resp=%d must be >= 1", n_resp);
-    std::vector<int> idx(n_stream, 0);
+    std::vector<int> idx(single ? 2 : n_stream, 0);
     if (resp_index)
         for (int s = 0; s < n_stream; ++s) {
             ARG_TRY(resp_index[s] >= 0 && resp_index[s] < n_resp,
                     "bbt_osm_plan_create: resp_index[%d]=%d out of range", s, resp_index[s]);
             idx[s] = resp_index[s];
         }
+    if (single) idx[1] = idx[0];            // both halves of a pair of blocks are the one stream
     bbt_osm_plan* p = new bbt_osm_plan;
     auto bail = [&](int) {
         bbt_osm_plan_destroy(p);
@@ -961,7 +992,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (hipGetDevice(&p->device) != hipSuccess) return bail(fail("hipGetDevice failed"));
     p->n = n_fft;
     p->S = n_stream;
-    p->npair = n_stream / 2;
+    p->npair = single ? 1 : n_stream / 2;
+    p->single = single;
     p->C = n_resp;
     if (!fast) {
         p->generic = true;
@@ -1031,8 +1063,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (e != hipSuccess)
         return bail(fail("bbt_osm_plan_create: response permutation failed: %s",
                          hipGetErrorString(e)));
-    if (hipMalloc((void**)&p->resp_index, n_stream * sizeof(int)) != hipSuccess ||
-        hipMemcpy(p->resp_index, idx.data(), n_stream * sizeof(int), hipMemcpyHostToDevice) !=
+    if (hipMalloc((void**)&p->resp_index, idx.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(p->resp_index, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice) !=
             hipSuccess)
         return bail(fail("bbt_osm_plan_create: resp_index upload failed"));
 
@@ -1057,10 +1089,18 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     }
     while (chunk > 1 && (long long)chunk * p->npair > 65535) --chunk;      // grid.y of the row pass
     if ((double)chunk * per_block * lanes > 16.0 * (1u << 30)) lanes = 1;   // (config 4: 2 x 2 GiB)
+    if (single) {
+        // `chunk` pairs of blocks fit the work buffer: a chunk of descriptors holds twice as many blocks
+        const int pairs = chunk > BBT_MAX_CHUNK / 2 ? BBT_MAX_CHUNK / 2 : chunk;
+        p->work_bytes = per_block * pairs;
+        chunk = 2 * pairs;
+    } else {
+        p->work_bytes = per_block * chunk;
+    }
     p->chunk = chunk;
     p->lanes = lanes;
+    if (p->n1 == 1) p->work_bytes = 0;        // one kernel, no work buffer
     if (p->n1 > 1) {
-        p->work_bytes = per_block * chunk;
         for (int l = 0; l < p->lanes; ++l) {
             if (hipMalloc((void**)&p->lane_work[l], p->work_bytes) != hipSuccess)
                 return bail(fail("bbt_osm_plan_create: hipMalloc(workspace %zu bytes) failed",
@@ -1119,7 +1159,7 @@ int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chun
 
 int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     // can bbt_osm_execute_channelized take Channelize(n_chan) into the row pass?
-    if (!p || p->generic || (p->n1 == 1 && p->outer == 1)) return 0;
+    if (!p || p->generic || p->single || (p->n1 == 1 && p->outer == 1)) return 0;
     if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
         return p->n1 == 256 || p->n1 == 4096 || p->outer == 256;            // exchange in the row pass
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
@@ -1151,6 +1191,7 @@ int bbt_osm_execute_prefiltered(bbt_osm_plan* p, const bbt_fir_plan* fir, const 
                                 const int32_t* valid_count, bbt_stream stream) {
     const char* who = "bbt_osm_execute_prefiltered";
     ARG_TRY(p && fir && in_dev && out_dev, "%s: null argument", who);
+    ARG_TRY(!p->single, "%s: not for one-stream plans", who);
     ARG_TRY(fir->S == p->S, "%s: the filter has %d streams, the plan %d", who, fir->S, p->S);
     ARG_TRY(p->n >= 256 * BBT_FIR_R, "%s: blocks of %lld samples are too short", who, (long long)p->n);
     if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;

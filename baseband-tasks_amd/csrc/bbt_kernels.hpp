@@ -304,6 +304,34 @@ struct OsmChunk {
     OsmBlock b[BBT_MAX_CHUNK];
 };
 
+// One-stream plans (S == 1, SINGLE kernels): the two transforms a thread carries
+// side by side are two consecutive BLOCKS of the one stream -- blocks 2q and
+// 2q + 1 of the chunk, the second absent when the chunk holds an odd number --
+// instead of the two streams of a pair.  Only the stream side differs (8-byte
+// loads and stores with each block's own offsets); the work buffers, the row
+// pass and the response (the same column for both) are those of a pair.
+struct SinglePair {
+    OsmBlock a, b;
+    bool has_b;
+};
+__device__ __forceinline__ SinglePair single_pair(const OsmChunk& ch, int q) {
+    SinglePair sp;
+    sp.a = ch.b[2 * q];
+    sp.has_b = 2 * q + 1 < ch.nblk;
+    sp.b = ch.b[sp.has_b ? 2 * q + 1 : 2 * q];
+    return sp;
+}
+__device__ __forceinline__ c2 ld_single(const float2* __restrict__ in, const SinglePair& sp, long long e) {
+    const float2 a = in[sp.a.in_off + e];
+    const float2 b = sp.has_b ? in[sp.b.in_off + e] : make_float2(0.f, 0.f);
+    return c2{v2{a.x, b.x}, v2{a.y, b.y}};
+}
+__device__ __forceinline__ void st_single(float2* __restrict__ out, const SinglePair& sp, long long e, c2 v) {
+    const long long ra = e - sp.a.valid_start, rb = e - sp.b.valid_start;
+    if (ra >= 0 && ra < sp.a.valid_count) out[sp.a.out_off + ra] = make_float2(v.re.x, v.im.x);
+    if (sp.has_b && rb >= 0 && rb < sp.b.valid_count) out[sp.b.out_off + rb] = make_float2(v.re.y, v.im.y);
+}
+
 // Multiply by the response (chirp), already scaled by 1/N: element j of this
 // thread is at h[STRIDE * j].  The "same column for both streams" test is
 // hoisted out of the loop (a per-element runtime select makes hipcc branch
@@ -328,7 +356,7 @@ __device__ __forceinline__ void apply_resp(c2 (&v)[16], const cf* __restrict__ h
 // with n_chan * S streams) the lanes run over PP pairs first, so a wave touches
 // PP * 16 contiguous bytes of each complete sample instead of 16; the PP
 // transforms are interleaved in LDS (COLMODE = PP).
-template <int N, int PP>
+template <int N, int PP, bool SINGLE = false>
 __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restrict__ in,
                                                           float2* __restrict__ out, OsmChunk ch, int S,
                                                           const cf* __restrict__ resp,
@@ -341,12 +369,25 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
     extern __shared__ v2 osm_small_lds[];          // G::LDS_ELEMS * PP elements (up to 72 KiB)
     v2* lds = osm_small_lds;
     // the pairs of one block share cache lines: consecutive virtual ids, one XCD
-    const int npg = (S >> 1) / PP;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    c2 v[16];
+    if constexpr (SINGLE) {                       // PP == 1; workgroup vb = pair of blocks
+        const int tau = threadIdx.x;
+        const SinglePair pr = single_pair(ch, vb);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_single(in, pr, tau + T * j);
+        wg_fft<N, -1, CM>(v, lds, tau, 0, tw0, tw1);
+        const cf* h = resp + (long long)resp_index[0] * N + tau;
+        apply_resp<T>(v, h, h, true);
+        wg_fft<N, +1, CM>(v, lds, tau, 0, tw0, tw1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st_single(out, pr, tau + T * j, v[j]);
+        return;
+    }
+    const int npg = (S >> 1) / PP;
     const int pl = threadIdx.x % PP, tau = threadIdx.x / PP;
     const int sp = (vb % npg) * PP + pl;
     const OsmBlock blk = ch.b[vb / npg];
-    c2 v[16];
     const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
@@ -365,18 +406,36 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
 
 // Column pass, N1 == 16: one thread per 2-stream column, radix-16 in registers.
 //   FIRST: stream -> work (forward).  !FIRST: work -> valid output (inverse).
-template <bool FIRST, bool SPEC = false>
+template <bool FIRST, bool SPEC = false, bool SINGLE = false>
 __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in,
                                                    float2* __restrict__ out,
                                                    float2* __restrict__ work, OsmChunk ch, int S,
                                                    int N2, SpecOut so) {
-    const int npair = S >> 1;
+    const int npair = SINGLE ? 1 : S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
     const int n2 = (vb / npair) * 256 + threadIdx.x;
     const int b = blockIdx.y, sp = vb % npair;
-    const OsmBlock blk = ch.b[b];
     float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
     c2 v[16];
+    if constexpr (SINGLE) {                       // b = pair of blocks of the one stream
+        static_assert(!SPEC, "one-stream plans have no fused channelizer");
+        const SinglePair pr = single_pair(ch, b);
+        if (FIRST) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_single(in, pr, (long long)j * N2 + n2);
+            radix16<-1>(v);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) st_int(w + (long long)j * N2 * 2, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)j * N2 * 2);
+            radix16<+1>(v);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)j * N2 + n2, v[j]);
+        }
+        return;
+    }
+    const OsmBlock blk = ch.b[b];
     if (FIRST) {
         // blk.shift (fused channelizer): the block is read circularly shifted, element
         // e from sample (e + shift) mod N -- a circular convolution commutes with it.
@@ -419,7 +478,7 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
 // FCOL / PP columns (PP > 1): the stream side then moves PP * 16 contiguous
 // bytes per complete sample (a whole 128-byte line for 8 pairs) at the price
 // of FCOL / PP * 16-byte runs on the work-buffer side.
-template <bool FIRST, bool SPEC, int FCOL, bool DET = false, int PP = 1>
+template <bool FIRST, bool SPEC, int FCOL, bool DET = false, int PP = 1, bool SINGLE = false>
 __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restrict__ in,
                                                           float2* __restrict__ out,
                                                           float2* __restrict__ work, OsmChunk ch,
@@ -430,16 +489,34 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     v2* lds = col256_lds;
     static_assert(!DET || PP == 1, "fused detection needs the lanes of a row in one stream pair");
     const int f = threadIdx.x % FCOL, tau = threadIdx.x / FCOL;
-    const int npair = S >> 1;
+    const int npair = SINGLE ? 1 : S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
     constexpr int CPT = FCOL / PP;                       // columns per tile
     const int npg = npair / PP;                          // pair groups
     const int n2 = (vb / npg) * CPT + f / PP;
     const int b = blockIdx.y, sp = (vb % npg) * PP + f % PP;
-    const OsmBlock blk = ch.b[b];
     // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*256 + k1)*N2 + n2
     float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
     c2 v[16];
+    if constexpr (SINGLE) {                              // b = pair of blocks of the one stream
+        static_assert(!SPEC && !DET && PP == 1, "one-stream plans: plain output only");
+        const SinglePair pr = single_pair(ch, b);
+        if (FIRST) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_single(in, pr, (long long)(tau + 16 * j) * N2 + n2);
+            wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+            wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)(tau + 16 * j) * N2 + n2, v[j]);
+        }
+        return;
+    }
+    const OsmBlock blk = ch.b[b];
     if (FIRST) {
         // read circularly shifted by blk.shift (see k_osm_col16): row 255 can wrap
         const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);

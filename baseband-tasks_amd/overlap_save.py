@@ -79,6 +79,9 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
     #: Run pairs of real streams as single complex streams when they share a response.
     PAIR_REAL_STREAMS = True
     _paired = None
+    #: Do not pad a lone complex stream to a pair (power-of-two blocks only).
+    SINGLE_STREAM_UNPADDED = True
+    _single = False
 
     def _plan_layout(self):
         """(response columns, column index per stream the plan sees, number of
@@ -92,6 +95,13 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             index = index[0:s:2]
             if index.shape[0] % 2:
                 index = np.concatenate([index, index[-1:]])
+        # ONE complex stream (or two float32 streams) on power-of-two blocks runs as it is:
+        # the library pairs consecutive blocks instead of streams (include/bbt_hip.h)
+        n = self._ih_samples_per_frame
+        self._single = bool(self.SINGLE_STREAM_UNPADDED and (s // 2 if self._paired else s) == 1
+                            and 256 <= n <= (1 << 24) and not n & (n - 1))
+        if self._single:
+            index = index[:1]
         return columns, np.ascontiguousarray(index, dtype=np.int32), index.shape[0]
 
     def _get_plan(self):
@@ -115,7 +125,7 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             final, out = out, hip.DeviceArray((n_out, s), np.complex64)
         else:
             final = None
-        se = s + s % 2
+        se = s if self._single else s + s % 2
         if se != s:
             x = hip.pad_streams_to_even(x, s)
             target = hip.DeviceArray((n_out, se), np.complex64)

@@ -63,6 +63,7 @@ def share_response(task, torch, dist, device, src=0, comm=None):
     dist.broadcast(shape, src)
     ncol, n_plan = int(shape[0].item()), int(shape[2].item())
     task._paired = bool(shape[3].item())
+    task._single = n_plan == 1               # one stream: run unpadded (overlap_save._plan_layout)
     assert int(shape[1].item()) == n, "ranks disagree about the block length"
     if rank == src:
         resp = torch.view_as_real(torch.from_numpy(columns)).to(device).contiguous()

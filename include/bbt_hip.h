@@ -109,7 +109,10 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  *               reference's NumPy engine picks (fourier/numpy.py:99-126,
  *               block rule base.py:750-758) -- that is <= 8192 or splits
  *               into two such factors <= 8192 (generic LDS Stockham path)
- *   n_stream    S, even
+ *   n_stream    S, even; or 1 with a power-of-two n_fft: the one stream runs
+ *               unpadded, two consecutive blocks side by side where a pair of
+ *               streams would be (plain bbt_osm_execute only: no fused
+ *               channelizer, no prefilter)
  *   n_resp      number of distinct response columns C
  *   resp        C x N complex64, FFT-natural order, UNSCALED
  *               (= Disperse.phase_factor, dispersion.py:115-129, or

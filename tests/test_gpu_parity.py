@@ -1944,6 +1944,49 @@ def test_one_stream_through_the_channelizer_unpadded(n_chan):
         hip.ChanPlan(128, 1, -1)
 
 
+@pytest.mark.parametrize('n_fft', [1024, 4096, 2**14, 2**16, 2**18, 2**21])
+def test_one_stream_through_overlap_save_unpadded(n_fft):
+    """One complex stream (and two float32 streams with a Hermitian response,
+    which are one complex stream) through every block-length regime: the
+    library pairs consecutive blocks instead of streams, for odd and even
+    numbers of blocks and a ragged last block, and matches the padded route
+    bit for bit."""
+    rng = np.random.default_rng(n_fft)
+    n_tap = 33
+    spf = n_fft - n_tap + 1
+    resp = (rng.standard_normal(n_tap) + 1j * rng.standard_normal(n_tap)).astype(np.complex64)
+    limit_r, limit_c = bt.Convolve.FIR_MAX_TAPS, bt.Convolve.FIR_MAX_TAPS_COMPLEX
+    bt.Convolve.FIR_MAX_TAPS = bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0
+    try:
+        for n_blocks, extra in ((1, 0), (2, 0), (3, 77), (6, 5)):
+            n_in = n_blocks * spf + n_tap - 1 + extra
+            x = (rng.standard_normal(n_in) + 1j * rng.standard_normal(n_in)).astype(np.complex64)
+            ds = bt.DeviceStream(x, T0, 1 * u.MHz)
+            cv = bt.Convolve(ds, resp, samples_per_frame=spf)
+            assert cv._ih_samples_per_frame == n_fft
+            got = cv.read()
+            assert cv._single and cv._get_plan().n_stream == 1
+            want = np.convolve(x.astype(np.complex128), resp.astype(np.complex128), mode='valid')
+            assert_parity(got, want[:got.shape[0]].astype(np.complex64), f'one stream, n_fft {n_fft}, {n_blocks} blocks')
+            padded = bt.Convolve(ds, resp, samples_per_frame=spf)
+            padded.SINGLE_STREAM_UNPADDED = False
+            assert np.array_equal(padded.read(), got) and not padded._single
+            if n_blocks > 1:
+                cv.seek(spf - 3)                              # a read across a block seam
+                assert np.array_equal(cv.read(7), got[spf - 3:spf + 4])
+        # two float32 streams, real response
+        xr = rng.standard_normal((3 * spf + n_tap - 1 + 11, 2)).astype(np.float32)
+        rr = rng.standard_normal(n_tap).astype(np.float32)
+        cv = bt.Convolve(bt.DeviceStream(xr, T0, 1 * u.MHz), rr, samples_per_frame=spf)
+        got = cv.read()
+        assert cv._single and got.dtype == np.float32
+        want = np.stack([np.convolve(xr[:, k].astype(np.float64), rr.astype(np.float64), mode='valid')
+                         for k in range(2)], axis=1)[:got.shape[0]]
+        assert np.abs(got - want).max() <= 1e-5 * np.sqrt(np.mean(want ** 2)) * 3
+    finally:
+        bt.Convolve.FIR_MAX_TAPS, bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit_r, limit_c
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
