@@ -21,7 +21,7 @@
  *   - array layout is numpy complex64, C-contiguous, shape (n, S): time
  *     major, the S = prod(sample_shape) streams innermost, interleaved
  *     (re, im) float32.  S must be even (callers pad odd S, see
- *     bbt_memcpy2d).
+ *     bbt_pad_streams) or, where a function says so, 1.
  *   - `*_dev` pointers are device pointers on the current device; the caller
  *     owns them (bbt_malloc, or any other HIP allocation such as a torch
  *     tensor's data_ptr()).  `stream` is a hipStream_t (NULL = default).
