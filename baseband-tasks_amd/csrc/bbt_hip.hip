@@ -1561,6 +1561,12 @@ template <int N, int NTAP>
 static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* out, int64_t n_spec,
                               hipStream_t st) {
     constexpr int NG = 4096 / N;
+    if (p->S == 1) {            // one stream: two groups of NG spectra side by side
+        const unsigned gx = (unsigned)((n_spec + 2 * NG - 1) / (2 * NG));
+        hipLaunchKernelGGL((k_pfb_window<N, NTAP, true>), dim3(gx), dim3(256), 0, st, in, out,
+                           (long long)n_spec, 1, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+        return;
+    }
     const unsigned gx = (unsigned)((n_spec + NG - 1) / NG);
     hipLaunchKernelGGL((k_pfb_window<N, NTAP>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
                        (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
@@ -1600,7 +1606,7 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     ARG_TRY(fft_len_ok(n_chan),
             "bbt_pfb_plan_create: n_chan=%d must be a power of two in [256, 4096]", n_chan);
     ARG_TRY(n_tap >= 1 && n_tap <= 64, "bbt_pfb_plan_create: n_tap=%d must be in [1, 64]", n_tap);
-    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2,
+    ARG_TRY(n_stream == 1 || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
             "bbt_pfb_plan_create: n_stream=%d must be even and >= 2", n_stream);
     bbt_pfb_plan* p = new bbt_pfb_plan;
     p->n = n_chan;
@@ -1610,6 +1616,11 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     const size_t tb = (size_t)n_tap * n_chan * sizeof(float);
     const char* env = getenv("BBT_PFB_WINDOW");
     p->window = (!env || atoi(env) != 0) && pfb_window_dispatch(p, nullptr, nullptr, 0, nullptr, true);
+    if (n_stream == 1 && !p->window) {          // only the sliding-window kernels take one stream
+        delete p;
+        return fail("bbt_pfb_plan_create: one stream needs n_chan in 256..2048 and 4, 8, 12 or 16 taps "
+                    "(got %d x %d); pad to two streams otherwise", n_tap, n_chan);
+    }
     if ((p->window && get_tables(4096, &p->tab4096)) ||
         get_tables(n_chan, &p->tab) || hipMalloc((void**)&p->taps, tb) != hipSuccess ||
         hipMemcpy(p->taps, taps_host, tb, hipMemcpyHostToDevice) != hipSuccess) {

@@ -1109,7 +1109,9 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
 #ifndef BBT_PFB_BATCH
 #define BBT_PFB_BATCH 64
 #endif
-template <int N, int NTAP>
+// SINGLE (S == 1): the two transforms side by side are the workgroup's spectra
+// [i0, i0 + NG) and [i0 + NG, i0 + 2 NG) of the one stream (rows NG further on).
+template <int N, int NTAP, bool SINGLE = false>
 __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ in,
                                                     float2* __restrict__ out, long long n_spec,
                                                     int S, const float* __restrict__ taps,
@@ -1121,15 +1123,15 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
     constexpr int P = 16 / NG;         // columns per thread
     __shared__ v2 lds[G::LDS_ELEMS];
     const int tau = threadIdx.x;
-    const int npair = S >> 1;
+    const int npair = SINGLE ? 1 : S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const long long i0 = (long long)(vb / npair) * NG;      // first spectrum of this workgroup
+    const long long i0 = (long long)(vb / npair) * (SINGLE ? 2 * NG : NG);   // first spectrum of this workgroup
     const int sp = vb % npair;
     c2 v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = czero();
     const long long rows_left = n_spec + NTAP - 1 - i0;     // input rows that exist from i0 on
-    const float2* src = in + ((i0 * N + tau) * S + 2 * sp);
+    const float2* src = SINGLE ? in + (i0 * N + tau) : in + ((i0 * N + tau) * S + 2 * sp);
     // One column of the thread at a time: all NTAP + NG - 1 row loads of the
     // column are issued together (the kernel is bound by load latency at 2
     // waves/SIMD: this keeps 15 loads per thread in flight instead of ~4), then
@@ -1151,7 +1153,13 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
                 const int r = r0 + i;
                 if (r < NR) {
                     const long long rr = r < rows_left ? r : rows_left - 1;
-                    x[i] = ld_ext(src + (rr * N + T * c) * S);
+                    if constexpr (SINGLE) {
+                        const long long rb = r + NG < rows_left ? r + NG : rows_left - 1;
+                        const float2 a = src[rr * N + T * c], b = src[rb * N + T * c];
+                        x[i] = c2{v2{a.x, b.x}, v2{a.y, b.y}};
+                    } else {
+                        x[i] = ld_ext(src + (rr * N + T * c) * S);
+                    }
                 }
             }
 #pragma unroll
@@ -1159,12 +1167,19 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
                 const int r = r0 + i;
                 if (r < NR) {
                     const float keep = r < rows_left ? 1.f : 0.f;
+                    const float keep_b = (!SINGLE || r + NG < rows_left) ? 1.f : 0.f;
 #pragma unroll
                     for (int q = 0; q < NG; ++q) {
                         const int t = r - q;                  // tap index for spectrum i0 + q
                         if (t >= 0 && t < NTAP) {
-                            v[q * P + c].re += x[i].re * (h[t] * keep);
-                            v[q * P + c].im += x[i].im * (h[t] * keep);
+                            if constexpr (SINGLE) {
+                                const v2 hk = v2{h[t] * keep, h[t] * keep_b};
+                                v[q * P + c].re += x[i].re * hk;
+                                v[q * P + c].im += x[i].im * hk;
+                            } else {
+                                v[q * P + c].re += x[i].re * (h[t] * keep);
+                                v[q * P + c].im += x[i].im * (h[t] * keep);
+                            }
                         }
                     }
                 }
@@ -1197,6 +1212,17 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
     wg_fft_tail<4096, -1, 0>(v, lds, tau, 0, tw1);
     const int f = tau & 15, g = tau >> 4;
     const int q = f / P, c = f - q * P;
+    if constexpr (SINGLE) {
+        float2* dst = out + ((i0 + q) * N + c);
+        const bool act_a = i0 + q < n_spec, act_b = i0 + NG + q < n_spec;
+#pragma unroll
+        for (int c2i = 0; c2i < 16; ++c2i) {
+            const long long k = P * (g + 16 * c2i);
+            if (act_a) dst[k] = make_float2(v[c2i].re.x, v[c2i].im.x);
+            if (act_b) dst[(long long)NG * N + k] = make_float2(v[c2i].re.y, v[c2i].im.y);
+        }
+        return;
+    }
     if (i0 + q < n_spec) {
         float2* dst = out + (((i0 + q) * N + c) * S + 2 * sp);
 #pragma unroll

@@ -1,4 +1,6 @@
 """Polyphase filter bank on the GPU (reference baseband_tasks/pfb.py:14-154)."""
+import os
+
 import numpy as np
 
 from . import hip
@@ -49,7 +51,13 @@ class PolyphaseFilterBank(_RowFFTTask):
     frequency, sideband : optional overrides of the stream metadata.
     """
 
-    _SINGLE_STREAM = False       # the filter bank kernels take stream pairs only
+    def _even(self, count):
+        """One stream runs unpadded on the sliding-window kernels (n 256..2048 with
+        4, 8, 12 or 16 taps); every other odd count is padded to even."""
+        if (count == 1 and self._n in (256, 512, 1024, 2048) and self._response.shape[0] in (4, 8, 12, 16)
+                and os.environ.get('BBT_PFB_WINDOW', '1') != '0'):
+            return 1
+        return count + count % 2
 
     def __init__(self, ih, response, samples_per_frame=None, frequency=None, sideband=None):
         response = np.asanyarray(response)

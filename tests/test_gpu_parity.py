@@ -1987,6 +1987,28 @@ def test_one_stream_through_overlap_save_unpadded(n_fft):
         bt.Convolve.FIR_MAX_TAPS, bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit_r, limit_c
 
 
+@pytest.mark.parametrize('n_tap,n_chan', [(4, 256), (8, 512), (12, 1024), (16, 2048), (12, 4096), (5, 1024)])
+def test_one_stream_through_the_filter_bank(n_tap, n_chan):
+    """One complex stream / two float32 streams through PolyphaseFilterBank: unpadded
+    on the sliding-window kernels (two groups of spectra side by side), padded
+    for the other (taps, channels); both against the oracle."""
+    rng = np.random.default_rng(n_tap * n_chan)
+    resp = orc.sinc_hamming(n_tap, n_chan)
+    window = n_chan <= 2048 and n_tap in (4, 8, 12, 16)
+    for n_frames in (3, 4):
+        ih_spf = n_chan * (n_tap + 9)
+        n_in = ih_spf * (n_frames + 4)
+        x = (rng.standard_normal(n_in) + 1j * rng.standard_normal(n_in)).astype(np.complex64)
+        pfb = bt.PolyphaseFilterBank(bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=ih_spf), resp)
+        assert pfb._n_stream_even == (1 if window else 2)
+        want, _ = orc.polyphase_filter_bank(x, resp, ih_spf)
+        assert_parity(pfb.read(), want.astype(np.complex64), f'one stream {n_tap} x {n_chan}')
+        xr = rng.standard_normal((n_in, 2)).astype(np.float32)
+        pfb = bt.PolyphaseFilterBank(bt.DeviceStream(xr, T0, 1 * u.MHz, samples_per_frame=ih_spf), resp)
+        want, _ = orc.polyphase_filter_bank(xr, resp, ih_spf)
+        assert_parity(pfb.read(), want.astype(np.complex64), f'two real streams {n_tap} x {n_chan}')
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
