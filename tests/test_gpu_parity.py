@@ -1579,8 +1579,10 @@ def test_random_block_descriptors_through_the_c_abi():
                131220]
     for case in range(12):
         n_fft = int(rng.choice(lengths))
-        S = int(rng.choice([2, 4, 6, 16]))
-        n_resp = int(rng.choice([1, S // 2, S]))
+        S = int(rng.choice([1, 2, 4, 6, 16]))
+        if S == 1 and n_fft & (n_fft - 1):
+            S = 2                                      # (one stream: power-of-two blocks only)
+        n_resp = int(rng.choice([1, max(S // 2, 1), S]))
         resp = np.exp(2j * np.pi * rng.uniform(size=(n_resp, n_fft))) * rng.uniform(0.5, 1.5, size=(n_resp, n_fft))
         resp = resp.astype(np.complex64)
         index = None if n_resp == 1 else (np.arange(S, dtype=np.int32) * n_resp) // S    # one per stream or per pair
