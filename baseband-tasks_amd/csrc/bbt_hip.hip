@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 120
+#define BBT_VERSION 121
 
 // ---------------------------------------------------------------------------
 // errors

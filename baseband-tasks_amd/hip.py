@@ -96,6 +96,9 @@ SIGNATURES = {
     'bbt_gather_output': [_vp, _vp, _vp, _i64, _vp],
 }
 
+#: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
+MIN_LIB_VERSION = 121
+
 _lib = None
 _lock = threading.Lock()
 
@@ -118,6 +121,10 @@ def lib():
                     fn = getattr(handle, name)
                     fn.argtypes = argtypes
                     fn.restype = _int
+                if handle.bbt_version() < MIN_LIB_VERSION:
+                    raise HipLibraryMissing(
+                        f"{LIB_PATH} is version {handle.bbt_version()}, this package needs "
+                        f">= {MIN_LIB_VERSION}: rebuild it (python -c 'import __graft_entry__ as g; g.build()').")
                 _lib = handle
     return _lib
 
