@@ -14,7 +14,7 @@ from .generators import (StreamGenerator, EmptyStreamGenerator, Noise, NoiseGene
 from .dm import DispersionMeasure
 from .fourier import fft_maker, HipFFTMaker
 from .dispersion import Disperse, Dedisperse, DisperseSamples, DedisperseSamples
-from .convolution import Convolve
+from .convolution import Convolve, ConvolveSamples
 from .sampling import ShiftAndResample, Resample, TimeDelay, ShiftSamples
 from .channelize import Channelize, Dechannelize
 from .pfb import (sinc_hamming, PolyphaseFilterBank, PolyphaseFilterBankSamples,

@@ -7,7 +7,7 @@ from .base import check_broadcast_to
 from .device_task import fetch_device
 from .overlap_save import SpectralMultiplyTask
 
-__all__ = ['Convolve']
+__all__ = ['Convolve', 'ConvolveSamples']
 
 
 class Convolve(SpectralMultiplyTask):
@@ -112,3 +112,13 @@ class Convolve(SpectralMultiplyTask):
         if self._fir:
             self._fir.close()
         self._fir = None
+
+
+class ConvolveSamples(Convolve):
+    """Convolve a time stream with a response in the time domain (reference
+    convolution.py:23-62: `numpy.convolve` per stream, 'valid' part).  Same
+    arguments and result as `Convolve`; here it always takes the direct filter
+    kernel (`bbt_fir_execute`) up to 1024 taps -- beyond that the
+    Fourier-domain plan, which gives the same linear convolution."""
+    FIR_MAX_TAPS = 1024
+    FIR_MAX_TAPS_COMPLEX = 1024
