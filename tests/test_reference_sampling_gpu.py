@@ -1,0 +1,172 @@
+"""Known answers of the reference's resampling and sample-shift tests on the
+HIP path (reference baseband_tasks/tests/test_sampling.py:77-261 and 621-707;
+same signals, paddings, offsets, shifts and tolerances).
+
+Two streams carry the same signal, one at the full rate and one at a quarter
+of it; resampling the slow one onto quarter-sample offsets must reproduce
+every fourth sample of the fast one.  In this package plain numbers are
+samples and absolute times are `Time` objects (there are no unit quantities
+without astropy), so the reference's offsets given as durations appear here as
+the equivalent number of samples.  The receiver-chain simulations of
+test_sampling.py:264-620 (mixing, low-pass filtering, `Stack`) are not
+restated; `TimeDelay` and `ShiftAndResample(..., lo=...)` are pinned by the
+golden vectors `st_delay` / `sr_*` instead (test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+import baseband_tasks_amd as bt
+from baseband_tasks_amd import units as u
+
+pytestmark = pytest.mark.gpu
+
+START = bt.Time('2010-11-12T13:14:15')
+FULL_RATE = 1. * u.kHz
+FULL_FRAME = 4096
+N_FRAMES = 3
+ATOL = 7e-4                                  # test_sampling.py:91
+
+
+def from_array(data, rate, frame):
+    return bt.StreamGenerator(lambda fh: data[fh.tell():fh.tell() + fh.samples_per_frame], shape=data.shape,
+                              start_time=START, sample_rate=rate, samples_per_frame=frame, dtype=data.dtype,
+                              frequency=400. * u.kHz, sideband=np.array([-1, 1]))
+
+
+def two_tones(dtype):
+    """test_sampling.py:93-118: two tones not commensurate with quarter samples or frames."""
+    f_signal = FULL_RATE * 2 / FULL_FRAME * np.array([31.092, 65.1234])
+    t = np.arange(FULL_FRAME * N_FRAMES)[:, None] / FULL_RATE
+    phi = np.deg2rad(np.pi) + 2. * np.pi * f_signal * t
+    full = (np.cos(phi) if np.dtype(dtype).kind == 'f' else np.exp(1j * phi)).astype(dtype)
+    return full, 32
+
+
+def band_limited_noise(dtype):
+    """test_sampling.py:225-261: noise without the frequencies nearest to the slow
+    stream's band edge (resampling mixes them across the edge); pad 64."""
+    pad = 64
+    n = FULL_FRAME // 4 * N_FRAMES
+    rng = np.random.RandomState(123456)
+    part_ft = np.fft.fft(rng.normal(size=(n, 4)).view('c16'), axis=0)
+    part_ft[n // 2 - 2 * pad:n // 2 + 2 * pad] = 0
+    full_ft = np.concatenate([part_ft[:n // 2], np.zeros((3 * n, 2), 'c16'), part_ft[-n // 2:]], axis=0)
+    return np.fft.ifft(4 * full_ft, axis=0).astype(dtype), pad
+
+
+SIGNALS = {'tones-real': (two_tones, np.float32), 'tones-complex': (two_tones, np.complex64),
+           'noise-complex': (band_limited_noise, np.complex64)}
+
+
+@pytest.fixture(scope='module', params=sorted(SIGNALS))
+def streams(request):
+    make, dtype = SIGNALS[request.param]
+    full, pad = make(dtype)
+    part = np.ascontiguousarray(full[::4])
+    return full, from_array(part, FULL_RATE / 4, FULL_FRAME // 4), pad
+
+
+def every_fourth_from(full, first_full_sample, count, stream=Ellipsis):
+    assert abs(first_full_sample - round(first_full_sample)) < 1e-6 and round(first_full_sample) >= 0
+    return full[int(round(first_full_sample))::4][:count][:, stream]
+
+
+@pytest.mark.parametrize('offset', [34, 34.5, 35.75, 12.5, 16.25, 'time'])
+def test_resample_onto_quarter_sample_offsets(streams, offset):
+    """test_sampling.py:128-163 (12.5 and 16.25 samples are its 50 ms and 65 ms)."""
+    full, part_fh, pad = streams
+    if offset == 'time':
+        offset = START + 0.073
+        in_samples = 0.073 * part_fh.sample_rate
+    else:
+        in_samples = float(offset)
+    ih = bt.Resample(part_fh, offset, pad=pad)
+    assert ih.shape[0] == part_fh.shape[0] - 2 * pad and ih.sample_shape == part_fh.sample_shape
+    assert abs((ih.time - START) - in_samples / part_fh.sample_rate) < 1e-9           # left at the requested time
+    whole = round(in_samples)
+    assert ih.offset + pad == whole
+    assert abs((ih.start_time - START) - (pad + in_samples - whole) / part_fh.sample_rate) < 1e-9
+    ih.seek(0)
+    data = ih.read()
+    expected = every_fourth_from(full, (ih.start_time - START) * FULL_RATE, data.shape[0])
+    assert data.dtype == full.dtype and np.abs(data - expected).max() < ATOL
+
+
+@pytest.mark.parametrize('shift', [0., 0.25, -5.25, [1.75, 10.25], [-0.25, 3.25]])
+@pytest.mark.parametrize('offset', [None, 0, 0.25])
+def test_shift_and_resample(streams, shift, offset):
+    """test_sampling.py:171-202 ([-0.25, 3.25] samples are its [-1, 13] ms)."""
+    full, part_fh, pad = streams
+    ih = bt.ShiftAndResample(part_fh, shift, offset=offset, pad=pad)
+    grid = offset if offset is not None else float(np.mean(shift))
+    off_grid = (ih.start_time - START) * ih.sample_rate - grid
+    assert abs(off_grid - round(off_grid)) < 1e-9 * ih.sample_rate * 1e3
+    assert abs(ih.shape[0] - (part_fh.shape[0] - 2 * pad - np.ptp(shift))) <= 0.5
+    ih.seek(0)
+    data = ih.read()
+    for i, s in enumerate(np.atleast_1d(shift)):
+        first = ((ih.start_time - START) - s / ih.sample_rate) * FULL_RATE
+        which = i if np.ndim(shift) else Ellipsis
+        expected = every_fourth_from(full, first, data.shape[0], which)
+        assert np.abs(data[:, which] - expected).max() < ATOL
+
+
+def test_a_shift_per_row_of_a_one_axis_sample_is_refused(streams):
+    """test_sampling.py:209-212."""
+    with pytest.raises(ValueError, match='broadcast to sample shape'):
+        bt.ShiftAndResample(streams[1], np.array([[1], [2]]))
+
+
+# ------------------------------------------------------------------ test_sampling.py:621-707
+@pytest.fixture(scope='module')
+def counter():
+    """Every element of sample i is i: (1000, 5, 3) float64."""
+    def frame(fh):
+        here = np.arange(fh.tell(), fh.tell() + fh.samples_per_frame, dtype=float)
+        return np.broadcast_to(here[:, None, None], (fh.samples_per_frame, 5, 3)).copy()
+    return bt.StreamGenerator(frame, (1000, 5, 3), bt.Time('2010-11-12T00:00:00'), 1. * u.Hz,
+                              samples_per_frame=100, dtype=float)
+
+
+@pytest.mark.parametrize('start,n', [(0, 5), (90, 20)])
+def test_shifts_back_only(counter, start, n):
+    """test_sampling.py:647-660: shifts -4 .. 0 along the 5-axis keep the start time."""
+    shift = np.arange(-4, 1)
+    task = bt.ShiftSamples(counter, shift.reshape(-1, 1), samples_per_frame=100)
+    assert task.start_time == counter.start_time
+    task.seek(start)
+    got = task.read(n)
+    counter.seek(start)
+    raw = counter.read(100)
+    for i, back in enumerate(-shift):
+        assert np.array_equal(got[:, i], raw[back:back + n, i])
+
+
+@pytest.mark.parametrize('start,n', [(0, 5), (100, 20)])
+def test_shifts_both_ways(counter, start, n):
+    """test_sampling.py:662-672: the largest forward shift sets the new start."""
+    shift = np.array([-2, 0, 3])
+    task = bt.ShiftSamples(counter, shift, samples_per_frame=100)
+    assert abs(task.start_time - counter.start_time - 3 / counter.sample_rate) < 1e-9
+    task.seek(start)
+    got = task.read(n)
+    counter.seek(start)
+    raw = counter.read(100)
+    for i, back in enumerate(3 - shift):
+        assert np.array_equal(got[:, :, i], raw[back:back + n, :, i])
+
+
+@pytest.mark.parametrize('fshift,ishift', [
+    (np.array([1., 2., 3.25]), [1, 2, 3]),
+    (np.array([[-1.9], [-5.], [5.25], [3.49], [-1.2]]), np.reshape([-2, -5, 5, 3, -1], (-1, 1)))])
+def test_fractional_shifts_are_rounded(counter, fshift, ishift):
+    """test_sampling.py:688-703 (the variant with the shift as a duration needs unit quantities)."""
+    rounded, exact = bt.ShiftSamples(counter, fshift), bt.ShiftSamples(counter, ishift)
+    assert np.array_equal(rounded._shift, exact._shift)
+    assert np.array_equal(rounded.read(), exact.read())
+
+
+def test_sample_shift_of_the_wrong_shape_is_refused(counter):
+    """test_sampling.py:705-707."""
+    with pytest.raises(ValueError, match='broadcast to sample shape'):
+        bt.ShiftSamples(counter, np.array([[1], [2]]))
