@@ -193,17 +193,51 @@ class Base:
     def _tell_time(self, offset):
         return self._start_time + offset / self._sample_rate
 
-    def _repr_args(self):
-        return [f"shape={self.shape}", f"start_time={self._start_time.isot}",
-                f"sample_rate={self.sample_rate} Hz",
-                f"samples_per_frame={self.samples_per_frame}", f"dtype={self.dtype}"]
+    # -- repr: the constructor call that would rebuild the object (reference base.py:174-233) --
+    def _constructor_parameters(self):
+        """Parameters of this class's constructor and, as long as a constructor
+        forwards ``**kwargs``, of its bases' constructors (first mention wins)."""
+        found = {}
+        for cls in type(self).__mro__:
+            try:
+                params = inspect.signature(cls).parameters
+            except (TypeError, ValueError):
+                break
+            for key, par in params.items():
+                found.setdefault(key, par)
+            if cls is Base or not any(par.kind is par.VAR_KEYWORD for par in params.values()):
+                break
+        return found
+
+    def _repr_item(self, key, default, value=None):
+        """``key=value`` for a constructor argument whose value on the instance
+        (attribute ``key`` or ``_key``) is set and differs from ``default``; else None."""
+        if value is None:
+            value = getattr(self, key, None)
+            if value is None:
+                value = getattr(self, '_' + key, None)
+            if value is None:
+                return None
+        if default is not inspect.Parameter.empty:
+            try:
+                if np.all(value == default):
+                    return None
+            except Exception:
+                pass
+        if isinstance(value, Time):
+            value = value.isot
+        elif isinstance(value, np.ndarray) and value.size > 16:
+            value = np.array2string(value, threshold=6)
+        return f"{key}={value}".replace('\n', ',')
 
     def __repr__(self):
         name = type(self).__name__
-        meta = [f"{k}={np.array2string(np.asarray(v), threshold=6)}".replace('\n', ',')
-                for k, v in self.meta.get('__attributes__', {}).items()]
+        params = self._constructor_parameters()
+        items = [self._repr_item(key, par.default) for key, par in params.items()
+                 if par.kind not in (par.VAR_KEYWORD, par.VAR_POSITIONAL)]
+        items += [self._repr_item(key, None) for key in self.meta.get('__attributes__', {}) if key not in params]
         sep = ",\n " + " " * len(name)
-        return f"{name}({sep.join(self._repr_args() + meta)})"
+        return f"{name}({sep.join(item for item in items if item)})"
 
     # -- pointer ---------------------------------------------------------------
     def seek(self, offset, whence=0):
@@ -360,8 +394,25 @@ class BaseTaskBase(Base):
         super().__init__(shape=shape, start_time=start_time, sample_rate=sample_rate,
                          samples_per_frame=samples_per_frame, dtype=dtype, **kwargs)
 
+    def _repr_item(self, key, default, value=None):
+        """Arguments left at None default to what the underlying stream has."""
+        if key == 'ih':
+            return 'ih'
+        if default is None:
+            if key == 'samples_per_frame':
+                default = getattr(self, '_ih_samples_per_frame', None)
+            elif key == 'ih_samples_per_frame':
+                default = getattr(self.ih, 'samples_per_frame', None)
+            else:
+                default = getattr(self.ih, key, None)
+        return super()._repr_item(key, default, value)
+
     def __repr__(self):
-        return super().__repr__() + "\nih: " + "\n    ".join(repr(self.ih).split('\n'))
+        head = super().__repr__()
+        if head.count('\n') == 1:
+            head = ' '.join(part.strip() for part in head.split('\n'))
+        inner = repr(self.ih) if not self.closed else '(closed)'
+        return head + "\nih: " + "\n    ".join(inner.split('\n'))
 
     def close(self):
         """Drop the reference to the underlying stream (it is not closed)."""

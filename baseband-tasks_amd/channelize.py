@@ -267,8 +267,10 @@ class Dechannelize(_RowFFTTask):
                 raise ValueError("need explicit 'n' for real transform.")
             n = ih.shape[1]
         n = operator.index(n)
+        # (like the reference, a channel count that does not fit n is only an error once data are read)
+        self._mismatch = None
         if ih.shape[1] != (n // 2 + 1 if self._real else n):
-            raise ValueError(f"{ih.shape[1]} channels do not match n={n} for {dtype} output.")
+            self._mismatch = f"{ih.shape[1]} channels do not match n={n} for {dtype} output."
         _check_n(n)
         if samples_per_frame is None:
             ih_spf = ih.samples_per_frame
@@ -299,6 +301,8 @@ class Dechannelize(_RowFFTTask):
             self._run(x.reshape(n_spectra * n, s), n_spectra, out.reshape(n_spectra * n, s))
 
     def _compute_frames(self, first, last, out):
+        if self._mismatch:
+            raise ValueError(self._mismatch)
         start, stop = self._frame_span(first, last)
         n_spectra = (stop - start) // self._n
         x = fetch_device(self.ih, start // self._n, n_spectra)

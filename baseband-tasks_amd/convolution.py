@@ -28,6 +28,12 @@ class Convolve(SpectralMultiplyTask):
         self._keep_from = self._pad_start + self._pad_end
         self._ft_response_cache = None
 
+    def _repr_item(self, key, default, value=None):
+        # the 'offset' argument (= the padding at the end), not the sample pointer
+        if key == 'offset' and value is None:
+            value = self._pad_end
+        return super()._repr_item(key, default, value)
+
     @property
     def _ft_response(self):
         """FFT of the zero-extended response (convolution.py:108-114),

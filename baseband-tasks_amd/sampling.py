@@ -96,6 +96,12 @@ class ShiftAndResample(Convolve):
         phase = self._shift / self.sample_rate * self._lo * self.sideband
         return self._response * np.exp(-2j * np.pi * phase)
 
+    def _repr_item(self, key, default, value=None):
+        # the 'offset' argument, not the sample pointer of the same name
+        if key == 'offset':
+            value = self._offset
+        return super()._repr_item(key, default, value)
+
 
 class Resample(ShiftAndResample):
     """Resample so that a sample falls exactly on ``offset`` and leave the

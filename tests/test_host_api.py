@@ -412,3 +412,28 @@ def test_single_precision_adapter():
     real = bt.NoiseGenerator((3000,), T0, 1e6, 1000, dtype=np.float64, seed=4)
     assert bt.SinglePrecision(real).dtype == np.float32
     assert bt.SinglePrecision(bt.SinglePrecision(real)).read(10).dtype == np.float32
+
+
+def test_repr_lists_the_non_default_constructor_arguments():
+    """The reference's repr (base.py:207-233, 580-599) and what its tests ask of it
+    (test_channelize.py:117-126, test_convolution.py:87-93, test_sampling.py:165-169):
+    class name, 'ih', then only the arguments that differ from their defaults --
+    with None meaning "as the underlying stream" -- and the underlying stream's own
+    repr after 'ih:'.  (No GPU needed: plans are made on first read.)"""
+    nh = bt.NoiseGenerator((16384, 2), '2020-01-01T00:00:00', 1 * u.MHz, 1024, seed=3, frequency=300 * u.MHz,
+                           sideband=np.array([1, -1]))
+    ct = bt.Channelize(nh, 1024)
+    r = repr(ct)
+    assert r.startswith('Channelize(ih') and 'n=1024' in r and '\nih: NoiseGenerator(shape=(16384, 2)' in r
+    dr = repr(bt.Dechannelize(ct, 1024))
+    assert dr.startswith('Dechannelize(ih') and 'n=1024' in dr and '\nih: Channelize(ih' in dr
+    cr = repr(bt.ConvolveSamples(nh, np.ones(3)))
+    assert cr.startswith('ConvolveSamples(ih') and 'response=' in cr and 'offset=' not in cr
+    assert 'samples_per_frame' in cr                      # differs from the input's
+    assert 'offset=1' in repr(bt.Convolve(nh, np.ones(3), offset=1))
+    rr = repr(bt.Resample(nh, 0.5, samples_per_frame=511))
+    assert rr.startswith('Resample(ih') and 'offset=0.5' in rr
+    assert repr(bt.Integrate(bt.Square(nh), 16)).startswith('Integrate(ih, step=16)\nih: Square(ih)')
+    sr = repr(bt.SetAttribute(nh, frequency=1e9, sideband=1))
+    assert 'frequency=1000000000.0' in sr and 'sideband=1' in sr and 'sample_rate' not in sr.split('\nih:')[0]
+    assert repr(nh).startswith('NoiseGenerator(shape=(16384, 2),\n               start_time=2020-01-01T00:00:00')
