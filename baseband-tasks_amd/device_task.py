@@ -36,6 +36,11 @@ class DeviceTaskMixin:
     #: upper bound on frames computed by one call (bounds device memory)
     max_frames_per_call = 32
 
+    @property
+    def _device_dtype(self):
+        """dtype of the frames in HBM (a task may present another one to its readers)."""
+        return self.dtype
+
     _cache = None          # DeviceArray holding frames [_cache_first, _cache_last)
     _cache_first = 0
     _cache_last = 0
@@ -59,7 +64,7 @@ class DeviceTaskMixin:
         if buf is None or buf.size < need:
             # drop the old one first so peak memory is one buffer
             self._cache = self._cache_buffer = None
-            buf = self._cache_buffer = DeviceArray((need,), self.dtype)
+            buf = self._cache_buffer = DeviceArray((need,), self._device_dtype)
         return buf[:need].reshape((n_samples,) + tuple(self.sample_shape))
 
     def _ensure_frames(self, first, last):
@@ -74,7 +79,7 @@ class DeviceTaskMixin:
             # request instead of recomputing it
             s0, s1 = self._frame_span(first, first + 1)
             c0 = self._cache_first * self.samples_per_frame
-            reuse = DeviceArray((s1 - s0,) + tuple(self.sample_shape), self.dtype)
+            reuse = DeviceArray((s1 - s0,) + tuple(self.sample_shape), self._device_dtype)
             reuse.copy_from_device(self._cache[s0 - c0:s1 - c0])
         out = self._out_buffer(stop - start)
         if reuse is not None:
@@ -91,13 +96,13 @@ class DeviceTaskMixin:
         again."""
         count = self._prepare_read(count, None)
         if count == 0:
-            return DeviceArray((0,) + tuple(self.sample_shape), self.dtype)
+            return DeviceArray((0,) + tuple(self.sample_shape), self._device_dtype)
         spf = self.samples_per_frame
         first = self.offset // spf
         last = (self.offset + count - 1) // spf + 1
         if last - first > self.max_frames_per_call:
             # too much for one cache: assemble piecewise into a fresh array
-            out = DeviceArray((count,) + tuple(self.sample_shape), self.dtype)
+            out = DeviceArray((count,) + tuple(self.sample_shape), self._device_dtype)
             done = 0
             while done < count:
                 pos = self.offset
@@ -117,7 +122,7 @@ class DeviceTaskMixin:
     def read(self, count=None, out=None):
         count = self._prepare_read(count, out)
         if out is None:
-            out = np.empty((count,) + tuple(self.sample_shape), dtype=self.dtype)
+            out = np.empty((count,) + tuple(self.sample_shape), dtype=self._device_dtype)
         spf = self.samples_per_frame
         done = 0
         while done < count:
@@ -129,7 +134,7 @@ class DeviceTaskMixin:
             piece = cache[pos - c0:pos - c0 + n]
             target = out[done:done + n]
             if isinstance(target, np.ndarray) and target.flags.c_contiguous \
-                    and target.dtype == self.dtype:
+                    and target.dtype == self._device_dtype:
                 piece.to_host(target)
             else:
                 out[done:done + n] = piece.to_host()

@@ -34,8 +34,10 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
     start : int or `~baseband_tasks_amd.units.Time`
         Offset (or time, rounded to the nearest sample) of the first sample.
     average : bool
-        Only averaging is supported here (the reference's ``average=False``
-        returns a structured array of sums and counts).
+        True: averages.  False: like the reference, `read` returns a structured
+        array with the sums in ``'data'`` and the number of samples summed in
+        ``'count'`` (the task's ``dtype`` is that structured type; the frames in
+        HBM hold the sums).
     samples_per_frame : int
         Output samples per frame (framing only).
     dtype : optional, must equal the input dtype.
@@ -49,8 +51,6 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
                  samples_per_frame=1, dtype=None):
         if phase is not None:
             raise NotImplementedError("integration in pulse phase is outside the accelerated path.")
-        if not average:
-            raise NotImplementedError("only average=True is accelerated.")
         ih_start = ih.seek(start)
         ih_n = ih.shape[0] - ih_start
         if ih_start < 0 or ih_n < 0:
@@ -70,11 +70,36 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
         n_out = int(ih_n / step + 0.5 / step)
         assert n_out >= 1, "time per frame larger than total time in stream"
         rate = _stream_rate(ih)
+        self._start = start
         self._step, self._ih_start = step, ih_start
-        self.average = average
+        self.average = bool(average)
+        self._sum_dtype = in_dtype
+        out_dtype = in_dtype if average else np.dtype([('data', in_dtype), ('count', int)])
         super().__init__(ih, shape=(n_out,) + tuple(ih.shape[1:]), sample_rate=rate / step,
                          samples_per_frame=samples_per_frame,
-                         start_time=_stream_start(ih) + ih_start / rate, dtype=in_dtype)
+                         start_time=_stream_start(ih) + ih_start / rate, dtype=out_dtype)
+
+    @property
+    def _device_dtype(self):
+        return self._sum_dtype
+
+    def read(self, count=None, out=None):
+        if self.average:
+            return super().read(count, out)
+        if out is not None:
+            raise NotImplementedError("average=False: read() makes its own structured output.")
+        count = self._prepare_read(count, None)
+        sums = super().read(count, np.empty((count,) + tuple(self.sample_shape), self._sum_dtype))
+        result = np.empty(sums.shape, self.dtype)
+        result['data'] = sums
+        result['count'] = self._step
+        return result
+
+    def _repr_item(self, key, default, value=None):
+        # 'step' as given (None = everything), 'start' as given
+        if key == 'step' and self._step == self.ih.shape[0] - self._ih_start and self.shape[0] == 1:
+            return None
+        return super()._repr_item(key, default, value)
 
     def _compute_frames(self, first, last, out):
         a, b = self._frame_span(first, last)
@@ -91,7 +116,7 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
             src._detect(x, n_out, step, out, self.average)
             return
         x = fetch_device(src, self._ih_start + a * step, n_out * step)
-        n_float = _prod(self.sample_shape) * (2 if self.dtype.kind == 'c' else 1)
+        n_float = _prod(self.sample_shape) * (2 if self._sum_dtype.kind == 'c' else 1)
         hip.detect_integrate(x, out, n_out, step, n_float, 2, self.average)
 
     def close(self):
