@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 121
+#define BBT_VERSION 122
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1696,6 +1696,20 @@ extern "C" int bbt_detect_integrate(const void* in_dev, void* out_dev, int64_t n
     else
         hipLaunchKernelGGL((k_detect_integrate<2>), grid, block, 0, st, in_dev, out_dev,
                            (long long)n_out, (long long)step, q, scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bbt_detect_power_axis(const void* in_dev, void* out_dev, int64_t n_out, int64_t step,
+                                     int outer, int inner, int average, bbt_stream stream) {
+    ARG_TRY(in_dev && out_dev, "bbt_detect_power_axis: null argument");
+    ARG_TRY(n_out >= 0 && step >= 1 && outer >= 1 && inner >= 1, "bbt_detect_power_axis: bad sizes");
+    if (n_out == 0) return 0;
+    const long long total = (long long)n_out * outer * inner;
+    ARG_TRY((total + 255) / 256 < (1ll << 31), "bbt_detect_power_axis: too many output elements for one call");
+    hipLaunchKernelGGL(k_power_axis, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)in_dev, (float*)out_dev, (long long)n_out, (long long)step, outer, inner,
+                       average ? 1.0f / (float)step : 1.0f);
     HIP_TRY(hipGetLastError());
     return 0;
 }

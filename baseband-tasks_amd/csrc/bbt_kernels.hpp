@@ -1304,6 +1304,37 @@ __global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in,
         if (r < n_rows) out[r * n_elem + e] = in[(r + off) * n_elem + e];
 }
 
+// Power with the polarization axis anywhere in the sample (reference
+// functions.py:131-143 takes any axis): a complete sample is (outer, 2, inner)
+// complex, X = [:, 0, :], Y = [:, 1, :]; out (n_out, outer, 4, inner) float32 =
+// scale * sum over `step` samples of |X|^2, |Y|^2, Re X conj(Y), Im X conj(Y).
+// One thread per (output sample, outer, inner) position.
+__global__ __launch_bounds__(256) void k_power_axis(const float2* __restrict__ in, float* __restrict__ out,
+                                                    long long n_out, long long step, int outer, int inner,
+                                                    float scale) {
+    const long long per = (long long)outer * inner;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_out * per) return;
+    const long long i = t / per;
+    const int r = (int)(t - i * per);
+    const int o = r / inner, k = r - o * inner;
+    const long long row = 2 * per;                       // complex elements per input sample
+    const float2* src = in + i * step * row + ((long long)o * 2) * inner + k;
+    float xx = 0.f, yy = 0.f, re = 0.f, im = 0.f;
+    for (long long s = 0; s < step; ++s) {
+        const float2 x = src[s * row], y = src[s * row + inner];
+        xx += x.x * x.x + x.y * x.y;
+        yy += y.x * y.x + y.y * y.y;
+        re += x.x * y.x + x.y * y.y;
+        im += x.y * y.x - x.x * y.y;
+    }
+    float* dst = out + (i * outer + o) * 4ll * inner + k;
+    dst[0] = xx * scale;
+    dst[inner] = yy * scale;
+    dst[2 * inner] = re * scale;
+    dst[3 * inner] = im * scale;
+}
+
 // Pitched device-to-device copy: `rows` runs of `wpr` elements of type T (4, 8
 // or 16 bytes), run r from src + r * spitch to dst + r * dpitch (pitches in
 // elements).  hipMemcpy2DAsync moves 8-byte-wide rows -- padding an odd stream

@@ -31,6 +31,10 @@ class _DetectTask(DeviceTaskMixin, TaskBase):
                 hip.square_real(x, tmp)
                 hip.detect_integrate(tmp, out, n_out, step, n_elem, 2, average)
             return
+        inner = getattr(self, '_inner', 1)
+        if self._mode == 1 and inner > 1:        # polarization axis not last
+            hip.detect_power_axis(x, out, n_out, step, n_elem // (2 * inner), inner, average)
+            return
         hip.detect_integrate(x, out, n_out, step, n_elem, self._mode, average)
 
     def _compute_frames(self, first, last, out):
@@ -64,11 +68,12 @@ class Square(_DetectTask):
 class Power(_DetectTask):
     """Powers and cross terms of two polarizations X, Y along the
     polarization axis (2 -> 4): ``|X|^2, |Y|^2, Re(X Y*), Im(X Y*)``, labelled
-    XX, YY, XY, YX (reference functions.py:59-143).  On the GPU the
-    polarization axis must be the last sample axis."""
+    XX, YY, XY, YX (reference functions.py:59-143).  Any sample axis may be
+    the polarization axis; the last one is the fast layout."""
     _mode = 1
 
     def __init__(self, ih, polarization=None):
+        self._polarization_given = polarization
         if polarization is None:
             pol = ih.polarization
             if pol.size != 2:
@@ -89,8 +94,14 @@ class Power(_DetectTask):
             raise ValueError("Power only works on a complex timestream.")
         if np.dtype(ih.dtype) != np.complex64:
             raise TypeError(f"the accelerated Power handles complex64 streams; got {ih.dtype}.")
-        if self._axis != ih.ndim - 1:
-            raise NotImplementedError("the accelerated Power needs the polarization axis to be "
-                                      "the last sample axis.")
+        self._inner = _prod(ih.shape[self._axis + 1:])       # 1: (X, Y) adjacent, the fast layout
         shape = ih.shape[:self._axis] + (4,) + ih.shape[self._axis + 1:]
         super().__init__(ih, shape=shape, polarization=polarization, dtype=np.float32)
+
+    def _repr_item(self, key, default, value=None):
+        # 'polarization' as given: labels taken from the stream are not an argument
+        if key == 'polarization':
+            if self._polarization_given is None:
+                return None
+            value = np.asanyarray(self._polarization_given)
+        return super()._repr_item(key, default, value)

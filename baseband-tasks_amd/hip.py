@@ -50,6 +50,7 @@ SIGNATURES = {
     'bbt_memcpy_d2d': [_vp, _vp, _sz, _vp],
     'bbt_memcpy2d': [_vp, _sz, _vp, _sz, _sz, _sz, _int, _vp],
     'bbt_pad_streams': [_vp, _vp, _i64, _int, _int, _int, _vp],
+    'bbt_detect_power_axis': [_vp, _vp, _i64, _i64, _int, _int, _int, _vp],
     'bbt_stream_create': [_pvp],
     'bbt_stream_destroy': [_vp],
     'bbt_stream_sync': [_vp],
@@ -97,7 +98,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 121
+MIN_LIB_VERSION = 122
 
 _lib = None
 _lock = threading.Lock()
@@ -389,6 +390,12 @@ def detect_integrate(in_dev, out_dev, n_out, step, n_elem, mode, average=True):
     """Square (mode 0) / Power (1) / plain sum (2) over ``step`` samples."""
     check(lib().bbt_detect_integrate(in_dev.ptr, out_dev.ptr, int(n_out), int(step), int(n_elem),
                                      int(mode), int(bool(average)), _stream))
+
+
+def detect_power_axis(in_dev, out_dev, n_out, step, outer, inner, average=True):
+    """Power (mode 1 of `detect_integrate`) for samples (outer, 2, inner)."""
+    check(lib().bbt_detect_power_axis(in_dev.ptr, out_dev.ptr, int(n_out), int(step), int(outer), int(inner),
+                                      int(bool(average)), _stream))
 
 
 def real_to_complex(x):

@@ -109,7 +109,8 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
             # a channelizer on top of an overlap-save task detects and sums in
             # that task's last pass: neither stream is ever stored
             fused = getattr(src.ih, '_compute_detected', None)
-            if (fused is not None and not src._real and not getattr(src.ih, 'closed', False)
+            if (fused is not None and not src._real and getattr(src, '_inner', 1) == 1
+                    and not getattr(src.ih, 'closed', False)
                     and fused(self._ih_start + a * step, n_out, step, src._mode, self.average, out)):
                 return
             x = fetch_device(src.ih, self._ih_start + a * step, n_out * step)

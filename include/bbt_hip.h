@@ -249,6 +249,11 @@ int bbt_pfb_execute(bbt_pfb_plan* plan, const void* in_dev, void* out_dev, int64
  *   mode 2  f = identity on float32 elements: in (n_out*step, n_elem) float32 */
 int bbt_detect_integrate(const void* in_dev, void* out_dev, int64_t n_out, int64_t step,
                          int64_t n_elem, int mode, int average, bbt_stream stream);
+/* Mode 1 with the polarization axis anywhere in the sample (Power takes any
+ * axis, functions.py:131-143): in (n_out*step, outer, 2, inner) complex64, X =
+ * [.., 0, :], Y = [.., 1, :]; out (n_out, outer, 4, inner) float32. */
+int bbt_detect_power_axis(const void* in_dev, void* out_dev, int64_t n_out, int64_t step, int outer,
+                          int inner, int average, bbt_stream stream);
 
 /* ---- integer sample shifts -------------------------------------------------
  * Replaces ShiftSamples.task (sampling.py:424-425, data[self._indices]), the
