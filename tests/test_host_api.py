@@ -437,3 +437,27 @@ def test_repr_lists_the_non_default_constructor_arguments():
     sr = repr(bt.SetAttribute(nh, frequency=1e9, sideband=1))
     assert 'frequency=1000000000.0' in sr and 'sideband=1' in sr and 'sample_rate' not in sr.split('\nih:')[0]
     assert repr(nh).startswith('NoiseGenerator(shape=(16384, 2),\n               start_time=2020-01-01T00:00:00')
+
+
+@pytest.mark.parametrize('n,samples_per_frame,fast,ih_spf,spf', [
+    (3, None, False, 20000, 19998), (3, None, True, 20000, 19998), (3, 128, False, 130, 128),
+    (3, 128, True, 135, 133), (5, 128, True, 135, 131)])
+def test_padded_frames_table_of_the_reference(n, samples_per_frame, fast, ih_spf, spf):
+    """Reference tests/test_base.py:519-535: an n-sample box filter over a
+    (40000, 8) stream with 20000-sample frames -- input and output frame sizes
+    with and without rounding up to a fast FFT length (135 = 3^3 * 5) -- and
+    511-518: shape, start time and values from either end."""
+    data = np.random.default_rng(4).choice(np.array([-3., -1., 1., 3.], np.float32), size=(40000, 8))
+    fh = bt.StreamGenerator(lambda f: data[f.tell():f.tell() + f.samples_per_frame], data.shape,
+                            '2014-06-16T05:56:07', 32 * u.MHz, samples_per_frame=20000, dtype=np.float32)
+    hat = _HostPadded(fh, n - 1, 0, samples_per_frame=samples_per_frame,
+                      next_fast_len=orc.next_fast_len if fast else None)
+    assert hat._ih_samples_per_frame == ih_spf and hat.samples_per_frame == spf
+    assert hat.sample_rate == fh.sample_rate and hat.shape == (40000 - n + 1, 8)
+    assert abs((hat.start_time - fh.start_time) - (n - 1) / fh.sample_rate) < 1e-9
+    box = sum(data[k:40000 - (n - 1) + k] for k in range(n))
+    assert np.array_equal(hat.read(10), box[:10])
+    hat.seek(-10, 2)
+    assert np.array_equal(hat.read(10), box[-10:])
+    hat.close()
+    assert hat.closed
