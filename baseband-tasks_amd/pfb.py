@@ -30,6 +30,36 @@ class _PaddedSource(PaddedTaskBase):
         return self._owner.ppf(data)
 
 
+class _FewChannelPfbPlan:
+    """The filter bank for n < 256 channels (GUPPI's 12 x 64, reference
+    tests/test_pfb.py:33-35), with the interface of `hip.PfbPlan`: seen as
+    ``(blocks, n * S)`` the stream is n * S streams of blocks, the polyphase sum
+    is an ``n_tap``-tap filter along the block axis with its own taps per phase
+    (`hip.FirPlan`, the direct filter kernel), and the channelizer transform
+    follows (`hip.ChanPlan`, the short-transform kernel)."""
+
+    def __init__(self, response, n_stream):
+        response = np.asarray(response, dtype=np.float64)
+        self.n_tap, self.n_chan = response.shape
+        self.n_stream = int(n_stream)
+        # out[i] = sum_t x[i + t] h[t]  ==  FirPlan's sum_k r[k] x[i + n_tap - 1 - k] with r = h reversed
+        taps = np.repeat(response[::-1], self.n_stream, axis=1)          # (n_tap, n * S), streams innermost
+        self._fir = hip.FirPlan(np.ascontiguousarray(taps, dtype=np.complex64))
+        self._fft = hip.ChanPlan(self.n_chan, self.n_stream, -1)
+
+    def execute(self, in_dev, out_dev, n_spectra):
+        n, s = self.n_chan, self.n_stream
+        rows = n_spectra + self.n_tap - 1
+        blocks = hip.DeviceArray((rows, n * s), np.complex64, ptr=in_dev.ptr, owner=in_dev)
+        summed = hip.DeviceArray((n_spectra, n * s), np.complex64)
+        self._fir.execute(blocks, summed, n_spectra)
+        self._fft.execute(summed.reshape(n_spectra * n, s), out_dev, n_spectra)
+
+    def close(self):
+        self._fir.close()
+        self._fft.close()
+
+
 class PolyphaseFilterBank(_RowFFTTask):
     """Channelize with a polyphase filter: spectrum ``i`` is the FFT over ``c``
     of ``sum_t x[(i + t) n + c] * response[t, c]`` (the definition in
@@ -62,7 +92,7 @@ class PolyphaseFilterBank(_RowFFTTask):
     def __init__(self, ih, response, samples_per_frame=None, frequency=None, sideband=None):
         response = np.asanyarray(response)
         n_tap, n = response.shape
-        _check_n(n, minimum=256)
+        _check_n(n, minimum=256 if n >= 256 else 2)      # fewer channels: filter + short transforms
         if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
             raise TypeError("the accelerated filter bank handles complex64 and float32 streams; "
                             f"got {ih.dtype} (wrap the stream in SinglePrecision(...)).")
@@ -96,10 +126,12 @@ class PolyphaseFilterBank(_RowFFTTask):
 
     def _get_plan(self):
         if self._plan is None:
-            self._plan = hip.PfbPlan(self._response, self._n_stream_even)
+            self._plan = self._make_plan(self._n_stream_even)
         return self._plan
 
     def _make_plan(self, n_stream_even):
+        if self._n < 256:
+            return _FewChannelPfbPlan(self._response, n_stream_even)
         return hip.PfbPlan(self._response, n_stream_even)
 
     def _compute_frames(self, first, last, out):
@@ -198,7 +230,9 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
 
     On the GPU this is the overlap-save spectral-multiply plan run along the
     block axis with ``n * prod(sample_shape)`` streams (one response column per
-    polyphase phase); complex output only.
+    polyphase phase); a real-valued output (``dtype`` float32, for the half
+    spectra of a real stream's filter bank) goes through the same plan with zero
+    imaginary parts -- the Wiener filter of real taps is Hermitian.
 
     Parameters
     ----------
@@ -218,9 +252,13 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
                  frequency=None, sideband=None, dtype=None):
         response = np.asanyarray(response)
         n_tap, n = response.shape
-        if dtype is not None and np.dtype(dtype) != np.complex64:
-            raise NotImplementedError("the accelerated inverse filter bank produces complex64.")
-        self.dechannelized = Dechannelize(ih, n=n, frequency=frequency, sideband=sideband)
+        dtype = np.dtype(np.complex64 if dtype is None else dtype)
+        if dtype.kind == 'f' and dtype.itemsize == 8 or dtype.kind == 'c' and dtype.itemsize == 16:
+            dtype = np.dtype(np.float32 if dtype.kind == 'f' else np.complex64)     # computed in single precision
+        if dtype not in (np.dtype(np.complex64), np.dtype(np.float32)):
+            raise TypeError("the accelerated inverse filter bank produces complex64 or float32.")
+        self._real = dtype.kind == 'f'
+        self.dechannelized = Dechannelize(ih, n=n, frequency=frequency, sideband=sideband, dtype=dtype)
         self._response = response
         self._n = n
         pad_minimum = (n_tap - 1) * n
@@ -237,8 +275,11 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         self._ft_inverse_cache = None
 
     def next_fast_len(self, m):
-        """A block count the engine transforms (power of two >= 256) times n."""
-        return max(self._FFT.next_fast_len(m), 256 * self._n)
+        """A fast length that is a whole number of blocks of n samples (reference
+        pfb.py:236-241), the number of blocks itself being a length the engine
+        transforms (the transform here runs along the block axis)."""
+        blocks = -(-self._FFT.next_fast_len(m) // self._n)
+        return self._FFT.next_fast_len(blocks) * self._n
 
     @property
     def _ft_inverse_response(self):
@@ -277,10 +318,14 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         tmp_off = np.concatenate([[0], np.cumsum(n_blk)[:-1]])
         in0 = int(starts[0])
         x = fetch_device(self.dechannelized, in0, int(starts[-1]) + n_in - in0)
+        if self._real:
+            x = hip.real_to_complex(x)
         x = x.reshape(x.shape[0] // n, n * s)
         tmp = hip.DeviceArray((int(n_blk.sum()), n * s), np.complex64)
         plan.execute(x, tmp, (starts - in0) // n, tmp_off, keep // n, n_blk)
         tmp = tmp.reshape(int(n_blk.sum()) * n, s)
+        if self._real:
+            tmp = hip.real_part(tmp)
         flat = out.reshape(out.shape[0], s)
         base = first * spf
         for m, t0, cnt in zip(frames, tmp_off, counts):
@@ -302,7 +347,8 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         tmp = hip.DeviceArray((n_blk, n * s), np.complex64)
         plan.execute(x, tmp, [0], [0], [keep // n], [n_blk])
         res = tmp.to_host().reshape((n_blk * n,) + tuple(self.sample_shape))
-        return np.ascontiguousarray(res[off:off + spf])
+        res = res[off:off + spf]
+        return np.ascontiguousarray(res.real if self._real else res)
 
     def close(self):
         super().close()

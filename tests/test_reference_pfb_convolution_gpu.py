@@ -5,10 +5,9 @@ test_convolution.py:42-98; same streams, seeds, responses and expectations).
 The reference runs these on float64 / complex128 noise; the kernels compute in
 single precision, so the double-precision streams pass through
 `SinglePrecision` and the comparisons use float32 tolerances (stated at each
-assertion).  The inversion tests of test_pfb.py (104-236) need a real-valued
-output of InversePolyphaseFilterBank and 64-channel filter banks, which the
-accelerated classes do not offer (complex64 output, 256..4096 channels): the
-inverse is pinned by the golden vector `sm_ipfb` instead (test_gpu_parity.py).
+assertion).  The inversion tests (test_pfb.py:104-236, CHIME's 4 x 2048 and
+GUPPI's 12 x 64 filter banks on real noise, with and without digitization) are
+at the end.
 """
 import numpy as np
 import pytest
@@ -112,3 +111,106 @@ class TestSmoothingFilter:
         assert task.tell() == task.shape[0] - 3
         tail = task.read()
         assert tail.shape[0] == 3 and np.allclose(tail, self.box[-3:], atol=1e-4)
+
+
+# ------------------------------------------------------------------ test_pfb.py:104-236
+def digitize(spectra, level):
+    """Round real and imaginary parts to multiples of ``level`` (test_pfb.py:22-23)."""
+    flat = np.ascontiguousarray(spectra)
+    return (np.round(flat.view(flat.real.dtype) / level) * level).view(flat.dtype)
+
+
+class TestInversion:
+    """Undoing CHIME's 4 x 2048 and GUPPI's 12 x 64 filter banks on real noise
+    (test_pfb.py:104-236).  The reference runs these in float64; here the noise
+    is the same (same generator and seed) but cast to float32 and every
+    transform is single precision, which the tolerances -- set by the
+    deconvolution, not by rounding -- absorb."""
+
+    @classmethod
+    def setup_class(cls):
+        nh = bt.NoiseGenerator(shape=(2500 * N_CHAN,), start_time=bt.Time('2010-01-01T00:00:00'),
+                               sample_rate=1. * u.kHz, seed=12345, samples_per_frame=128, dtype='f8')
+        cls.nh = bt.SinglePrecision(nh)
+        cls.chime = bt.sinc_hamming(4, 2048)
+        cls.guppi = bt.sinc_hamming(12, 64, sinc_scale=0.95)
+
+    def input_blocks(self, first_sample, n_blocks, n):
+        self.nh.seek(first_sample)
+        return self.nh.read(n_blocks * n).reshape(-1, n).astype(np.float64)
+
+    def test_by_hand_with_and_without_wiener_filter(self):
+        """test_pfb.py:104-133: dechannelize the filter bank output, divide by the
+        response's transform along the block axis; the band edges (the middle
+        of each 2048-sample block) cannot be recovered, a Wiener filter with
+        threshold 0.05 tames them."""
+        n_sample = 128
+        d_in = self.input_blocks(3 * 2048, n_sample, 2048)
+        pfb = bt.PolyphaseFilterBank(self.nh, self.chime, samples_per_frame=n_sample)
+        ft_pfb = pfb.read(n_sample + 3).astype(np.complex128)
+        d_pfb = np.fft.irfft(ft_pfb, axis=1)
+        ft_fine = np.fft.rfft(d_pfb, axis=0)
+        long_response = np.zeros((n_sample + 3, 2048))
+        long_response[:4] = self.chime
+        ft_resp = np.fft.rfft(long_response, axis=0).conj()
+        d_out = np.fft.irfft(ft_fine / ft_resp, axis=0, n=d_pfb.shape[0])[3:]
+        assert np.allclose(d_in[32:-32, :900], d_out[32:-32, :900], atol=0.001)
+        assert np.allclose(d_in[32:-32, 1150:], d_out[32:-32, 1150:], atol=0.001)
+        threshold = 0.05
+        inverse = ft_resp.conj() / (threshold ** 2 + np.abs(ft_resp) ** 2) * (1 + threshold ** 2)
+        d_out2 = np.fft.irfft(ft_fine * inverse, axis=0, n=d_pfb.shape[0])[3:]
+        assert np.allclose(d_in[32:-32], d_out2[32:-32], atol=0.3)
+
+    def test_chime_filter_bank_inverted(self):
+        """test_pfb.py:170-183: sn = 100, 48 blocks of padding; all but the 50
+        samples at either edge of each block to 0.01."""
+        n_sample, pad = 128, 48
+        d_in = self.input_blocks(pad * 2048 + 3 * 2048 // 2, n_sample, 2048)
+        pfb = bt.PolyphaseFilterBank(self.nh, self.chime)
+        ipfb = bt.InversePolyphaseFilterBank(pfb, self.chime, sn=100, pad_start=pad, pad_end=pad,
+                                             samples_per_frame=n_sample * 2048, dtype=self.nh.dtype)
+        d_out = ipfb.read(n_sample * 2048).reshape(-1, 2048)
+        assert d_out.dtype == np.float32
+        assert np.allclose(d_in[:, 50:-50], d_out[:, 50:-50], atol=0.01)
+
+    def test_chime_filter_bank_inverted_after_digitization(self):
+        """test_pfb.py:185-202: spectra rounded at a third of their rms, sn = 10:
+        residual rms 0.125 +- 0.01, everything within 1.1."""
+        n_sample, pad = 128, 32
+        d_in = self.input_blocks(pad * 2048 + 3 * 2048 // 2, n_sample, 2048)
+        pfb = bt.PolyphaseFilterBank(self.nh, self.chime)
+        level = pfb.read(n_sample).real.std() / 3.
+        rounded = bt.Task(pfb, lambda ft: digitize(ft, level), samples_per_frame=n_sample)
+        ipfb = bt.InversePolyphaseFilterBank(rounded, self.chime, sn=10, pad_start=pad, pad_end=pad,
+                                             samples_per_frame=n_sample * 2048, dtype=self.nh.dtype)
+        d_out = ipfb.read(n_sample * 2048).reshape(-1, 2048)
+        assert np.isclose((d_out - d_in).std(), 0.125, atol=0.01)
+        assert np.allclose(d_in, d_out, atol=1.1)
+
+    def test_guppi_filter_bank_inverted(self):
+        """test_pfb.py:204-222: 12 x 64 with sinc scale 0.95 cuts the channel edges so
+        hard that sn = 30 only gives 0.15; without regularisation all but the
+        two samples at either edge of each block come back to 0.005."""
+        n_sample, pad = 512, 128
+        d_in = self.input_blocks(pad * 64 + 11 * 64 // 2, n_sample, 64)
+        pfb = bt.PolyphaseFilterBank(self.nh, self.guppi)
+        ipfb = bt.InversePolyphaseFilterBank(pfb, self.guppi, sn=30, pad_start=pad, pad_end=pad,
+                                             samples_per_frame=n_sample * 64, dtype=self.nh.dtype)
+        d_out = ipfb.read(n_sample * 64).reshape(-1, 64)
+        assert np.allclose(d_in, d_out, atol=0.15)
+        ipfb2 = bt.InversePolyphaseFilterBank(pfb, self.guppi, sn=1e9, pad_start=pad, pad_end=pad,
+                                              samples_per_frame=n_sample * 64, dtype=self.nh.dtype)
+        d_out2 = ipfb2.read(n_sample * 64).reshape(-1, 64)
+        assert np.allclose(d_in[:, 2:-2], d_out2[:, 2:-2], atol=0.005)
+
+    def test_guppi_filter_bank_inverted_after_digitization(self):
+        """test_pfb.py:224-236: rounding at a thirtieth of the rms hardly matters."""
+        n_sample, pad = 512, 128
+        d_in = self.input_blocks(pad * 64 + 11 * 64 // 2, n_sample, 64)
+        pfb = bt.PolyphaseFilterBank(self.nh, self.guppi)
+        level = pfb.read(n_sample).real.std() / 30.
+        rounded = bt.Task(pfb, lambda ft: digitize(ft, level), samples_per_frame=n_sample)
+        ipfb = bt.InversePolyphaseFilterBank(rounded, self.guppi, sn=30, pad_start=pad, pad_end=pad,
+                                             samples_per_frame=n_sample * 64, dtype=self.nh.dtype)
+        d_out = ipfb.read(n_sample * 64).reshape(-1, 64)
+        assert np.allclose(d_in, d_out, atol=0.15)
