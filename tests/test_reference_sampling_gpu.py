@@ -8,9 +8,8 @@ every fourth sample of the fast one.  In this package plain numbers are
 samples and absolute times are `Time` objects (there are no unit quantities
 without astropy), so the reference's offsets given as durations appear here as
 the equivalent number of samples.  The receiver-chain simulations of
-test_sampling.py:264-620 (mixing, low-pass filtering, `Stack`) are not
-restated; `TimeDelay` and `ShiftAndResample(..., lo=...)` are pinned by the
-golden vectors `st_delay` / `sr_*` instead (test_gpu_parity.py).
+test_sampling.py:264-620 (`TimeDelay`, `ShiftAndResample(..., lo=...)`) are in
+test_reference_delay_gpu.py.
 """
 import numpy as np
 import pytest
