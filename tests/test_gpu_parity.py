@@ -2011,6 +2011,19 @@ def test_one_stream_through_the_filter_bank(n_tap, n_chan):
         assert_parity(pfb.read(), want.astype(np.complex64), f'two real streams {n_tap} x {n_chan}')
 
 
+def test_streams_with_more_than_2_31_elements():
+    """Index arithmetic beyond 32 bits (tools/large_index_check.py: a 17 GB stream through Channelize,
+    Dedisperse, the fused pair and Power+Integrate, highest indices compared with numpy).  In its own
+    process: the stream is made with torch, which has to initialise the GPU before this library does."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, os.path.join(root, 'tools', 'large_index_check.py')], capture_output=True,
+                          text=True, timeout=900)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert 'large index check ok' in done.stdout
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
