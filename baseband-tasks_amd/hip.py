@@ -3,7 +3,9 @@ helpers.  There is deliberately NO fallback: if the library is missing or a
 call fails, an exception is raised.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -104,12 +106,45 @@ _lib = None
 _lock = threading.Lock()
 
 
+_torch_lib_dir = None      # set when PyTorch's bundled ROCm runtime was preloaded
+
+
+def _preload_torch_runtime(name='libamdhip64.so'):
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 / libhsa-runtime64 / librccl; libbbt_hip.so is linked against
+    the system's.  If this library is loaded first it pulls in the system
+    runtime, and a later ``import torch`` brings a second one that finds no GPU
+    ("No HIP GPUs are available", measured on the MI355X box).  So when torch is
+    installed but not imported yet, its copy is loaded first, globally: this
+    library and torch then share it whatever the import order (the same sonames;
+    it is what `bench.py`, which imports torch first, runs on anyway).
+    BBT_HIP_RUNTIME=system skips this."""
+    global _torch_lib_dir
+    if os.environ.get('BBT_HIP_RUNTIME', '') == 'system':
+        return
+    if _torch_lib_dir is None:
+        if 'torch' in sys.modules and name == 'libamdhip64.so':
+            return                       # already in the process
+        try:
+            spec = importlib.util.find_spec('torch')
+        except (ImportError, ValueError):
+            spec = None
+        where = list(getattr(spec, 'submodule_search_locations', None) or [])
+        if not where or not os.path.exists(os.path.join(where[0], 'lib', 'libamdhip64.so')):
+            return
+        _torch_lib_dir = os.path.join(where[0], 'lib')
+    path = os.path.join(_torch_lib_dir, name)
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library (loads on first use; raises if it is not built)."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
+                _preload_torch_runtime()
                 if not os.path.exists(LIB_PATH):
                     raise HipLibraryMissing(
                         f"{LIB_PATH} not found: build it with "
@@ -646,6 +681,9 @@ COMM_ID_BYTES = 128
 
 def comm_unique_id():
     """The id rank 0 creates and hands to the other ranks (bytes)."""
+    lib()
+    if _torch_lib_dir is not None:
+        _preload_torch_runtime('librccl.so')         # the RCCL that goes with the preloaded runtime
     buf = C.create_string_buffer(COMM_ID_BYTES)
     check(lib().bbt_comm_unique_id(buf, COMM_ID_BYTES))
     return buf.raw
@@ -659,6 +697,9 @@ class Comm(_Plan):
     def __init__(self, n_ranks, rank, uid):
         super().__init__()
         self.n_ranks, self.rank = int(n_ranks), int(rank)
+        lib()
+        if _torch_lib_dir is not None:
+            _preload_torch_runtime('librccl.so')
         uid = bytes(uid)
         check(lib().bbt_comm_init(C.byref(self._h), self.n_ranks, self.rank, uid, len(uid)))
 

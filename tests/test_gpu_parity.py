@@ -2024,6 +2024,36 @@ def test_streams_with_more_than_2_31_elements():
     assert 'large index check ok' in done.stdout
 
 
+def test_this_library_and_torch_share_one_hip_runtime_in_either_import_order():
+    """PyTorch bundles its own ROCm runtime; two runtimes in one process leave the
+    second without a GPU ("No HIP GPUs are available" when this library came
+    first).  hip.lib() therefore loads torch's copy first when torch is installed:
+    both orders work, and only one libamdhip64 is mapped."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = '''
+import sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch-first":
+    import torch
+    t = torch.ones(4, device="cuda")
+import baseband_tasks_amd as bt
+a = bt.hip.DeviceArray.from_host(__import__("numpy").arange(4, dtype="float32"))
+if order == "lib-first":
+    import torch
+    t = torch.ones(4, device="cuda")
+assert float(t.sum()) == 4. and a.to_host().sum() == 6.
+maps = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+assert len(maps) == 1, maps
+print("one runtime:", maps[0])
+''' % root
+    for order in ('lib-first', 'torch-first'):
+        done = subprocess.run([sys.executable, '-c', script, order], capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0 and 'one runtime:' in done.stdout, (order, done.stdout[-500:], done.stderr[-1500:])
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each
