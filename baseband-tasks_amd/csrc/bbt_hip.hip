@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 122
+#define BBT_VERSION 123
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1920,9 +1920,18 @@ extern "C" int bbt_fir_execute(bbt_fir_plan* p, const void* in_dev, void* out_de
 
 // ---------------------------------------------------------------------------
 // sampler frames -> float32 / complex64 (k_unpack)
+extern "C" int bbt_unpack_masked(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
+                                 int header_bytes, int bits, int samples_per_frame, int n_thread,
+                                 int n_elem, int code, const void* valid_dev, bbt_stream stream);
 extern "C" int bbt_unpack(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
                           int header_bytes, int bits, int samples_per_frame, int n_thread,
                           int n_elem, int code, bbt_stream stream) {
+    return bbt_unpack_masked(raw_dev, out_dev, n_frames, frame_bytes, header_bytes, bits,
+                             samples_per_frame, n_thread, n_elem, code, nullptr, stream);
+}
+extern "C" int bbt_unpack_masked(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
+                                 int header_bytes, int bits, int samples_per_frame, int n_thread,
+                                 int n_elem, int code, const void* valid_dev, bbt_stream stream) {
     ARG_TRY(raw_dev && out_dev, "bbt_unpack: null argument");
     ARG_TRY(n_frames >= 0 && n_thread >= 1 && n_frames % n_thread == 0,
             "bbt_unpack: %lld frames are not whole sets of %d threads", (long long)n_frames, n_thread);
@@ -1950,7 +1959,7 @@ extern "C" int bbt_unpack(const void* raw_dev, void* out_dev, int64_t n_frames, 
 #define BBT_UNPACK(G_)                                                                           \
     hipLaunchKernelGGL((k_unpack<G_>), grid, dim3(256), 0, (hipStream_t)stream,                  \
                        (const unsigned char*)raw_dev, (float*)out_dev, frame_bytes, header_bytes, \
-                       bits, samples_per_frame, n_thread, n_elem, code)
+                       bits, samples_per_frame, n_thread, n_elem, code, (const unsigned char*)valid_dev)
     if (g == 4) BBT_UNPACK(4);
     else if (g == 2) BBT_UNPACK(2);
     else BBT_UNPACK(1);

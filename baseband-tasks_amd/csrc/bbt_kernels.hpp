@@ -1586,12 +1586,17 @@ __device__ __forceinline__ float unpack_level(unsigned v, int bits, int code) {
     return (float)v - (float)(1u << (bits - 1));
 }
 #define BBT_UNPACK_ITER 4     // groups of G components per thread
+// `valid` (optional): one byte per frame; frames flagged 0 (invalid or missing in
+// the file: their bytes are whatever the host put there) are written as zeros,
+// the fill value of `baseband`'s readers.
 template <int G>
 __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict__ raw,
                                                 float* __restrict__ out, int frame_bytes,
                                                 int header_bytes, int bits, int spf, int n_thread,
-                                                int E, int code) {
+                                                int E, int code,
+                                                const unsigned char* __restrict__ valid) {
     const unsigned frame = blockIdx.x;
+    const bool good = valid == nullptr || valid[frame] != 0;
     const unsigned set = frame / (unsigned)n_thread, thr = frame - set * (unsigned)n_thread;
     const unsigned* payload =
         reinterpret_cast<const unsigned*>(raw + (long long)frame * frame_bytes + header_bytes);
@@ -1609,7 +1614,8 @@ __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict_
         w >>= (bit & 31);
         float x[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) x[g] = unpack_level((unsigned)(w >> (g * bits)) & mask, bits, code);
+        for (int g = 0; g < G; ++g)
+            x[g] = good ? unpack_level((unsigned)(w >> (g * bits)) & mask, bits, code) : 0.f;
         float* dst = frame_out + (long long)t * n_thread * E + e;
         if (G == 4) {
             *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[G > 1 ? 1 : 0], x[G > 2 ? 2 : 0], x[G - 1]);

@@ -92,6 +92,7 @@ SIGNATURES = {
     'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
     'bbt_scale_streams': [_vp, _vp, _i64, _int, _vp, _vp],
     'bbt_unpack': [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp],
+    'bbt_unpack_masked': [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp],
     'bbt_comm_unique_id': [_vp, _sz],
     'bbt_comm_init': [_pvp, _int, _int, _vp, _sz],
     'bbt_comm_destroy': [_vp],
@@ -100,7 +101,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 122
+MIN_LIB_VERSION = 123
 
 _lib = None
 _lock = threading.Lock()

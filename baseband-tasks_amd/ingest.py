@@ -41,7 +41,7 @@ class RawFrameStream(DeviceTaskMixin, Base):
 
     def __init__(self, raw, *, frame_nbytes, header_nbytes, samples_per_frame, bits, n_chan=1,
                  n_thread=1, complex_data=False, code=0, start_time, sample_rate, squeeze=True,
-                 sample_shape=None, first_byte=0, **kwargs):
+                 sample_shape=None, first_byte=0, frame_map=None, **kwargs):
         raw = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8)
         self._raw = raw[first_byte:]
         self._frame_nbytes = operator.index(frame_nbytes)
@@ -49,7 +49,14 @@ class RawFrameStream(DeviceTaskMixin, Base):
         self._bits, self._code = operator.index(bits), operator.index(code)
         self._n_chan, self._n_thread = operator.index(n_chan), operator.index(n_thread)
         self._n_elem = self._n_chan * (2 if complex_data else 1)
-        n_sets = self._raw.shape[0] // (self._frame_nbytes * self._n_thread)
+        # frame_map[set, thread] = index of that frame in ``raw``, -1 where the file has none
+        # (or only an invalid one): those samples read as 0.  None: frames in order, all valid.
+        self._frame_map = None if frame_map is None else np.ascontiguousarray(frame_map, dtype=np.int64)
+        if self._frame_map is not None:
+            assert self._frame_map.ndim == 2 and self._frame_map.shape[1] == self._n_thread
+            n_sets = self._frame_map.shape[0]
+        else:
+            n_sets = self._raw.shape[0] // (self._frame_nbytes * self._n_thread)
         if n_sets < 1:
             raise ValueError("the buffer holds less than one complete frame set.")
         if sample_shape is None:
@@ -66,12 +73,25 @@ class RawFrameStream(DeviceTaskMixin, Base):
 
     def _compute_frames(self, first, last, out):
         nb = self._frame_nbytes * self._n_thread
-        chunk = np.ascontiguousarray(self._raw[first * nb:last * nb])
+        valid_dev = None
+        if self._frame_map is None:
+            chunk = np.ascontiguousarray(self._raw[first * nb:last * nb])
+        else:
+            # gather the frames of these sets in (set, thread) order; absent ones stay zero bytes
+            index = self._frame_map[first:last].ravel()
+            present = index >= 0
+            frames = self._raw[:(self._raw.shape[0] // self._frame_nbytes) * self._frame_nbytes]
+            frames = frames.reshape(-1, self._frame_nbytes)
+            chunk = np.zeros((index.shape[0], self._frame_nbytes), np.uint8)
+            chunk[present] = frames[index[present]]
+            if not present.all():
+                valid_dev = hip.DeviceArray.from_host(present.astype(np.uint8))
         raw_dev = hip.DeviceArray.from_host(chunk)
-        hip.check(hip.lib().bbt_unpack(raw_dev.ptr, out.ptr, (last - first) * self._n_thread,
-                                       self._frame_nbytes, self._header_nbytes, self._bits,
-                                       self.samples_per_frame, self._n_thread, self._n_elem, self._code,
-                                       hip.get_stream()))
+        hip.check(hip.lib().bbt_unpack_masked(raw_dev.ptr, out.ptr, (last - first) * self._n_thread,
+                                              self._frame_nbytes, self._header_nbytes, self._bits,
+                                              self.samples_per_frame, self._n_thread, self._n_elem,
+                                              self._code, valid_dev.ptr if valid_dev is not None else None,
+                                              hip.get_stream()))
 
     def close(self):
         super().close()
@@ -104,8 +124,14 @@ def _epoch_time(ref_epoch, seconds):
 
 
 def open_vdif(raw, sample_rate=None, **kwargs):
-    """`RawFrameStream` for a VDIF file / buffer whose frames are all valid,
-    equally long and ordered thread 0 .. n_thread-1 within every frame set.
+    """`RawFrameStream` for a VDIF file / buffer of equally long frames.
+
+    Every header is read: frames are put in time order by (seconds, frame
+    number) and in thread order by thread id, whatever their order in the file;
+    frames flagged invalid, and (set, thread) slots the file has no frame for,
+    read as zeros (the fill value of `baseband`'s VDIF reader); of duplicates the
+    first one counts.  A file that is complete and in order is read without the
+    indirection.
 
     ``sample_rate`` (Hz, per channel; complex samples count once) is taken
     from an EDV 1 / 3 header if not given, else from the number of frames per
@@ -120,15 +146,18 @@ def open_vdif(raw, sample_rate=None, **kwargs):
     if nb <= h0['header_nbytes'] or buf.shape[0] < nb:
         raise ValueError("not a VDIF stream: bad frame length in the first header.")
     n_frames = buf.shape[0] // nb
-    heads = buf[:n_frames * nb].reshape(n_frames, nb)[:, :32].copy().view('<u4')
-    fields = [vdif_header(hw) for hw in heads[:min(n_frames, 4096)]]
-    thread_ids = [f['thread_id'] for f in fields]
-    n_thread = len(set(thread_ids))
-    for i, f in enumerate(fields):
-        if f['invalid'] or f['frame_nbytes'] != nb or f['bits'] != h0['bits'] or \
-                f['thread_id'] != thread_ids[i % n_thread]:
-            raise ValueError(f"frame {i}: invalid, of another length, or out of thread order; "
-                             "such files need the host reader.")
+    heads = buf[:n_frames * nb].reshape(n_frames, nb)[:, :16].copy().view('<u4').astype(np.int64)
+    invalid = (heads[:, 0] >> 31) & 1
+    secs = heads[:, 0] & 0x3fffffff
+    frame_nr = heads[:, 1] & 0xffffff
+    length = (heads[:, 2] & 0xffffff) * 8
+    bits = ((heads[:, 3] >> 26) & 0x1f) + 1
+    thread_id = (heads[:, 3] >> 16) & 0x3ff
+    usable = (invalid == 0)
+    if np.any((length != nb) | (bits != h0['bits'])):
+        raise ValueError("frames of different lengths or sample sizes in one VDIF stream are not supported.")
+    if not usable.any():
+        raise ValueError("no valid frame in the buffer.")
     payload_bits = (nb - h0['header_nbytes']) * 8
     ncomp = 2 if h0['complex_data'] else 1
     spf = payload_bits // (h0['bits'] * h0['n_chan'] * ncomp)
@@ -136,18 +165,33 @@ def open_vdif(raw, sample_rate=None, **kwargs):
         sample_rate = h0['sample_rate']
     if sample_rate is None:
         # frames per second: highest frame number seen in a second that is complete
-        frame_nr = (heads[:, 1] & 0xffffff).astype(np.int64)
-        secs = (heads[:, 0] & 0x3fffffff).astype(np.int64)
         complete = secs < secs.max()
         if not complete.any():
             raise ValueError("cannot infer the sample rate from less than a second of frames; "
                              "pass sample_rate.")
         sample_rate = float((frame_nr[complete].max() + 1) * spf)
-    start = _epoch_time(h0['ref_epoch'], h0['seconds']) + h0['frame_nr'] * spf / u.to_hz(sample_rate)
+    rate = u.to_hz(sample_rate)
+    fps = int(round(rate / spf))
+    # position of every frame: frame set (time) and thread
+    threads = np.unique(thread_id[usable])
+    n_thread = threads.shape[0]
+    when = secs * fps + frame_nr
+    first = when[usable].min()
+    which_set = when - first
+    which_thread = np.searchsorted(threads, thread_id)
+    n_sets = int(which_set[usable].max()) + 1
+    frame_map = np.full((n_sets, n_thread), -1, np.int64)
+    take = usable & (which_set >= 0)
+    # later duplicates must not overwrite earlier ones: assign in reverse file order
+    order = np.nonzero(take)[0][::-1]
+    frame_map[which_set[order], which_thread[order]] = order
+    in_order = n_sets * n_thread == n_frames and np.array_equal(frame_map.ravel(), np.arange(n_frames))
+    start = _epoch_time(h0['ref_epoch'], int(first // fps)) + int(first % fps) * spf / rate
     return RawFrameStream(buf[:n_frames * nb], frame_nbytes=nb, header_nbytes=h0['header_nbytes'],
                           samples_per_frame=spf, bits=h0['bits'], n_chan=h0['n_chan'],
                           n_thread=n_thread, complex_data=h0['complex_data'], code=0,
-                          start_time=start, sample_rate=sample_rate, **kwargs)
+                          start_time=start, sample_rate=sample_rate,
+                          frame_map=None if in_order else frame_map, **kwargs)
 
 
 def encode_vdif_frames(data, bits, *, seconds=0, ref_epoch=40, frame_nr0=0, frames_per_second=None,

@@ -323,6 +323,13 @@ int bbt_fir_execute(bbt_fir_plan* plan, const void* in_dev, void* out_dev, int64
 int bbt_unpack(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
                int header_bytes, int bits, int samples_per_frame, int n_thread, int n_elem,
                int code, bbt_stream stream);
+/* The same with one byte per frame in valid_dev (device; NULL = all valid): frames
+ * flagged 0 -- invalid in their header, or missing from the file and put in by
+ * the host as padding -- are written as zeros (the fill value of `baseband`'s
+ * readers). */
+int bbt_unpack_masked(const void* raw_dev, void* out_dev, int64_t n_frames, int frame_bytes,
+                      int header_bytes, int bits, int samples_per_frame, int n_thread, int n_elem,
+                      int code, const void* valid_dev, bbt_stream stream);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------
  * The reference has no distributed code; these are what SURVEY 8(b)/(e) ask a

@@ -1344,6 +1344,41 @@ def test_vdif_frames_are_unpacked_on_the_device(bits, complex_data):
         (bits, n_chan, complex_data, 49998, 3)
 
 
+def test_vdif_frames_out_of_order_invalid_or_missing():
+    """open_vdif reads every header: frames shuffled in the file come back in
+    time and thread order; a frame flagged invalid and a frame that is not in
+    the file at all read as zeros; a duplicated frame counts once (parity
+    unpinned, as for the decoder itself: `baseband` fills such frames with its
+    fill value 0)."""
+    from baseband_tasks_amd import ingest
+    rng = np.random.default_rng(17)
+    n_sets, n_thread, n_chan, spf = 12, 2, 4, 160
+    levels = np.array([-3.3359, -1., 1., 3.3359], np.float32)
+    data = rng.choice(levels, size=(n_sets * spf, n_thread, n_chan * 2)).view(np.complex64)
+    raw = ingest.encode_vdif_frames(data, 2, seconds=7, ref_epoch=41, frame_nr0=24996, frames_per_second=25000,
+                                    samples_per_frame=spf, edv=3, sample_rate=4e6)
+    nb = len(raw) // (n_sets * n_thread)
+    frames = [bytearray(raw[i * nb:(i + 1) * nb]) for i in range(n_sets * n_thread)]      # (set, thread) order
+    frames[2 * 5 + 1][3] |= 0x80                          # set 5, thread 1: invalid flag (bit 31 of word 0)
+    gone = 2 * 8 + 0                                      # set 8, thread 0: not in the file
+    order = [i for i in rng.permutation(len(frames)) if i != gone]
+    order.insert(3, 2 * 2 + 1)                            # set 2, thread 1 twice (the later copy is garbage)
+    shuffled = [bytes(frames[i]) for i in order]
+    late = len(shuffled) - 1 - order[::-1].index(2 * 2 + 1)
+    shuffled[late] = shuffled[late][:32] + bytes(len(shuffled[late]) - 32)
+    fh = bt.open_vdif(b''.join(shuffled), frequency=300 * u.MHz, sideband=1)
+    assert fh.shape == (n_sets * spf, n_thread, n_chan) and fh.sample_rate == 4e6
+    assert abs((fh.start_time - bt.Time('2020-07-01T00:00:07')) - 24996 * spf / 4e6) < 1e-9
+    want = data.copy()
+    want[5 * spf:6 * spf, 1] = 0.
+    want[8 * spf:9 * spf, 0] = 0.
+    assert np.array_equal(fh.read(), want)
+    fh.seek(7 * spf + 11)
+    assert np.array_equal(fh.read(2 * spf), want[7 * spf + 11:9 * spf + 11])
+    # a complete file in order takes the direct route
+    assert bt.open_vdif(raw)._frame_map is None and fh._frame_map is not None
+
+
 def test_dada_samples_are_unpacked_on_the_device():
     """PSRDADA: ASCII header + signed 8-bit (time, pol, re/im) samples (parity unpinned)."""
     rng = np.random.default_rng(8)
