@@ -179,9 +179,12 @@ class Channelize(_RowFFTTask):
             return None
         if self._real or dd._real:
             return None
-        if dd._n_stream != dd._n_stream_even or dd.samples_per_frame < self._n:
+        if dd.samples_per_frame < self._n:
             return None
-        if not dd._get_plan().fusable(self._n):
+        plan = dd._get_plan()
+        if dd._n_stream != dd._n_stream_even and not dd._single:      # (one stream runs unpadded)
+            return None
+        if not plan.fusable(self._n):
             return None
         return dd
 
@@ -219,7 +222,7 @@ class Channelize(_RowFFTTask):
         overlap-save plan, without storing them.  Returns False when that
         route does not apply (the caller then detects the stored spectra)."""
         dd = self._fusable_input() if FUSE_DETECTION else None
-        if dd is None or dd._ih_samples_per_frame > (1 << 20) or self._n < MIN_FFT_LEN:
+        if dd is None or dd._single or dd._ih_samples_per_frame > (1 << 20) or self._n < MIN_FFT_LEN:
             return False
         plan = dd._get_plan()
         if plan.info()['n1'] != 256 or plan.detect_bins_max(self._n, step) > 64:

@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 123
+#define BBT_VERSION 124
 
 // ---------------------------------------------------------------------------
 // errors
@@ -646,13 +646,12 @@ template <bool FIRST, bool SPEC>
 static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                           const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
     constexpr size_t lds1 = FftGeo<256>::LDS_ELEMS * sizeof(v2);     // per column of a tile
-    if constexpr (!SPEC) {
-        if (p->single) {
-            hipLaunchKernelGGL((k_osm_col256<FIRST, false, 16, false, 1, true>),
-                               dim3(row_len / 16, (ch.nblk + 1) / 2), dim3(256), 16 * lds1, st, in, out,
-                               work, ch, 1, row_len, p->tab1.tw0, so);
-            return 0;
-        }
+    if (p->single) {
+        if (so.det) return fail("osm: one-stream plans have no fused detection");
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 1, true>),
+                           dim3(row_len / 16, (ch.nblk + 1) / 2), dim3(256), 16 * lds1, st, in, out, work,
+                           ch, 1, row_len, p->tab1.tw0, so);
+        return 0;
     }
     if constexpr (SPEC && !FIRST) {
         if (so.det) {
@@ -771,7 +770,6 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         in = stage;
     }
     const OsmChunk& ch = *chp;         // (block i of a prefiltered chunk reads staging[i * N])
-    if (p->single && nch) return fail("osm: one-stream plans have no fused channelizer");
     OsmChunk pairs_view;               // one stream: the work buffers hold pairs of blocks
     if (p->single) {
         pairs_view = ch;
@@ -860,7 +858,10 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         if (launch_rowpass(p, work, chw, nch, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
         if (p->n1 == 16) {
-            if (p->single)
+            if (p->single && nch)
+                hipLaunchKernelGGL((k_osm_col16<false, true, true>), g16, dim3(256), 0, st, in, out,
+                                   work, ch, 1, p->n2, so);
+            else if (p->single)
                 hipLaunchKernelGGL((k_osm_col16<false, false, true>), g16, dim3(256), 0, st, in, out,
                                    work, ch, 1, p->n2, so);
             else if (nch)
@@ -953,8 +954,12 @@ static void launch_seam_fix(bbt_osm_plan* p, float2* out, const std::vector<Seam
         SeamJobs batch;
         const size_t n = std::min(jobs.size() - j0, (size_t)BBT_SEAM_JOBS_PER_LAUNCH);
         for (size_t i = 0; i < n; ++i) batch.j[i] = jobs[j0 + i];
-        hipLaunchKernelGGL((k_seam_fix<NCH>), dim3((unsigned)n, p->npair), dim3(NCH / 16), 0, st,
-                           p->seam, out, batch, p->S, p->npair, tab.tw0, tab.tw1, so);
+        if (p->single)
+            hipLaunchKernelGGL((k_seam_fix<NCH, true>), dim3((unsigned)n, 1), dim3(NCH / 16), 0, st, p->seam,
+                               out, batch, 1, 1, tab.tw0, tab.tw1, so);
+        else
+            hipLaunchKernelGGL((k_seam_fix<NCH>), dim3((unsigned)n, p->npair), dim3(NCH / 16), 0, st,
+                               p->seam, out, batch, p->S, p->npair, tab.tw0, tab.tw1, so);
     }
 }
 
@@ -1159,7 +1164,9 @@ int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chun
 
 int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     // can bbt_osm_execute_channelized take Channelize(n_chan) into the row pass?
-    if (!p || p->generic || p->single || (p->n1 == 1 && p->outer == 1)) return 0;
+    if (!p || p->generic || (p->n1 == 1 && p->outer == 1)) return 0;
+    if (p->single)              // one stream: blocks side by side; 256 channels and up, no detection
+        return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0 && p->n1 != 4096;
     if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
         return p->n1 == 256 || p->n1 == 4096 || p->outer == 256;            // exchange in the row pass
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
@@ -1232,6 +1239,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
             "4096 columns or of three levels)", who, n_chan, p->n2);
     const bool small = n_chan < 256;
     ARG_TRY(!(small && det_step > 0), "%s: fused detection needs n_chan >= 256", who);
+    ARG_TRY(!(p->single && det_step > 0), "%s: one-stream plans have no fused detection", who);
     ARG_TRY(first_spectrum >= 0 && n_spectra >= 0, "%s: bad spectrum range", who);
     if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
     for (int64_t b = 0; b < n_blocks; ++b)

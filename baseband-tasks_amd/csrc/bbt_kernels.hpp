@@ -299,6 +299,27 @@ __device__ __forceinline__ void emit_spectrum(c2 val, const SpecCursor& c, int j
     }
 }
 
+// One stream: the value of one block (one half of the register pair) goes out as 8 bytes;
+// the seam slots keep the pair format (second half zero) so k_seam_fix serves both.
+__device__ __forceinline__ void emit_spectrum_single(float2 val, const SpecCursor& c, int j) {
+    const c2 padded = c2{v2{val.x, 0.f}, v2{val.y, 0.f}};
+    int rel = c.rel + j * c.drel;
+    if (rel >= c.wrap_at) {
+        if (rel < c.vc) st_ext(c.seam1, padded);
+        rel -= c.n_fft;
+        if (rel < 0 && rel + c.nch > 0) st_ext(c.seam0, padded);
+        return;
+    }
+    if (rel >= 0 && rel + c.nch <= c.vc) {
+        const long long s = c.s0 + j * c.ds;
+        if (s >= 0 && s < c.n_out) c.dst[j * c.dstride] = val;
+    } else if (rel < 0 && rel + c.nch > 0) {
+        st_ext(c.seam0, padded);
+    } else if (rel < c.vc && rel + c.nch > c.vc) {
+        st_ext(c.seam1, padded);
+    }
+}
+
 struct OsmChunk {
     int nblk;
     OsmBlock b[BBT_MAX_CHUNK];
@@ -324,6 +345,16 @@ __device__ __forceinline__ SinglePair single_pair(const OsmChunk& ch, int q) {
 __device__ __forceinline__ c2 ld_single(const float2* __restrict__ in, const SinglePair& sp, long long e) {
     const float2 a = in[sp.a.in_off + e];
     const float2 b = sp.has_b ? in[sp.b.in_off + e] : make_float2(0.f, 0.f);
+    return c2{v2{a.x, b.x}, v2{a.y, b.y}};
+}
+// (fused channelizer: each block read circularly shifted by its own blk.shift, n = block length)
+__device__ __forceinline__ c2 ld_single_shifted(const float2* __restrict__ in, const SinglePair& sp, long long e,
+                                                long long n) {
+    long long ea = e + sp.a.shift, eb = e + sp.b.shift;
+    ea -= ea >= n ? n : 0;
+    eb -= eb >= n ? n : 0;
+    const float2 a = in[sp.a.in_off + ea];
+    const float2 b = sp.has_b ? in[sp.b.in_off + eb] : make_float2(0.f, 0.f);
     return c2{v2{a.x, b.x}, v2{a.y, b.y}};
 }
 __device__ __forceinline__ void st_single(float2* __restrict__ out, const SinglePair& sp, long long e, c2 v) {
@@ -418,11 +449,11 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
     c2 v[16];
     if constexpr (SINGLE) {                       // b = pair of blocks of the one stream
-        static_assert(!SPEC, "one-stream plans have no fused channelizer");
         const SinglePair pr = single_pair(ch, b);
         if (FIRST) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_single(in, pr, (long long)j * N2 + n2);
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_single_shifted(in, pr, (long long)j * N2 + n2, 16ll * N2);
             radix16<-1>(v);
 #pragma unroll
             for (int j = 0; j < 16; ++j) st_int(w + (long long)j * N2 * 2, v[j]);
@@ -430,8 +461,18 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)j * N2 * 2);
             radix16<+1>(v);
+            if constexpr (SPEC) {
+                const SpecCursor ca = spec_cursor(out, so, pr.a, 0, 1, N2, n2, 1, 0, 1);
+                const SpecCursor cb = spec_cursor(out, so, pr.b, 0, 1, N2, n2, 1, 0, 1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)j * N2 + n2, v[j]);
+                for (int j = 0; j < 16; ++j) {
+                    emit_spectrum_single(make_float2(v[j].re.x, v[j].im.x), ca, j);
+                    if (pr.has_b) emit_spectrum_single(make_float2(v[j].re.y, v[j].im.y), cb, j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)j * N2 + n2, v[j]);
+            }
         }
         return;
     }
@@ -499,11 +540,12 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
     c2 v[16];
     if constexpr (SINGLE) {                              // b = pair of blocks of the one stream
-        static_assert(!SPEC && !DET && PP == 1, "one-stream plans: plain output only");
+        static_assert(!DET && PP == 1, "one-stream plans: no fused detection");
         const SinglePair pr = single_pair(ch, b);
         if (FIRST) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_single(in, pr, (long long)(tau + 16 * j) * N2 + n2);
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_single_shifted(in, pr, (long long)(tau + 16 * j) * N2 + n2, 256ll * N2);
             wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
 #pragma unroll
             for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
@@ -511,8 +553,18 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
             wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
+            if constexpr (SPEC) {
+                const SpecCursor ca = spec_cursor(out, so, pr.a, tau, 16, N2, n2, 1, 0, 1);
+                const SpecCursor cb = spec_cursor(out, so, pr.b, tau, 16, N2, n2, 1, 0, 1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)(tau + 16 * j) * N2 + n2, v[j]);
+                for (int j = 0; j < 16; ++j) {
+                    emit_spectrum_single(make_float2(v[j].re.x, v[j].im.x), ca, j);
+                    if (pr.has_b) emit_spectrum_single(make_float2(v[j].re.y, v[j].im.y), cb, j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)(tau + 16 * j) * N2 + n2, v[j]);
+            }
         }
         return;
     }
@@ -989,7 +1041,7 @@ struct SeamJob {
 struct SeamJobs {         // passed by value: no upload, no synchronisation
     SeamJob j[BBT_SEAM_JOBS_PER_LAUNCH];
 };
-template <int NCH>
+template <int NCH, bool SINGLE = false>
 __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict__ seam,
                                                        float2* __restrict__ out, SeamJobs jobs,
                                                        int S, int npair,
@@ -1031,6 +1083,12 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
                 unsafeAtomicAdd(dst + 3, pw.w * so.det_scale);
             }
         }
+        return;
+    }
+    if constexpr (SINGLE) {                              // one stream: the first half of the pair format
+        float2* dst = out + (job.spectrum * NCH + tau);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dst[T * j] = make_float2(va[j].re.x, va[j].im.x);
         return;
     }
     float2* dst = out + ((job.spectrum * NCH + tau) * S + 2 * sp);

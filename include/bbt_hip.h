@@ -111,8 +111,9 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  *               into two such factors <= 8192 (generic LDS Stockham path)
  *   n_stream    S, even; or 1 with a power-of-two n_fft: the one stream runs
  *               unpadded, two consecutive blocks side by side where a pair of
- *               streams would be (plain bbt_osm_execute only: no fused
- *               channelizer, no prefilter)
+ *               streams would be (bbt_osm_execute, and
+ *               bbt_osm_execute_channelized for 256 channels and up; no fused
+ *               detection, no prefilter)
  *   n_resp      number of distinct response columns C
  *   resp        C x N complex64, FFT-natural order, UNSCALED
  *               (= Disperse.phase_factor, dispersion.py:115-129, or

@@ -1671,7 +1671,7 @@ def test_random_block_descriptors_through_the_c_abi():
             assert_parity(part.to_host(), want[a:a + k].astype(np.complex64), 'window ' + what)
         # the powers summed in the last pass instead of stored spectra
         step = int(rng.integers(1, 40))
-        if (geo['n1'] == 256 and n_fft <= 2**20 and n_chan >= 256 and n_spec >= step
+        if (S > 1 and geo['n1'] == 256 and n_fft <= 2**20 and n_chan >= 256 and n_spec >= step
                 and plan.detect_bins_max(n_chan, step) <= 64):
             n_bins = n_spec // step
             mode = int(rng.integers(0, 2))
@@ -2087,6 +2087,43 @@ print("one runtime:", maps[0])
     for order in ('lib-first', 'torch-first'):
         done = subprocess.run([sys.executable, '-c', script, order], capture_output=True, text=True, timeout=300)
         assert done.returncode == 0 and 'one runtime:' in done.stdout, (order, done.stdout[-500:], done.stderr[-1500:])
+
+
+@pytest.mark.parametrize('n_fft,n_chan', [(2**14, 256), (2**15, 2048), (2**16, 4096), (2**18, 1024), (2**20, 512),
+                                          (2**21, 256)])
+def test_one_stream_through_the_fused_channelizer(n_fft, n_chan):
+    """Channelize(Convolve(one complex stream)): fused, blocks paired, each block with
+    its own circular shift; odd and even numbers of blocks, seam spectra included;
+    equal to the unfused route and to numpy."""
+    import baseband_tasks_amd.channelize as chz
+    rng = np.random.default_rng(n_fft + n_chan)
+    n_tap = 45
+    spf = n_fft - n_tap + 1
+    resp = (rng.standard_normal(n_tap) + 1j * rng.standard_normal(n_tap)).astype(np.complex64)
+    limit = bt.Convolve.FIR_MAX_TAPS_COMPLEX
+    bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0
+    try:
+        for n_blocks, extra in ((2, 0), (3, 901), (5, 17)):
+            n_in = n_blocks * spf + n_tap - 1 + extra
+            x = (rng.standard_normal(n_in) + 1j * rng.standard_normal(n_in)).astype(np.complex64)
+            ds = bt.DeviceStream(x, T0, 1 * u.MHz)
+            cv = bt.Convolve(ds, resp, samples_per_frame=spf)
+            ch = bt.Channelize(cv, n_chan, samples_per_frame=2)
+            assert ch._fusable_input() is cv and cv._single
+            got = ch.read()
+            y = np.convolve(x.astype(np.complex128), resp.astype(np.complex128), mode='valid')
+            want = np.fft.fft(y[:got.shape[0] * n_chan].reshape(-1, n_chan), axis=1)
+            assert got.shape[0] >= (y.shape[0] // n_chan) - 1
+            assert_parity(got, want.astype(np.complex64), f'one stream fused, n_fft {n_fft} n_chan {n_chan} {n_blocks} blocks')
+            saved = chz.FUSE_WITH_OVERLAP_SAVE
+            chz.FUSE_WITH_OVERLAP_SAVE = False
+            try:
+                plain = bt.Channelize(bt.Convolve(ds, resp, samples_per_frame=spf), n_chan, samples_per_frame=2).read()
+            finally:
+                chz.FUSE_WITH_OVERLAP_SAVE = saved
+            assert rel_l2(got, plain) < 5e-7
+    finally:
+        bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
 
 
 def test_bench_two_ranks_share_this_gpu():

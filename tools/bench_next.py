@@ -287,6 +287,18 @@ def dedisperse_default(reps):
     return _dedisperse_row(reps, 'default')
 
 
+def fused_single(reps):
+    nblk = 384
+    x = randn_c64(nblk * 2**20, ())
+    ds = bt.DeviceStream(x, T0, 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    dd = bt.Dedisperse(ds, 100., samples_per_frame=836100)
+    ch = bt.Channelize(dd, 1024, 64)
+    assert ch._fusable_input() is dd
+    dt = timed(lambda: restart([dd, ch], ch, ch.shape[0]), reps)
+    return dict(units=ch.shape[0] * 1024, unit='complete samples', bytes_per_unit=8 * (1 + 2**20 / 836100), seconds=dt,
+                note='the metric pipeline on ONE complex64 stream: fused, consecutive blocks paired')
+
+
 def chan_single_1024(reps):
     n_chan, n_spec = 1024, 2**18
     x = randn_c64(n_spec * n_chan, ())
@@ -301,6 +313,7 @@ ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_
             chan_real_1024=chan_real_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
             pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
             dedisperse_single=dedisperse_single, dedisperse_default=dedisperse_default, chan_single_1024=chan_single_1024,
+            fused_single=fused_single,
             f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
             f3_dada=f3_dada,
             f4_dechan=f4_dechan, f4_ipfb=f4_ipfb)
