@@ -177,12 +177,20 @@ class Channelize(_RowFFTTask):
         dd = self.ih
         if not (FUSE_WITH_OVERLAP_SAVE and isinstance(dd, SpectralMultiplyTask)) or dd.closed:
             return None
-        if self._real or dd._real:
+        if self._real != dd._real:
             return None
         if dd.samples_per_frame < self._n:
             return None
         plan = dd._get_plan()
-        if dd._n_stream != dd._n_stream_even and not dd._single:      # (one stream runs unpadded)
+        if dd._real:
+            # real streams in pairs are complex streams to the plan (a + i b); their spectra are
+            # separated afterwards, so the pair route of both tasks must be on
+            if not (dd._paired and self._pairs()):
+                return None
+            n_plan = dd._n_stream // 2
+            if n_plan % 2 and not dd._single:
+                return None
+        elif dd._n_stream != dd._n_stream_even and not dd._single:    # (one stream runs unpadded)
             return None
         if not plan.fusable(self._n):
             return None
@@ -200,6 +208,16 @@ class Channelize(_RowFFTTask):
             in0, in_len, starts, out_abs, keep, counts = dd._block_descriptors(m0, m1)
             if np.all(counts >= n):      # (a short final frame cannot host a whole spectrum)
                 x = fetch_device(dd.ih, in0, in_len)
+                if self._real:
+                    # (n, S) float32 == (n, S/2) complex64 z = a + i b: spectra of z from the fused plan,
+                    # then the half spectra of a and b
+                    p = self._n_stream // 2
+                    x = hip.DeviceArray((in_len, p), np.complex64, ptr=x.ptr, owner=x)
+                    z = hip.DeviceArray((n_spectra * n, p), np.complex64)
+                    dd._get_plan().execute_channelized(x, z, starts - in0, out_abs, keep, counts, n,
+                                                       start, n_spectra)
+                    hip.split_real_pair_spectra(z, n, self._n_stream, out)
+                    return
                 dd._get_plan().execute_channelized(x, flat, starts - in0, out_abs, keep, counts, n,
                                                    start, n_spectra)
                 return

@@ -2126,6 +2126,38 @@ def test_one_stream_through_the_fused_channelizer(n_fft, n_chan):
         bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
 
 
+@pytest.mark.parametrize('shape', [(2,), (4,)])
+def test_real_streams_through_the_fused_channelizer(shape):
+    """Channelize(Dedisperse(float32 streams)): pairs of real streams are complex
+    streams to the fused plan, their spectra are separated afterwards; equal to
+    the oracle's rfft of the dedispersed real streams and to the unfused route."""
+    import baseband_tasks_amd.channelize as chz
+    rng = np.random.default_rng(sum(shape))
+    fs, n_chan = 4e6, 512
+    n_in = 5 * 2**16 + 1234
+    x = rng.standard_normal((n_in,) + shape).astype(np.float32)
+    ds = bt.DeviceStream(x, T0, fs, samples_per_frame=2**14, frequency=400 * u.MHz, sideband=1)
+    probe = bt.Dedisperse(ds, 3.)
+    dd = bt.Dedisperse(ds, 3., samples_per_frame=2**16 - (probe._pad_start + probe._pad_end))
+    dd._get_plan()
+    assert dd._ih_samples_per_frame == 2**16 and dd._real and dd._paired
+    ch = bt.Channelize(dd, n_chan, samples_per_frame=4)
+    assert ch._fusable_input() is dd
+    got = ch.read()
+    y = dd.read()                                                    # the dedispersed real streams (GPU, unfused)
+    want = np.fft.rfft(y[:got.shape[0] * n_chan].astype(np.float64).reshape((-1, n_chan) + shape), axis=1)
+    assert got.shape == want.shape
+    assert_parity(got, want.astype(np.complex64), f'real streams fused {shape}')
+    saved = chz.FUSE_WITH_OVERLAP_SAVE
+    chz.FUSE_WITH_OVERLAP_SAVE = False
+    try:
+        plain = bt.Channelize(bt.Dedisperse(ds, 3., samples_per_frame=dd.samples_per_frame), n_chan,
+                              samples_per_frame=4).read()
+    finally:
+        chz.FUSE_WITH_OVERLAP_SAVE = saved
+    assert rel_l2(got, plain) < 5e-7
+
+
 def test_bench_two_ranks_share_this_gpu():
     """`python bench.py --gpus 2` end to end on one GPU: the launcher starts two
     ranks (gloo, as RCCL wants one device per rank), the chirp is broadcast, each

@@ -299,6 +299,23 @@ def fused_single(reps):
                 note='the metric pipeline on ONE complex64 stream: fused, consecutive blocks paired')
 
 
+def fused_real(reps):
+    nblk = 384
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    x = torch.randn((nblk * 2**20, 2), generator=g, device=DEV, dtype=torch.float32)
+    ds = bt.DeviceStream(x, T0, 32e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    probe = bt.Dedisperse(ds, 100.)
+    pad = probe._ih_samples_per_frame - probe.samples_per_frame
+    dd = bt.Dedisperse(ds, 100., samples_per_frame=2**20 - pad)
+    ch = bt.Channelize(dd, 1024, 64)
+    assert ch._fusable_input() is dd
+    dt = timed(lambda: restart([dd, ch], ch, ch.shape[0]), reps)
+    return dict(units=ch.shape[0] * 1024, unit='complete samples',
+                bytes_per_unit=8 * 2**20 / dd.samples_per_frame + 16 * 513 / 1024, seconds=dt,
+                note='the metric pipeline on two float32 streams: fused as one complex stream, then split')
+
+
 def chan_single_1024(reps):
     n_chan, n_spec = 1024, 2**18
     x = randn_c64(n_spec * n_chan, ())
@@ -313,7 +330,7 @@ ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_
             chan_real_1024=chan_real_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
             pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
             dedisperse_single=dedisperse_single, dedisperse_default=dedisperse_default, chan_single_1024=chan_single_1024,
-            fused_single=fused_single,
+            fused_single=fused_single, fused_real=fused_real,
             f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
             f3_dada=f3_dada,
             f4_dechan=f4_dechan, f4_ipfb=f4_ipfb)
