@@ -81,7 +81,7 @@ class Convolve(SpectralMultiplyTask):
                                         and np.array_equal(full[:, 0::2], full[:, 1::2]))
                 if self._fir_paired:
                     full = full[:, 0::2]
-                if full.shape[1] % 2:
+                if full.shape[1] % 2 and full.shape[1] > 1:      # (one stream runs as it is)
                     full = np.concatenate([full, np.zeros_like(full[:, :1])], axis=1)
                 self._fir = hip.FirPlan(np.ascontiguousarray(full))
         return self._fir is not False
@@ -100,7 +100,7 @@ class Convolve(SpectralMultiplyTask):
         elif self._real:
             x = hip.real_to_complex(x.reshape(n_out + pad, s))
             final, out = out, hip.DeviceArray((n_out, s), np.complex64)
-        se = s + s % 2
+        se = s if s == 1 else s + s % 2
         if se != s:
             x = hip.pad_streams_to_even(x, s)
             target = hip.DeviceArray((n_out, se), np.complex64)

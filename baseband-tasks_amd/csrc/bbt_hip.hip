@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 124
+#define BBT_VERSION 125
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1198,7 +1198,7 @@ int bbt_osm_execute_prefiltered(bbt_osm_plan* p, const bbt_fir_plan* fir, const 
                                 const int32_t* valid_count, bbt_stream stream) {
     const char* who = "bbt_osm_execute_prefiltered";
     ARG_TRY(p && fir && in_dev && out_dev, "%s: null argument", who);
-    ARG_TRY(!p->single, "%s: not for one-stream plans", who);
+    ARG_TRY(!p->single && fir->S != 1, "%s: not for one-stream plans", who);
     ARG_TRY(fir->S == p->S, "%s: the filter has %d streams, the plan %d", who, fir->S, p->S);
     ARG_TRY(p->n >= 256 * BBT_FIR_R, "%s: blocks of %lld samples are too short", who, (long long)p->n);
     if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
@@ -1865,13 +1865,13 @@ extern "C" int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream,
     ARG_TRY(plan && response_host, "bbt_fir_plan_create: null argument");
     *plan = nullptr;
     ARG_TRY(n_tap >= 1 && n_tap <= 1024, "bbt_fir_plan_create: n_tap=%d must be in [1, 1024]", n_tap);
-    ARG_TRY(n_stream >= 2 && n_stream % 2 == 0,
-            "bbt_fir_plan_create: n_stream=%d must be even and >= 2 (pad odd counts)", n_stream);
+    ARG_TRY(n_stream == 1 || (n_stream >= 2 && n_stream % 2 == 0),
+            "bbt_fir_plan_create: n_stream=%d must be 1 or even (pad other odd counts)", n_stream);
     constexpr int R = BBT_FIR_R;
     bbt_fir_plan* p = new bbt_fir_plan;
     p->n_tap = n_tap;
     p->S = n_stream;
-    p->npair = n_stream / 2;
+    p->npair = n_stream == 1 ? 1 : n_stream / 2;
     p->n_chunks = (n_tap + R - 1 + R - 1) / R;           // inputs u = r + m < n_tap + R - 1
     p->pitch = 256 + p->n_chunks;
     while (p->pitch % 16 != 2) ++p->pitch;
@@ -1881,7 +1881,8 @@ extern "C" int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream,
     for (int sp = 0; sp < p->npair; ++sp)
         for (int m = 0; m < n_tap; ++m) {
             const cf a = resp[(size_t)(n_tap - 1 - m) * n_stream + 2 * sp];
-            const cf b = resp[(size_t)(n_tap - 1 - m) * n_stream + 2 * sp + 1];
+            const cf b = n_stream == 1 ? a          // one stream: both halves of the time range
+                                       : resp[(size_t)(n_tap - 1 - m) * n_stream + 2 * sp + 1];
             re[(size_t)sp * p->tap_pitch + (R - 1) + m] = make_float2(a.x, b.x);
             im[(size_t)sp * p->tap_pitch + (R - 1) + m] = make_float2(a.y, b.y);
             if (a.y != 0.f || b.y != 0.f) p->cplx = true;
@@ -1910,7 +1911,9 @@ extern "C" int bbt_fir_execute(bbt_fir_plan* p, const void* in_dev, void* out_de
     if (n_out == 0) return 0;
     constexpr int R = BBT_FIR_R;
     const long long n_in = n_out + p->n_tap - 1;
-    const long long tiles = (n_out + 256 * R - 1) / (256 * R);
+    // (one stream: the grid covers the first half of the outputs, a thread's second filter the other half)
+    const long long covered = p->S == 1 ? (n_out + 1) / 2 : n_out;
+    const long long tiles = (covered + 256 * R - 1) / (256 * R);
     ARG_TRY(tiles * p->npair < (1ll << 31), "bbt_fir_execute: too large for one call");
     const size_t lds = (size_t)R * p->pitch * sizeof(float4);
     const dim3 grid((unsigned)(tiles * p->npair));

@@ -1516,19 +1516,34 @@ __global__ __launch_bounds__(256) void k_scale_streams(const float2* __restrict_
 // reads (column t + q for thread t) are conflict free.
 //   tre/tim : [npair][tap_pitch] float2 (g_A, g_B) real / imaginary parts,
 //             R-1 zeros in front and >= R zeros behind the n_tap taps.
+// `half` > 0 (one stream, S == 1): the two filters a thread carries side by side
+// are the first and the second half of the one stream -- outputs [0, half) and
+// [half, n_out) -- instead of the two streams of a pair.
 template <int R, bool CPLX>
 __device__ __forceinline__ void fir_tile(const float2* __restrict__ in, float2* __restrict__ out,
                                          long long n_in, long long n_out, int S, int sp,
                                          long long base, const float2* __restrict__ tre,
                                          const float2* __restrict__ tim, int tap_pitch,
-                                         int n_chunks, int pitch, float4* __restrict__ fir_tile_lds) {
+                                         int n_chunks, int pitch, float4* __restrict__ fir_tile_lds,
+                                         long long half = 0) {
     constexpr int T = 256;
     const int t = threadIdx.x;
     const int n_tile = R * (T + n_chunks);
     for (int s = t; s < n_tile; s += T) {
         const long long g = base + s;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < n_in) x = *reinterpret_cast<const float4*>(in + (g * S + 2 * sp));
+        if (half > 0) {
+            if (g < n_in) {
+                const float2 a = in[g];
+                x.x = a.x;
+                x.y = a.y;
+            }
+            if (g + half < n_in) {
+                const float2 b = in[g + half];
+                x.z = b.x;
+                x.w = b.y;
+            }
+        } else if (g < n_in) x = *reinterpret_cast<const float4*>(in + (g * S + 2 * sp));
         // the tile holds register order (re_A re_B im_A im_B): the swizzle is done once per
         // sample here instead of once per use in the tap loop (3 v_mov per input, 15 % of its VALU)
         fir_tile_lds[(s % R) * pitch + s / R] = make_float4(x.x, x.z, x.y, x.w);
@@ -1576,7 +1591,13 @@ __device__ __forceinline__ void fir_tile(const float2* __restrict__ in, float2* 
     __syncthreads();
     for (int s = t; s < T * R; s += T) {
         const long long g = base + s;
-        if (g < n_out) *reinterpret_cast<float4*>(out + (g * S + 2 * sp)) = fir_tile_lds[(s % R) * pitch + s / R];
+        if (half > 0) {
+            const float4 y = fir_tile_lds[(s % R) * pitch + s / R];
+            if (g < half && g < n_out) out[g] = make_float2(y.x, y.y);
+            if (g + half < n_out) out[g + half] = make_float2(y.z, y.w);
+        } else if (g < n_out) {
+            *reinterpret_cast<float4*>(out + (g * S + 2 * sp)) = fir_tile_lds[(s % R) * pitch + s / R];
+        }
     }
 }
 
@@ -1587,9 +1608,15 @@ __global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, floa
                                              const float2* __restrict__ tim, int tap_pitch,
                                              int n_chunks, int pitch) {
     extern __shared__ float4 fir_tile_mem[];
-    const int npair = S >> 1;
     // the pairs of one tile share cache lines: consecutive virtual ids, one XCD
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    if (S == 1) {               // one stream: the grid covers the first half, see fir_tile
+        const long long tiles = gridDim.x;
+        fir_tile<R, CPLX>(in, out, n_in, n_out, 1, 0, (long long)vb * (256 * R), tre, tim, tap_pitch, n_chunks,
+                          pitch, fir_tile_mem, tiles * (256 * R));
+        return;
+    }
+    const int npair = S >> 1;
     fir_tile<R, CPLX>(in, out, n_in, n_out, S, vb % npair, (long long)(vb / npair) * (256 * R), tre, tim,
                       tap_pitch, n_chunks, pitch, fir_tile_mem);
 }

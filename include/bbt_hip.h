@@ -303,8 +303,9 @@ int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_samples, int 
  * Resample, sampling.py:177-193) this computes it directly: one read and one
  * write of the stream instead of three FFT passes, and no block structure.
  * response_host: complex64 (n_tap, n_stream), the reference's `response`
- * broadcast to the streams (n_stream even).  `in` holds n_out + n_tap - 1
- * complete samples.  Purely real responses take a cheaper kernel. */
+ * broadcast to the streams (n_stream even, or 1: the two halves of the one
+ * stream's time range are then filtered side by side).  `in` holds n_out +
+ * n_tap - 1 complete samples.  Purely real responses take a cheaper kernel. */
 int bbt_fir_plan_create(bbt_fir_plan** plan, int n_tap, int n_stream, const void* response_host);
 int bbt_fir_plan_destroy(bbt_fir_plan* plan);
 int bbt_fir_execute(bbt_fir_plan* plan, const void* in_dev, void* out_dev, int64_t n_out,

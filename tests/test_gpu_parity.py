@@ -1850,13 +1850,14 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         # direct FIR, real and complex responses
         n_tap = int(rng.choice([1, 2, 3, 17, 64, 129, 200]))
         n_out = int(rng.choice(counts + [4095, 4097, 20000]))
-        resp = cplx(n_tap, S) if case % 2 else rng.standard_normal((n_tap, S)).astype(np.complex64)
-        x = cplx(max(n_out, 1) + n_tap - 1, S)
-        out, n = guarded((n_out, S), np.complex64)
-        hip.FirPlan(resp).execute(hip.DeviceArray.from_host(x), out, n_out)
-        want = np.stack([np.convolve(x[:, k].astype(np.complex128), resp[:, k].astype(np.complex128), mode='valid')
-                         for k in range(S)], axis=1)[:n_out]
-        check_guarded(out, n, (n_out, S), want, f'fir case {case}: taps {n_tap} S {S} count {n_out}')
+        for Sf in (S, 1):                                           # (one stream: its two halves side by side)
+            resp = cplx(n_tap, Sf) if case % 2 else rng.standard_normal((n_tap, Sf)).astype(np.complex64)
+            x = cplx(max(n_out, 1) + n_tap - 1, Sf)
+            out, n = guarded((n_out, Sf), np.complex64)
+            hip.FirPlan(resp).execute(hip.DeviceArray.from_host(x), out, n_out)
+            want = np.stack([np.convolve(x[:, k].astype(np.complex128), resp[:, k].astype(np.complex128), mode='valid')
+                             for k in range(Sf)], axis=1)[:n_out]
+            check_guarded(out, n, (n_out, Sf), want, f'fir case {case}: taps {n_tap} S {Sf} count {n_out}')
         # per-element sample shifts: 4- and 8-byte elements, neighbours moving together or not
         n_elem = int(rng.choice([1, 2, 3, 4, 6, 16, 128, 130, 600]))
         n_out = int(rng.choice(counts + [5000]))
