@@ -51,6 +51,8 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
     #: transforms side by side instead of a stream pair) for power-of-two n in
     #: [256, 4096]; other odd stream counts are padded to even
     _SINGLE_STREAM = True
+    #: the plain channelizer's kernel can separate the spectra of two real streams itself
+    _SPLIT_IN_TRANSFORM = True
 
     def _even(self, count):
         if count == 1 and self._SINGLE_STREAM and 256 <= self._n <= 4096 and not self._n & (self._n - 1):
@@ -97,6 +99,13 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
         spectra directly."""
         p = self._pairs()
         pe = self._even(p)
+        if p == 1 and pe == 1 and self._SPLIT_IN_TRANSFORM:
+            # two real streams = one complex stream: the transform kernel pairs k with n - k
+            # itself and writes the half spectra (no separate pass over the spectra)
+            if self._pair_plan is None:
+                self._pair_plan = hip.ChanPlan(self._n, 1, -2)
+            self._pair_plan.execute(x, out, n_spectra)
+            return
         if self._pair_plan is None:
             self._pair_plan = self._make_plan(pe)
         if pe != p:

@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 125
+#define BBT_VERSION 126
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1408,6 +1408,7 @@ int bbt_osm_timing_read(bbt_osm_plan* p, double ms[3], int64_t* launches) {
 // channelizer
 struct bbt_chan_plan {
     int n = 0, S = 0, npair = 0, dir = -1;
+    bool split_real = false;    // direction -2: one stream z = a + i b, output = half spectra of a and b
     FftTables tab;
     cf* wroot = nullptr;
     // channel counts that are not powers of two, or 8192 (gen_kernels.hpp)
@@ -1442,6 +1443,13 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
     constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
     if (p->S == 1) {            // one stream: two consecutive transforms side by side
         const unsigned gx = (unsigned)(((n_fft + 1) / 2 + FPW - 1) / FPW);
+        if constexpr (SIGN < 0) {
+            if (p->split_real) {    // ... of two real streams: their half spectra come out directly
+                hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, true, true>), dim3(gx), dim3(FPW * N / 16), 0, st,
+                                   in, out, (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
+                return;
+            }
+        }
         hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, true>), dim3(gx), dim3(FPW * N / 16), 0, st, in, out,
                            (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
         return;
@@ -1485,12 +1493,19 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     ARG_TRY(single || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
             "bbt_chan_plan_create: n_stream=%d must be even and >= 2 (or 1 for a power-of-two n_chan "
             "in [256, 4096])", n_stream);
-    ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1 or +1");
+    // direction -2: forward transform of ONE stream z = a + i b made of two real streams, writing their
+    // half spectra (n_spectra, n_chan / 2 + 1, 2) instead of Z (Channelize of float32 streams in one pass)
+    const bool split_real = direction == -2;
+    ARG_TRY(!split_real || single, "bbt_chan_plan_create: direction -2 needs n_stream = 1 and a "
+            "power-of-two n_chan in [256, 4096]");
+    if (split_real) direction = -1;
+    ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1, +1 or -2");
     bbt_chan_plan* p = new bbt_chan_plan;
     p->n = n_chan;
     p->S = n_stream;
     p->npair = n_stream / 2;
     p->dir = direction;
+    p->split_real = split_real;
     if (!fast) {
         p->generic = true;
         if (!factor_7smooth(n_chan, &p->g) || get_gen_table(n_chan, &p->wn)) {

@@ -41,7 +41,13 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
 // SINGLE (S == 1): the two transforms a thread carries side by side are two
 // consecutive groups of the one stream instead of the two streams of a pair
 // (8-byte loads and stores, fully coalesced; nothing is padded or wasted).
-template <int N, int SIGN, int FPW, bool SINGLE = false>
+// SPLIT (with SINGLE, forward): the one stream is z = a + i b of two real streams;
+// instead of the spectrum Z of z the kernel writes the half spectra of a and b,
+//   A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2i,  k <= n/2,
+// as (transform, k, 2 streams): Z goes through the transform's exchange area once
+// more (real parts, then imaginary parts) so that a thread can pair k with n - k.
+// This is Channelize of float32 streams without the separate pass over the spectra.
+template <int N, int SIGN, int FPW, bool SINGLE = false, bool SPLIT = false>
 __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restrict__ in,
                                                            float2* __restrict__ out, long long n_fft,
                                                            int S, float scale,
@@ -69,6 +75,47 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
             v[j] = c2{v2{a.x, b.x}, v2{a.y, b.y}};
         }
         wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+        if constexpr (SPLIT) {
+            static_assert(SIGN < 0, "the split of real pairs belongs to the forward transform");
+            v2* area = lds + slot * G::LDS_ELEMS;                 // N elements fit (LDS_ELEMS >= N)
+            // k = tau + T j for j < 8 covers 0 .. N/2 - 1; thread 0 also takes k = N/2
+            v2 zk_re[9], zm_re[9], zk_im[9], zm_im[9];
+            __syncthreads();                                      // (the transform's last reads are done)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) area[tau + T * j] = v[j].re;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = tau + T * j;
+                zk_re[j] = area[k];
+                zm_re[j] = area[(N - k) & (N - 1)];
+            }
+            zk_re[8] = zm_re[8] = area[N / 2];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) area[tau + T * j] = v[j].im;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = tau + T * j;
+                zk_im[j] = area[k];
+                zm_im[j] = area[(N - k) & (N - 1)];
+            }
+            zk_im[8] = zm_im[8] = area[N / 2];
+            constexpr int HALF = N / 2 + 1;
+            float4* dst_a = reinterpret_cast<float4*>(out) + 2 * i * HALF;        // (a, b) per k: 16 bytes
+            float4* dst_b = dst_a + HALF;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                if (j == 8 && tau != 0) break;
+                const int k = j < 8 ? tau + T * j : N / 2;
+                const v2 ar = 0.5f * (zk_re[j] + zm_re[j]), ai = 0.5f * (zk_im[j] - zm_im[j]);
+                const v2 br = 0.5f * (zk_im[j] + zm_im[j]), bi = -0.5f * (zk_re[j] - zm_re[j]);
+                if (act_a) dst_a[k] = make_float4(ar.x, ai.x, br.x, bi.x);
+                if (act_b) dst_b[k] = make_float4(ar.y, ai.y, br.y, bi.y);
+            }
+            return;
+        }
         float2* dst = out + (2 * i * N + tau);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {

@@ -81,6 +81,8 @@ class PolyphaseFilterBank(_RowFFTTask):
     frequency, sideband : optional overrides of the stream metadata.
     """
 
+    _SPLIT_IN_TRANSFORM = False      # (the filter bank kernels write full spectra)
+
     def _even(self, count):
         """One stream runs unpadded on the sliding-window kernels (n 256..2048 with
         4, 8, 12 or 16 taps); every other odd count is padded to even."""
