@@ -1835,6 +1835,14 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
             blocks = x[:n_spec * n_chan].reshape(n_spec, n_chan, S).astype(np.complex128)
             want = np.fft.fft(blocks, axis=1) if direction < 0 else np.fft.ifft(blocks, axis=1)
             check_guarded(out, n, (n_spec, n_chan, S), want, f'chan case {case}: n {n_chan} S {S} count {n_spec} dir {direction}')
+        # two real streams as one complex stream, half spectra straight from the transform (direction -2)
+        n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        n_spec = int(rng.choice(counts[:11]))
+        xr = rng.standard_normal((max(n_spec, 1) * n_chan, 2)).astype(np.float32)
+        out, n = guarded((n_spec, n_chan // 2 + 1, 2), np.complex64)
+        hip.ChanPlan(n_chan, 1, -2).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
+        want = np.fft.rfft(xr[:n_spec * n_chan].astype(np.float64).reshape(n_spec, n_chan, 2), axis=1)
+        check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2), want, f'real pair case {case}: n {n_chan} count {n_spec}')
         # polyphase filter bank
         n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
         n_tap = int(rng.integers(1, 17))
