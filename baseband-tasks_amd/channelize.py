@@ -103,7 +103,7 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
             # two real streams = one complex stream: the transform kernel pairs k with n - k
             # itself and writes the half spectra (no separate pass over the spectra)
             if self._pair_plan is None:
-                self._pair_plan = hip.ChanPlan(self._n, 1, -2)
+                self._pair_plan = self._make_split_plan()
             self._pair_plan.execute(x, out, n_spectra)
             return
         if self._pair_plan is None:
@@ -116,6 +116,10 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
 
     def _make_plan(self, n_stream_even):
         return hip.ChanPlan(self._n, n_stream_even, self._direction)
+
+    def _make_split_plan(self):
+        """Plan that takes z = a + i b of two real streams and writes their half spectra."""
+        return hip.ChanPlan(self._n, 1, -2)
 
     def _run(self, x, n_spectra, out_flat):
         """x: (n_spectra * n, S) -> out_flat: (n_spectra * n, S)."""

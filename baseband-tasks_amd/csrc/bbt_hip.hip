@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 126
+#define BBT_VERSION 127
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1558,8 +1558,10 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
             }
             continue;
         }
+        // (half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum on the output side)
+        const int64_t out_off = p->split_real ? s0 * (p->n / 2 + 1) * 2 : off;
         int rc = (p->dir < 0)
-                     ? chan_dispatch<-1>(p, in + off, out + off, ns, 1.0f, (hipStream_t)stream)
+                     ? chan_dispatch<-1>(p, in + off, out + out_off, ns, 1.0f, (hipStream_t)stream)
                      : chan_dispatch<+1>(p, in + off, out + off, ns, 1.0f / (float)p->n,
                                          (hipStream_t)stream);
         if (rc) return rc;
@@ -1574,6 +1576,7 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
 // polyphase filter bank
 struct bbt_pfb_plan {
     int n = 0, S = 0, npair = 0, n_tap = 0;
+    bool split_real = false;    // n_stream -1: one stream z = a + i b of two real streams, half spectra out
     float* taps = nullptr;
     FftTables tab;
     FftTables tab4096;   // for the sliding-window kernel
@@ -1586,8 +1589,12 @@ static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* o
     constexpr int NG = 4096 / N;
     if (p->S == 1) {            // one stream: two groups of NG spectra side by side
         const unsigned gx = (unsigned)((n_spec + 2 * NG - 1) / (2 * NG));
-        hipLaunchKernelGGL((k_pfb_window<N, NTAP, true>), dim3(gx), dim3(256), 0, st, in, out,
-                           (long long)n_spec, 1, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+        if (p->split_real)
+            hipLaunchKernelGGL((k_pfb_window<N, NTAP, true, true>), dim3(gx), dim3(256), 0, st, in, out,
+                               (long long)n_spec, 1, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+        else
+            hipLaunchKernelGGL((k_pfb_window<N, NTAP, true>), dim3(gx), dim3(256), 0, st, in, out,
+                               (long long)n_spec, 1, p->taps, p->tab4096.tw0, p->tab4096.tw1);
         return;
     }
     const unsigned gx = (unsigned)((n_spec + NG - 1) / NG);
@@ -1629,9 +1636,14 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     ARG_TRY(fft_len_ok(n_chan),
             "bbt_pfb_plan_create: n_chan=%d must be a power of two in [256, 4096]", n_chan);
     ARG_TRY(n_tap >= 1 && n_tap <= 64, "bbt_pfb_plan_create: n_tap=%d must be in [1, 64]", n_tap);
+    // n_stream -1: as 1, the stream being z = a + i b of two real streams; out receives their half
+    // spectra (n_spectra, n_chan / 2 + 1, 2) -- the filter bank of two float32 streams in one pass
+    const bool split_real = n_stream == -1;
+    if (split_real) n_stream = 1;
     ARG_TRY(n_stream == 1 || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
             "bbt_pfb_plan_create: n_stream=%d must be even and >= 2", n_stream);
     bbt_pfb_plan* p = new bbt_pfb_plan;
+    p->split_real = split_real;
     p->n = n_chan;
     p->S = n_stream;
     p->npair = n_stream / 2;
@@ -1675,8 +1687,10 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
         const int64_t off = s0 * p->n * p->S;
         hipStream_t st = (hipStream_t)stream;
         if (p->window) {
-            // input of slab s0 starts at spectrum s0 (same offset as the output)
-            pfb_window_dispatch(p, in + off, out + off, ns, st, false);
+            // input of slab s0 starts at spectrum s0 (same offset as the output, except
+            // for half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum)
+            const int64_t out_off = p->split_real ? s0 * (p->n / 2 + 1) * 2 : off;
+            pfb_window_dispatch(p, in + off, out + out_off, ns, st, false);
             continue;
         }
         switch (p->n) {

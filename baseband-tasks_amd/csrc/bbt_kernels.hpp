@@ -1216,7 +1216,9 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
 #endif
 // SINGLE (S == 1): the two transforms side by side are the workgroup's spectra
 // [i0, i0 + NG) and [i0 + NG, i0 + 2 NG) of the one stream (rows NG further on).
-template <int N, int NTAP, bool SINGLE = false>
+// SPLIT (with SINGLE): the one stream is z = a + i b of two real streams and the
+// half spectra of a and b are written, as in k_fft_rows.
+template <int N, int NTAP, bool SINGLE = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ in,
                                                     float2* __restrict__ out, long long n_spec,
                                                     int S, const float* __restrict__ taps,
@@ -1317,6 +1319,48 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
     wg_fft_tail<4096, -1, 0>(v, lds, tau, 0, tw1);
     const int f = tau & 15, g = tau >> 4;
     const int q = f / P, c = f - q * P;
+    if constexpr (SINGLE && SPLIT) {
+        // the NG spectra of each half of the pair through the exchange area (real parts, then
+        // imaginary parts) at [q N + k]; then channel k meets N - k of the same spectrum
+        constexpr int HALF = N / 2 + 1, PER = N / 2;          // outputs per spectrum handled in the main loop
+        v2 zk_re[8], zm_re[8], zk_im[8], zm_im[8], ny_re, ny_im;
+        __syncthreads();
+#pragma unroll
+        for (int c2i = 0; c2i < 16; ++c2i) lds[q * N + c + P * (g + 16 * c2i)] = v[c2i].re;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tau + 256 * j, qq = idx / PER, k = idx - qq * PER;
+            zk_re[j] = lds[qq * N + k];
+            zm_re[j] = lds[qq * N + ((N - k) & (N - 1))];
+        }
+        ny_re = lds[(tau & (NG - 1)) * N + N / 2];
+        __syncthreads();
+#pragma unroll
+        for (int c2i = 0; c2i < 16; ++c2i) lds[q * N + c + P * (g + 16 * c2i)] = v[c2i].im;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tau + 256 * j, qq = idx / PER, k = idx - qq * PER;
+            zk_im[j] = lds[qq * N + k];
+            zm_im[j] = lds[qq * N + ((N - k) & (N - 1))];
+        }
+        ny_im = lds[(tau & (NG - 1)) * N + N / 2];
+        float4* spectra = reinterpret_cast<float4*>(out);      // (spectrum, k) -> (a, b): 16 bytes
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j == 8 && tau >= NG) break;
+            const int idx = tau + 256 * j;
+            const int qq = j < 8 ? idx / PER : tau, k = j < 8 ? idx - qq * PER : N / 2;
+            const v2 kr = j < 8 ? zk_re[j] : ny_re, mr = j < 8 ? zm_re[j] : ny_re;
+            const v2 ki = j < 8 ? zk_im[j] : ny_im, mi = j < 8 ? zm_im[j] : ny_im;
+            const v2 ar = 0.5f * (kr + mr), ai = 0.5f * (ki - mi), br = 0.5f * (ki + mi), bi = -0.5f * (kr - mr);
+            const long long sa = i0 + qq, sb = i0 + NG + qq;
+            if (sa < n_spec) spectra[sa * HALF + k] = make_float4(ar.x, ai.x, br.x, bi.x);
+            if (sb < n_spec) spectra[sb * HALF + k] = make_float4(ar.y, ai.y, br.y, bi.y);
+        }
+        return;
+    }
     if constexpr (SINGLE) {
         float2* dst = out + ((i0 + q) * N + c);
         const bool act_a = i0 + q < n_spec, act_b = i0 + NG + q < n_spec;

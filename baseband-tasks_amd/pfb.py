@@ -81,7 +81,6 @@ class PolyphaseFilterBank(_RowFFTTask):
     frequency, sideband : optional overrides of the stream metadata.
     """
 
-    _SPLIT_IN_TRANSFORM = False      # (the filter bank kernels write full spectra)
 
     def _even(self, count):
         """One stream runs unpadded on the sliding-window kernels (n 256..2048 with
@@ -130,6 +129,9 @@ class PolyphaseFilterBank(_RowFFTTask):
         if self._plan is None:
             self._plan = self._make_plan(self._n_stream_even)
         return self._plan
+
+    def _make_split_plan(self):
+        return hip.PfbPlan(self._response, -1)
 
     def _make_plan(self, n_stream_even):
         if self._n < 256:

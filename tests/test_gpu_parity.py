@@ -1843,6 +1843,18 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         hip.ChanPlan(n_chan, 1, -2).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
         want = np.fft.rfft(xr[:n_spec * n_chan].astype(np.float64).reshape(n_spec, n_chan, 2), axis=1)
         check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2), want, f'real pair case {case}: n {n_chan} count {n_spec}')
+        # ... and the same for the filter bank's sliding-window kernels (n_stream -1)
+        n_chan = int(rng.choice([256, 512, 1024, 2048]))
+        n_tap = int(rng.choice([4, 8, 12, 16]))
+        n_spec = int(rng.choice(counts[:11]))
+        taps = rng.standard_normal((n_tap, n_chan)).astype(np.float32)
+        xr = rng.standard_normal(((max(n_spec, 1) + n_tap - 1) * n_chan, 2)).astype(np.float32)
+        out, n = guarded((n_spec, n_chan // 2 + 1, 2), np.complex64)
+        hip.PfbPlan(taps, -1).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
+        blocks = xr.reshape(-1, n_chan, 2).astype(np.float64)
+        acc = sum(blocks[t:t + n_spec] * taps[t].astype(np.float64)[:, None] for t in range(n_tap))
+        check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2), np.fft.rfft(acc, axis=1) if n_spec else acc,
+                      f'real pair pfb case {case}: n {n_chan} taps {n_tap} count {n_spec}')
         # polyphase filter bank
         n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
         n_tap = int(rng.integers(1, 17))
