@@ -320,6 +320,13 @@ class Dechannelize(_RowFFTTask):
 
     def _spectra_to_stream(self, x, n_spectra, out):
         n, s = self._n, self._n_stream
+        if self._real and self._pairs() == 1 and self._even(1) == 1:
+            # half spectra of two real streams -> z = a + i b in one pass (the kernel mirrors k > n/2)
+            if self._pair_plan is None:
+                self._pair_plan = hip.ChanPlan(n, 1, +2)
+            self._pair_plan.execute(x, hip.DeviceArray((n_spectra * n, 1), np.complex64, ptr=out.ptr, owner=out),
+                                    n_spectra)
+            return
         if self._real and self._pairs():
             p = self._pairs()
             z = hip.merge_real_pair_spectra(x, n, s, hip.DeviceArray((n_spectra * n, p), np.complex64))

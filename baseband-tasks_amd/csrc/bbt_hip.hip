@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 127
+#define BBT_VERSION 128
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1443,12 +1443,10 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
     constexpr int FPW = (N >= 1024) ? (4096 / N >= 4 ? 4 : 4096 / N) : (N == 512 ? 8 : 16);
     if (p->S == 1) {            // one stream: two consecutive transforms side by side
         const unsigned gx = (unsigned)(((n_fft + 1) / 2 + FPW - 1) / FPW);
-        if constexpr (SIGN < 0) {
-            if (p->split_real) {    // ... of two real streams: their half spectra come out directly
-                hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, true, true>), dim3(gx), dim3(FPW * N / 16), 0, st,
-                                   in, out, (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
-                return;
-            }
+        if (p->split_real) {    // ... of two real streams: half spectra out (forward) / in (inverse)
+            hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, true, true>), dim3(gx), dim3(FPW * N / 16), 0, st,
+                               in, out, (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
+            return;
         }
         hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, true>), dim3(gx), dim3(FPW * N / 16), 0, st, in, out,
                            (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
@@ -1495,11 +1493,12 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
             "in [256, 4096])", n_stream);
     // direction -2: forward transform of ONE stream z = a + i b made of two real streams, writing their
     // half spectra (n_spectra, n_chan / 2 + 1, 2) instead of Z (Channelize of float32 streams in one pass)
-    const bool split_real = direction == -2;
-    ARG_TRY(!split_real || single, "bbt_chan_plan_create: direction -2 needs n_stream = 1 and a "
+    // (+2: the inverse -- half spectra of two real streams in, z = a + i b out)
+    const bool split_real = direction == -2 || direction == 2;
+    ARG_TRY(!split_real || single, "bbt_chan_plan_create: direction -2 / +2 needs n_stream = 1 and a "
             "power-of-two n_chan in [256, 4096]");
-    if (split_real) direction = -1;
-    ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1, +1 or -2");
+    if (split_real) direction /= 2;
+    ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1, +1, -2 or +2");
     bbt_chan_plan* p = new bbt_chan_plan;
     p->n = n_chan;
     p->S = n_stream;
@@ -1558,12 +1557,13 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
             }
             continue;
         }
-        // (half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum on the output side)
-        const int64_t out_off = p->split_real ? s0 * (p->n / 2 + 1) * 2 : off;
+        // (half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum on that side)
+        const int64_t half_off = s0 * (p->n / 2 + 1) * 2;
         int rc = (p->dir < 0)
-                     ? chan_dispatch<-1>(p, in + off, out + out_off, ns, 1.0f, (hipStream_t)stream)
-                     : chan_dispatch<+1>(p, in + off, out + off, ns, 1.0f / (float)p->n,
-                                         (hipStream_t)stream);
+                     ? chan_dispatch<-1>(p, in + off, out + (p->split_real ? half_off : off), ns, 1.0f,
+                                         (hipStream_t)stream)
+                     : chan_dispatch<+1>(p, in + (p->split_real ? half_off : off), out + off, ns,
+                                         1.0f / (float)p->n, (hipStream_t)stream);
         if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());

@@ -68,15 +68,33 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
         const bool act_a = 2 * i < n_fft, act_b = 2 * i + 1 < n_fft;
         const float2* src = in + (2 * i * N + tau);
         const float2 zero = make_float2(0.f, 0.f);
+        if constexpr (SPLIT && SIGN > 0) {
+            // the inverse of the split below: the input holds the half spectra (transform, k, 2
+            // streams) of two real streams a, b; Z[k] = A[k] + i B[k] for k <= n/2, and
+            // conj(A[n-k]) + i conj(B[n-k]) above (imaginary parts of DC and Nyquist ignored, as
+            // irfft does) -- Dechannelize to two float32 streams without a separate merge pass
+            constexpr int HALF = N / 2 + 1;
+            const float4* half_a = reinterpret_cast<const float4*>(in) + 2 * i * HALF;
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float2 a = act_a ? src[T * j] : zero;
-            const float2 b = act_b ? src[N + T * j] : zero;
-            v[j] = c2{v2{a.x, b.x}, v2{a.y, b.y}};
+            for (int j = 0; j < 16; ++j) {
+                const int k = tau + T * j, kk = k <= N / 2 ? k : N - k;
+                float4 pa = act_a ? half_a[kk] : zero4, pb = act_b ? half_a[HALF + kk] : zero4;   // (A.re A.im B.re B.im)
+                if (kk == 0 || 2 * kk == N) pa.y = pa.w = pb.y = pb.w = 0.f;
+                const float sg = k <= N / 2 ? 1.f : -1.f;
+                // upper: (A.re - B.im, A.im + B.re); lower (mirror): (A.re + B.im, B.re - A.im)
+                v[j] = c2{v2{pa.x - sg * pa.w, pb.x - sg * pb.w}, v2{pa.z + sg * pa.y, pb.z + sg * pb.y}};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 a = act_a ? src[T * j] : zero;
+                const float2 b = act_b ? src[N + T * j] : zero;
+                v[j] = c2{v2{a.x, b.x}, v2{a.y, b.y}};
+            }
         }
         wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
-        if constexpr (SPLIT) {
-            static_assert(SIGN < 0, "the split of real pairs belongs to the forward transform");
+        if constexpr (SPLIT && SIGN < 0) {
             v2* area = lds + slot * G::LDS_ELEMS;                 // N elements fit (LDS_ELEMS >= N)
             // k = tau + T j for j < 8 covers 0 .. N/2 - 1; thread 0 also takes k = N/2
             v2 zk_re[9], zm_re[9], zk_im[9], zm_im[9];

@@ -1843,6 +1843,14 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         hip.ChanPlan(n_chan, 1, -2).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
         want = np.fft.rfft(xr[:n_spec * n_chan].astype(np.float64).reshape(n_spec, n_chan, 2), axis=1)
         check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2), want, f'real pair case {case}: n {n_chan} count {n_spec}')
+        # ... and back (direction +2): half spectra in, the two real streams out as one complex stream
+        half = (rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2))
+                + 1j * rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2))).astype(np.complex64)
+        out, n = guarded((n_spec * n_chan,), np.complex64)
+        hip.ChanPlan(n_chan, 1, +2).execute(hip.DeviceArray.from_host(half), out, n_spec)
+        back = np.fft.irfft(half[:n_spec].astype(np.complex128), n=n_chan, axis=1)          # (n_spec, n_chan, 2) real
+        check_guarded(out, n, (n_spec * n_chan,), (back[..., 0] + 1j * back[..., 1]).reshape(-1),
+                      f'real pair inverse case {case}: n {n_chan} count {n_spec}')
         # ... and the same for the filter bank's sliding-window kernels (n_stream -1)
         n_chan = int(rng.choice([256, 512, 1024, 2048]))
         n_tap = int(rng.choice([4, 8, 12, 16]))
