@@ -1,7 +1,7 @@
 #!/bin/bash
 # final job of the round: suite, profiles of every config, bench lines
 set -o pipefail
-TAG=${TAG:-r02r}
+TAG=${TAG:-r02s}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
