@@ -99,11 +99,11 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
         spectra directly."""
         p = self._pairs()
         pe = self._even(p)
-        if p == 1 and pe == 1 and self._SPLIT_IN_TRANSFORM:
-            # two real streams = one complex stream: the transform kernel pairs k with n - k
+        if self._SPLIT_IN_TRANSFORM and pe == p and self._split_plan_ok(p):
+            # pairs of real streams = complex streams: the transform kernel pairs k with n - k
             # itself and writes the half spectra (no separate pass over the spectra)
             if self._pair_plan is None:
-                self._pair_plan = self._make_split_plan()
+                self._pair_plan = self._make_split_plan(p)
             self._pair_plan.execute(x, out, n_spectra)
             return
         if self._pair_plan is None:
@@ -117,9 +117,12 @@ class _RowFFTTask(DeviceTaskMixin, TaskBase):
     def _make_plan(self, n_stream_even):
         return hip.ChanPlan(self._n, n_stream_even, self._direction)
 
-    def _make_split_plan(self):
-        """Plan that takes z = a + i b of two real streams and writes their half spectra."""
-        return hip.ChanPlan(self._n, 1, -2)
+    def _split_plan_ok(self, p):
+        return 256 <= self._n <= 4096 and not self._n & (self._n - 1)
+
+    def _make_split_plan(self, p):
+        """Plan that takes streams z = a + i b of two real streams each and writes their half spectra."""
+        return hip.ChanPlan(self._n, p, -2)
 
     def _run(self, x, n_spectra, out_flat):
         """x: (n_spectra * n, S) -> out_flat: (n_spectra * n, S)."""

@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 128
+#define BBT_VERSION 129
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1453,6 +1453,13 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
         return;
     }
     const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
+    if constexpr (SIGN < 0) {
+        if (p->split_real) {        // every stream z = a + i b of two real streams: half spectra out
+            hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, false, true>), dim3(gx * p->npair), dim3(FPW * N / 16), 0,
+                               st, in, out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW>), dim3(gx * p->npair), dim3(FPW * N / 16), 0, st, in,
                        out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
 }
@@ -1495,8 +1502,8 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     // half spectra (n_spectra, n_chan / 2 + 1, 2) instead of Z (Channelize of float32 streams in one pass)
     // (+2: the inverse -- half spectra of two real streams in, z = a + i b out)
     const bool split_real = direction == -2 || direction == 2;
-    ARG_TRY(!split_real || single, "bbt_chan_plan_create: direction -2 / +2 needs n_stream = 1 and a "
-            "power-of-two n_chan in [256, 4096]");
+    ARG_TRY(!split_real || (fast && n_chan >= 256 && (single || direction == -2)),
+            "bbt_chan_plan_create: direction -2 needs a power-of-two n_chan in [256, 4096]; +2 also n_stream = 1");
     if (split_real) direction /= 2;
     ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1, +1, -2 or +2");
     bbt_chan_plan* p = new bbt_chan_plan;
@@ -1558,7 +1565,7 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
             continue;
         }
         // (half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum on that side)
-        const int64_t half_off = s0 * (p->n / 2 + 1) * 2;
+        const int64_t half_off = s0 * (p->n / 2 + 1) * 2 * p->S;
         int rc = (p->dir < 0)
                      ? chan_dispatch<-1>(p, in + off, out + (p->split_real ? half_off : off), ns, 1.0f,
                                          (hipStream_t)stream)

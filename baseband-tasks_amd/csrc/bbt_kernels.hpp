@@ -157,6 +157,49 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
         for (int j = 0; j < 16; ++j) v[j] = czero();
     }
     wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    if constexpr (SPLIT && SIGN < 0) {
+        // Stream pairs, each stream z = a + i b of two real streams (S complex = 2 S real streams):
+        // the half spectra of all of them, (transform, k, 2 S reals), as in the one-stream case above.
+        v2* area = lds + slot * G::LDS_ELEMS;
+        v2 zk_re[9], zm_re[9], zk_im[9], zm_im[9];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) area[tau + T * j] = v[j].re;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = tau + T * j;
+            zk_re[j] = area[k];
+            zm_re[j] = area[(N - k) & (N - 1)];
+        }
+        zk_re[8] = zm_re[8] = area[N / 2];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) area[tau + T * j] = v[j].im;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = tau + T * j;
+            zk_im[j] = area[k];
+            zm_im[j] = area[(N - k) & (N - 1)];
+        }
+        zk_im[8] = zm_im[8] = area[N / 2];
+        if (active) {
+            constexpr int HALF = N / 2 + 1;
+            // per (transform, k): S float4, one per complex stream; this pair's two are adjacent
+            float4* dst = reinterpret_cast<float4*>(out) + i * HALF * S + 2 * sp;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                if (j == 8 && tau != 0) break;
+                const int k = j < 8 ? tau + T * j : N / 2;
+                const v2 ar = 0.5f * (zk_re[j] + zm_re[j]), ai = 0.5f * (zk_im[j] - zm_im[j]);
+                const v2 br = 0.5f * (zk_im[j] + zm_im[j]), bi = -0.5f * (zk_re[j] - zm_re[j]);
+                dst[(long long)k * S] = make_float4(ar.x, ai.x, br.x, bi.x);
+                dst[(long long)k * S + 1] = make_float4(ar.y, ai.y, br.y, bi.y);
+            }
+        }
+        return;
+    }
     if (active) {
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll

@@ -101,7 +101,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 128
+MIN_LIB_VERSION = 129
 
 _lib = None
 _lock = threading.Lock()

@@ -130,7 +130,10 @@ class PolyphaseFilterBank(_RowFFTTask):
             self._plan = self._make_plan(self._n_stream_even)
         return self._plan
 
-    def _make_split_plan(self):
+    def _split_plan_ok(self, p):
+        return p == 1 and self._even(1) == 1          # the sliding-window kernels, one pair
+
+    def _make_split_plan(self, p):
         return hip.PfbPlan(self._response, -1)
 
     def _make_plan(self, n_stream_even):

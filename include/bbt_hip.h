@@ -220,9 +220,9 @@ int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
  * channelize.py:164-165).  n_chan a power of two, 2..4096 (fast path), or
  * any 2^a 3^b 5^c 7^d <= 8192.  n_stream even, or 1 for a power-of-two n_chan
  * in [256, 4096] (one stream: two consecutive groups are transformed side by
- * side, nothing is padded).  direction -2 (with n_stream = 1): the stream is
- * z = a + i b of two real streams and out receives their half spectra,
- * (n_spectra, n_chan/2 + 1, 2) -- Channelize of two float32 streams in one pass;
+ * side, nothing is padded).  direction -2: every stream is z = a + i b of two
+ * real streams and out receives their half spectra, (n_spectra, n_chan/2 + 1,
+ * 2 n_stream) -- Channelize of float32 streams in one pass;
  * direction +2 is its inverse (half spectra in, z out, scaled by 1/n_chan). */
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction);
 int bbt_chan_plan_destroy(bbt_chan_plan* plan);

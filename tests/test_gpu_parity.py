@@ -1838,11 +1838,13 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         # two real streams as one complex stream, half spectra straight from the transform (direction -2)
         n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
         n_spec = int(rng.choice(counts[:11]))
-        xr = rng.standard_normal((max(n_spec, 1) * n_chan, 2)).astype(np.float32)
-        out, n = guarded((n_spec, n_chan // 2 + 1, 2), np.complex64)
-        hip.ChanPlan(n_chan, 1, -2).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
-        want = np.fft.rfft(xr[:n_spec * n_chan].astype(np.float64).reshape(n_spec, n_chan, 2), axis=1)
-        check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2), want, f'real pair case {case}: n {n_chan} count {n_spec}')
+        for pairs in (1, int(rng.choice([2, 4, 6]))):            # complex streams = pairs of real ones
+            xr = rng.standard_normal((max(n_spec, 1) * n_chan, 2 * pairs)).astype(np.float32)
+            out, n = guarded((n_spec, n_chan // 2 + 1, 2 * pairs), np.complex64)
+            hip.ChanPlan(n_chan, pairs, -2).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
+            want = np.fft.rfft(xr[:n_spec * n_chan].astype(np.float64).reshape(n_spec, n_chan, 2 * pairs), axis=1)
+            check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2 * pairs), want,
+                          f'real pair case {case}: n {n_chan} count {n_spec} pairs {pairs}')
         # ... and back (direction +2): half spectra in, the two real streams out as one complex stream
         half = (rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2))
                 + 1j * rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2))).astype(np.complex64)

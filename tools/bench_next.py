@@ -208,6 +208,18 @@ def chan_real_1024(reps):
     return _channelize_row(1024, reps, real=True)
 
 
+def chan_real4_1024(reps):
+    n_chan, n = 1024, 2**27
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    x = torch.randn((n, 2, 2), generator=g, device=DEV, dtype=torch.float32)
+    ds = bt.DeviceStream(x, T0, 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
+    ch = bt.Channelize(ds, n_chan, 1024)
+    dt = timed(lambda: restart([ch], ch, ch.shape[0]), reps)
+    return dict(units=ch.shape[0] * n_chan, unit='complete samples', bytes_per_unit=16 + 32 * 513 / 1024, seconds=dt,
+                note='Channelize(1024) of 4 float32 streams (2 x 2)')
+
+
 def _pfb_row(n_tap, n_chan, reps, real=False):
     nblk = 192
     if real:
@@ -327,7 +339,7 @@ def chan_single_1024(reps):
 
 
 ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_6000, chan_8192=chan_8192,
-            chan_real_1024=chan_real_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
+            chan_real_1024=chan_real_1024, chan_real4_1024=chan_real4_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
             pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
             dedisperse_single=dedisperse_single, dedisperse_default=dedisperse_default, chan_single_1024=chan_single_1024,
             fused_single=fused_single, fused_real=fused_real,
