@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 129
+#define BBT_VERSION 130
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1605,8 +1605,12 @@ static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* o
         return;
     }
     const unsigned gx = (unsigned)((n_spec + NG - 1) / NG);
-    hipLaunchKernelGGL((k_pfb_window<N, NTAP>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
-                       (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+    if (p->split_real)          // every stream z = a + i b of two real streams: half spectra out
+        hipLaunchKernelGGL((k_pfb_window<N, NTAP, false, true>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
+                           (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+    else
+        hipLaunchKernelGGL((k_pfb_window<N, NTAP>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
+                           (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
 }
 
 // sliding-window variants exist for these (n_chan, n_tap)
@@ -1645,8 +1649,9 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     ARG_TRY(n_tap >= 1 && n_tap <= 64, "bbt_pfb_plan_create: n_tap=%d must be in [1, 64]", n_tap);
     // n_stream -1: as 1, the stream being z = a + i b of two real streams; out receives their half
     // spectra (n_spectra, n_chan / 2 + 1, 2) -- the filter bank of two float32 streams in one pass
-    const bool split_real = n_stream == -1;
-    if (split_real) n_stream = 1;
+    // (a negative even n_stream -S: S such streams, in pairs)
+    const bool split_real = n_stream == -1 || (n_stream < 0 && n_stream % 2 == 0);
+    if (split_real) n_stream = -n_stream;
     ARG_TRY(n_stream == 1 || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
             "bbt_pfb_plan_create: n_stream=%d must be even and >= 2", n_stream);
     bbt_pfb_plan* p = new bbt_pfb_plan;
@@ -1658,7 +1663,7 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     const size_t tb = (size_t)n_tap * n_chan * sizeof(float);
     const char* env = getenv("BBT_PFB_WINDOW");
     p->window = (!env || atoi(env) != 0) && pfb_window_dispatch(p, nullptr, nullptr, 0, nullptr, true);
-    if (n_stream == 1 && !p->window) {          // only the sliding-window kernels take one stream
+    if ((n_stream == 1 || split_real) && !p->window) {   // only the sliding-window kernels take one stream / split
         delete p;
         return fail("bbt_pfb_plan_create: one stream needs n_chan in 256..2048 and 4, 8, 12 or 16 taps "
                     "(got %d x %d); pad to two streams otherwise", n_tap, n_chan);
@@ -1696,7 +1701,7 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
         if (p->window) {
             // input of slab s0 starts at spectrum s0 (same offset as the output, except
             // for half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum)
-            const int64_t out_off = p->split_real ? s0 * (p->n / 2 + 1) * 2 : off;
+            const int64_t out_off = p->split_real ? s0 * (p->n / 2 + 1) * 2 * p->S : off;
             pfb_window_dispatch(p, in + off, out + out_off, ns, st, false);
             continue;
         }

@@ -1422,6 +1422,51 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
         }
         return;
     }
+    if constexpr (!SINGLE && SPLIT) {
+        // stream pairs, each stream z = a + i b of two real streams: the same pairing of k with
+        // N - k; the two halves of the registers are the pair's two streams, same spectra
+        constexpr int HALF = N / 2 + 1, PER = N / 2;
+        v2 zk_re[8], zm_re[8], zk_im[8], zm_im[8], ny_re, ny_im;
+        __syncthreads();
+#pragma unroll
+        for (int c2i = 0; c2i < 16; ++c2i) lds[q * N + c + P * (g + 16 * c2i)] = v[c2i].re;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tau + 256 * j, qq = idx / PER, k = idx - qq * PER;
+            zk_re[j] = lds[qq * N + k];
+            zm_re[j] = lds[qq * N + ((N - k) & (N - 1))];
+        }
+        ny_re = lds[(tau & (NG - 1)) * N + N / 2];
+        __syncthreads();
+#pragma unroll
+        for (int c2i = 0; c2i < 16; ++c2i) lds[q * N + c + P * (g + 16 * c2i)] = v[c2i].im;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tau + 256 * j, qq = idx / PER, k = idx - qq * PER;
+            zk_im[j] = lds[qq * N + k];
+            zm_im[j] = lds[qq * N + ((N - k) & (N - 1))];
+        }
+        ny_im = lds[(tau & (NG - 1)) * N + N / 2];
+        float4* spectra = reinterpret_cast<float4*>(out) + 2 * sp;       // (spectrum, k, S complex streams)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j == 8 && tau >= NG) break;
+            const int idx = tau + 256 * j;
+            const int qq = j < 8 ? idx / PER : tau, k = j < 8 ? idx - qq * PER : N / 2;
+            const v2 kr = j < 8 ? zk_re[j] : ny_re, mr = j < 8 ? zm_re[j] : ny_re;
+            const v2 ki = j < 8 ? zk_im[j] : ny_im, mi = j < 8 ? zm_im[j] : ny_im;
+            const v2 ar = 0.5f * (kr + mr), ai = 0.5f * (ki - mi), br = 0.5f * (ki + mi), bi = -0.5f * (kr - mr);
+            const long long sa = i0 + qq;
+            if (sa < n_spec) {
+                float4* dst = spectra + (sa * HALF + k) * S;
+                dst[0] = make_float4(ar.x, ai.x, br.x, bi.x);
+                dst[1] = make_float4(ar.y, ai.y, br.y, bi.y);
+            }
+        }
+        return;
+    }
     if constexpr (SINGLE) {
         float2* dst = out + ((i0 + q) * N + c);
         const bool act_a = i0 + q < n_spec, act_b = i0 + NG + q < n_spec;

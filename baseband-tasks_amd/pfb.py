@@ -131,10 +131,10 @@ class PolyphaseFilterBank(_RowFFTTask):
         return self._plan
 
     def _split_plan_ok(self, p):
-        return p == 1 and self._even(1) == 1          # the sliding-window kernels, one pair
+        return self._even(1) == 1                     # (taps, channels) of the sliding-window kernels
 
     def _make_split_plan(self, p):
-        return hip.PfbPlan(self._response, -1)
+        return hip.PfbPlan(self._response, -p)
 
     def _make_plan(self, n_stream_even):
         if self._n < 256:

@@ -235,9 +235,9 @@ int bbt_chan_execute(bbt_chan_plan* plan, const void* in_dev, void* out_dev, int
  * taps[t, c] ).  Reads (n_spectra + n_tap - 1) * n_chan input samples.
  * taps: host float32 (n_tap, n_chan).  n_stream even, or 1 for n_chan in
  * 256..2048 with 4, 8, 12 or 16 taps (the sliding-window kernels: two groups of
- * spectra of the one stream side by side); n_stream -1: as 1 with the stream
- * z = a + i b made of two real streams, out receiving their half spectra
- * (n_spectra, n_chan/2 + 1, 2). */
+ * spectra of the one stream side by side); n_stream -S (S = 1 or even): S
+ * streams z = a + i b made of two real streams each, out receiving their half
+ * spectra (n_spectra, n_chan/2 + 1, 2 S) (sliding-window kernels only). */
 int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream,
                         const float* taps_host);
 int bbt_pfb_plan_destroy(bbt_pfb_plan* plan);

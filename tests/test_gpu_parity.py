@@ -1858,13 +1858,14 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         n_tap = int(rng.choice([4, 8, 12, 16]))
         n_spec = int(rng.choice(counts[:11]))
         taps = rng.standard_normal((n_tap, n_chan)).astype(np.float32)
-        xr = rng.standard_normal(((max(n_spec, 1) + n_tap - 1) * n_chan, 2)).astype(np.float32)
-        out, n = guarded((n_spec, n_chan // 2 + 1, 2), np.complex64)
-        hip.PfbPlan(taps, -1).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
-        blocks = xr.reshape(-1, n_chan, 2).astype(np.float64)
-        acc = sum(blocks[t:t + n_spec] * taps[t].astype(np.float64)[:, None] for t in range(n_tap))
-        check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2), np.fft.rfft(acc, axis=1) if n_spec else acc,
-                      f'real pair pfb case {case}: n {n_chan} taps {n_tap} count {n_spec}')
+        for pairs in (1, int(rng.choice([2, 4]))):
+            xr = rng.standard_normal(((max(n_spec, 1) + n_tap - 1) * n_chan, 2 * pairs)).astype(np.float32)
+            out, n = guarded((n_spec, n_chan // 2 + 1, 2 * pairs), np.complex64)
+            hip.PfbPlan(taps, -pairs).execute(hip.DeviceArray.from_host(xr.view(np.complex64)), out, n_spec)
+            blocks = xr.reshape(-1, n_chan, 2 * pairs).astype(np.float64)
+            acc = sum(blocks[t:t + n_spec] * taps[t].astype(np.float64)[:, None] for t in range(n_tap))
+            check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2 * pairs), np.fft.rfft(acc, axis=1) if n_spec else acc,
+                          f'real pair pfb case {case}: n {n_chan} taps {n_tap} count {n_spec} pairs {pairs}')
         # polyphase filter bank
         n_chan = int(rng.choice([256, 512, 1024, 2048, 4096]))
         n_tap = int(rng.integers(1, 17))
