@@ -323,11 +323,12 @@ class Dechannelize(_RowFFTTask):
 
     def _spectra_to_stream(self, x, n_spectra, out):
         n, s = self._n, self._n_stream
-        if self._real and self._pairs() == 1 and self._even(1) == 1:
-            # half spectra of two real streams -> z = a + i b in one pass (the kernel mirrors k > n/2)
+        p = self._pairs() if self._real else 0
+        if p and self._even(p) == p and 256 <= n <= 4096 and not n & (n - 1):
+            # half spectra of pairs of real streams -> streams z = a + i b in one pass (the kernel mirrors k > n/2)
             if self._pair_plan is None:
-                self._pair_plan = hip.ChanPlan(n, 1, +2)
-            self._pair_plan.execute(x, hip.DeviceArray((n_spectra * n, 1), np.complex64, ptr=out.ptr, owner=out),
+                self._pair_plan = hip.ChanPlan(n, p, +2)
+            self._pair_plan.execute(x, hip.DeviceArray((n_spectra * n, p), np.complex64, ptr=out.ptr, owner=out),
                                     n_spectra)
             return
         if self._real and self._pairs():

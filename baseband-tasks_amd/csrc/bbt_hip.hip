@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 130
+#define BBT_VERSION 131
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1453,12 +1453,10 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
         return;
     }
     const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
-    if constexpr (SIGN < 0) {
-        if (p->split_real) {        // every stream z = a + i b of two real streams: half spectra out
-            hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, false, true>), dim3(gx * p->npair), dim3(FPW * N / 16), 0,
-                               st, in, out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
-            return;
-        }
+    if (p->split_real) {            // every stream z = a + i b of two real streams: half spectra out / in
+        hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, false, true>), dim3(gx * p->npair), dim3(FPW * N / 16), 0,
+                           st, in, out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
+        return;
     }
     hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW>), dim3(gx * p->npair), dim3(FPW * N / 16), 0, st, in,
                        out, (long long)n_fft, p->S, scale, p->tab.tw0, p->tab.tw1);
@@ -1502,8 +1500,8 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     // half spectra (n_spectra, n_chan / 2 + 1, 2) instead of Z (Channelize of float32 streams in one pass)
     // (+2: the inverse -- half spectra of two real streams in, z = a + i b out)
     const bool split_real = direction == -2 || direction == 2;
-    ARG_TRY(!split_real || (fast && n_chan >= 256 && (single || direction == -2)),
-            "bbt_chan_plan_create: direction -2 needs a power-of-two n_chan in [256, 4096]; +2 also n_stream = 1");
+    ARG_TRY(!split_real || (fast && n_chan >= 256),
+            "bbt_chan_plan_create: direction -2 / +2 needs a power-of-two n_chan in [256, 4096]");
     if (split_real) direction /= 2;
     ARG_TRY(direction == -1 || direction == 1, "bbt_chan_plan_create: direction must be -1, +1, -2 or +2");
     bbt_chan_plan* p = new bbt_chan_plan;

@@ -143,7 +143,20 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
         return;
     }
     const bool active = i < n_fft;
-    if (active) {
+    if constexpr (SPLIT && SIGN > 0) {
+        // inverse of the pair-mode split: half spectra (transform, k, 2 S reals) in, S streams z = a + i b out
+        constexpr int HALF = N / 2 + 1;
+        const float4* half = reinterpret_cast<const float4*>(in) + i * HALF * S + 2 * sp;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = tau + T * j, kk = k <= N / 2 ? k : N - k;
+            float4 p0 = active ? half[(long long)kk * S] : zero4, p1 = active ? half[(long long)kk * S + 1] : zero4;
+            if (kk == 0 || 2 * kk == N) p0.y = p0.w = p1.y = p1.w = 0.f;
+            const float sg = k <= N / 2 ? 1.f : -1.f;
+            v[j] = c2{v2{p0.x - sg * p0.w, p1.x - sg * p1.w}, v2{p0.z + sg * p0.y, p1.z + sg * p1.y}};
+        }
+    } else if (active) {
         const float2* src = in + ((i * N + tau) * S + 2 * sp);
         if (S == 2) {
 #pragma unroll

@@ -101,7 +101,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 130
+MIN_LIB_VERSION = 131
 
 _lib = None
 _lock = threading.Lock()

@@ -223,7 +223,7 @@ int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
  * side, nothing is padded).  direction -2: every stream is z = a + i b of two
  * real streams and out receives their half spectra, (n_spectra, n_chan/2 + 1,
  * 2 n_stream) -- Channelize of float32 streams in one pass;
- * direction +2 is its inverse (half spectra in, z out, scaled by 1/n_chan). */
+ * direction +2 is its inverse (half spectra in, the streams z out, scaled by 1/n_chan). */
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction);
 int bbt_chan_plan_destroy(bbt_chan_plan* plan);
 int bbt_chan_execute(bbt_chan_plan* plan, const void* in_dev, void* out_dev, int64_t n_spectra,

@@ -1846,13 +1846,14 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
             check_guarded(out, n, (n_spec, n_chan // 2 + 1, 2 * pairs), want,
                           f'real pair case {case}: n {n_chan} count {n_spec} pairs {pairs}')
         # ... and back (direction +2): half spectra in, the two real streams out as one complex stream
-        half = (rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2))
-                + 1j * rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2))).astype(np.complex64)
-        out, n = guarded((n_spec * n_chan,), np.complex64)
-        hip.ChanPlan(n_chan, 1, +2).execute(hip.DeviceArray.from_host(half), out, n_spec)
-        back = np.fft.irfft(half[:n_spec].astype(np.complex128), n=n_chan, axis=1)          # (n_spec, n_chan, 2) real
-        check_guarded(out, n, (n_spec * n_chan,), (back[..., 0] + 1j * back[..., 1]).reshape(-1),
-                      f'real pair inverse case {case}: n {n_chan} count {n_spec}')
+        for pairs in (1, int(rng.choice([2, 4]))):
+            half = (rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2 * pairs))
+                    + 1j * rng.standard_normal((max(n_spec, 1), n_chan // 2 + 1, 2 * pairs))).astype(np.complex64)
+            out, n = guarded((n_spec * n_chan, pairs), np.complex64)
+            hip.ChanPlan(n_chan, pairs, +2).execute(hip.DeviceArray.from_host(half), out, n_spec)
+            back = np.fft.irfft(half[:n_spec].astype(np.complex128), n=n_chan, axis=1)      # (n_spec, n_chan, 2 pairs) real
+            z = (back[..., 0::2] + 1j * back[..., 1::2]).reshape(n_spec * n_chan, pairs)
+            check_guarded(out, n, (n_spec * n_chan, pairs), z, f'real pair inverse case {case}: n {n_chan} count {n_spec} pairs {pairs}')
         # ... and the same for the filter bank's sliding-window kernels (n_stream -1)
         n_chan = int(rng.choice([256, 512, 1024, 2048]))
         n_tap = int(rng.choice([4, 8, 12, 16]))
