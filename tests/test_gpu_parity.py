@@ -980,6 +980,10 @@ def test_fused_detection_matches_stored_spectra(sample_shape, monkeypatch):
             assert got.shape == want_gpu.shape == want.shape and got.dtype == np.float32
             _close(got, want_gpu, rtol=2e-6)
             _close(got, want, rtol=1e-5)
+    # sums with counts (average=False) through the fused route
+    summed = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds, 30.), n_chan, 32)), 64, average=False).read()
+    assert np.all(summed['count'] == 64)
+    _close(summed['data'], 64. * orc.integrate(orc.power(z), 64), rtol=1e-5)
     # a step too short for the fused route (more than 64 bins per workgroup) still works
     it = bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds, 30.), n_chan, 32)), 8)
     assert it.ih.ih.ih._get_plan().detect_bins_max(n_chan, 8) > 64
