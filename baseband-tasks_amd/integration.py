@@ -58,6 +58,8 @@ class Integrate(DeviceTaskMixin, BaseTaskBase):
         if step is None:
             step = ih_n
         try:
+            if isinstance(step, float) and step.is_integer():
+                step = int(step)                # (3.0 samples is 3 samples)
             step = operator.index(step)
         except TypeError:
             raise NotImplementedError("integration over time intervals (non-integer step) is "
