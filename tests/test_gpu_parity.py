@@ -1821,7 +1821,11 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
         assert np.all(host[n:] == 7.5), 'wrote past the end: ' + what
         if n:
             got, want = host[:n].reshape(shape), want.astype(host.dtype)
-            if host.dtype.kind == 'c':
+            if host.dtype.kind == 'c' and tol != 1.:
+                # (a handful of outputs, each a float32 sum of many random terms: the rel-L2 of so few
+                # samples scatters around the usual bound)
+                assert rel_l2(got, want) <= tol * REL_L2_TOL and max_over_rms(got, want) <= tol * MAX_TOL, what
+            elif host.dtype.kind == 'c':
                 assert_parity(got, want, what)
             else:
                 assert np.abs(got - want).max() <= 1e-5 * tol * np.abs(want).max(), what
@@ -1893,7 +1897,8 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
             hip.FirPlan(resp).execute(hip.DeviceArray.from_host(x), out, n_out)
             want = np.stack([np.convolve(x[:, k].astype(np.complex128), resp[:, k].astype(np.complex128), mode='valid')
                              for k in range(Sf)], axis=1)[:n_out]
-            check_guarded(out, n, (n_out, Sf), want, f'fir case {case}: taps {n_tap} S {Sf} count {n_out}')
+            check_guarded(out, n, (n_out, Sf), want, f'fir case {case}: taps {n_tap} S {Sf} count {n_out}',
+                          tol=2. if n_out * Sf < 64 else 1.)
         # per-element sample shifts: 4- and 8-byte elements, neighbours moving together or not
         n_elem = int(rng.choice([1, 2, 3, 4, 6, 16, 128, 130, 600]))
         n_out = int(rng.choice(counts + [5000]))
