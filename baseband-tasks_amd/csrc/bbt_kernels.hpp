@@ -79,9 +79,8 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int k = tau + T * j, kk = k <= N / 2 ? k : N - k;
-                float4 pa = act_a ? half_a[kk] : zero4, pb = act_b ? half_a[HALF + kk] : zero4;   // (A.re A.im B.re B.im)
-                if (kk == 0 || 2 * kk == N) pa.y = pa.w = pb.y = pb.w = 0.f;
-                const float sg = k <= N / 2 ? 1.f : -1.f;
+                const float4 pa = act_a ? half_a[kk] : zero4, pb = act_b ? half_a[HALF + kk] : zero4;   // (A.re A.im B.re B.im)
+                const float sg = (kk == 0 || 2 * kk == N) ? 0.f : (k <= N / 2 ? 1.f : -1.f);     // (0: DC, Nyquist)
                 // upper: (A.re - B.im, A.im + B.re); lower (mirror): (A.re + B.im, B.re - A.im)
                 v[j] = c2{v2{pa.x - sg * pa.w, pb.x - sg * pb.w}, v2{pa.z + sg * pa.y, pb.z + sg * pb.y}};
             }
@@ -151,9 +150,9 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int k = tau + T * j, kk = k <= N / 2 ? k : N - k;
-            float4 p0 = active ? half[(long long)kk * S] : zero4, p1 = active ? half[(long long)kk * S + 1] : zero4;
-            if (kk == 0 || 2 * kk == N) p0.y = p0.w = p1.y = p1.w = 0.f;
-            const float sg = k <= N / 2 ? 1.f : -1.f;
+            const float4 p0 = active ? half[(long long)kk * S] : zero4, p1 = active ? half[(long long)kk * S + 1] : zero4;
+            // +1 / -1 above and below n/2; 0 at DC and Nyquist, whose imaginary parts do not count
+            const float sg = (kk == 0 || 2 * kk == N) ? 0.f : (k <= N / 2 ? 1.f : -1.f);
             v[j] = c2{v2{p0.x - sg * p0.w, p1.x - sg * p1.w}, v2{p0.z + sg * p0.y, p1.z + sg * p1.y}};
         }
     } else if (active) {
