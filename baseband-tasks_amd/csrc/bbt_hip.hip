@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 131
+#define BBT_VERSION 132
 
 // ---------------------------------------------------------------------------
 // errors
@@ -913,7 +913,7 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
     }
     int64_t c = 0;
     for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
-        OsmChunk ch;
+        OsmChunk ch = {};                  // (fields a caller's fill does not set stay 0)
         ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
         for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
         const int l = fork ? (int)(c % p->lanes) : 0;
@@ -1189,6 +1189,36 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
                            blk.valid_count = valid_count[b];
                            blk.shift = 0;
                            blk.index = (int)b;
+                       });
+}
+
+int bbt_osm_execute_flat(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,
+                         const int64_t* in_off, const int64_t* out_elem_off, const int32_t* valid_start,
+                         int32_t first_elem, const int32_t* valid_elems, bbt_stream stream) {
+    const char* who = "bbt_osm_execute_flat";
+    ARG_TRY(p && in_dev && out_dev, "%s: null argument", who);
+    ARG_TRY(!p->generic && !p->single && p->n1 == 1 && p->outer == 1,
+            "%s: only for power-of-two blocks of at most 4096 samples with an even stream count", who);
+    ARG_TRY(n_blocks >= 0 && (n_blocks == 0 || (in_off && out_elem_off && valid_start && valid_elems)),
+            "%s: bad descriptors", who);
+    ARG_TRY(first_elem >= 0 && first_elem < p->S && first_elem % 2 == 0,
+            "%s: first_elem=%d must be an even element of a row of %d", who, first_elem, p->S);
+    for (int64_t b = 0; b < n_blocks; ++b)
+        ARG_TRY(in_off[b] >= 0 && out_elem_off[b] >= 0 && out_elem_off[b] % 2 == 0 && valid_start[b] >= 0 &&
+                    valid_elems[b] >= 0 && valid_elems[b] % 2 == 0 &&
+                    (int64_t)valid_start[b] * p->S + first_elem + valid_elems[b] <= p->n * p->S,
+                "%s: block %lld keeps elements outside the block", who, (long long)b);
+    hipStream_t st = (hipStream_t)stream;
+    SpecOut so = {};
+    PlanCall call(p, st);
+    return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+                       [&](OsmBlock& blk, int64_t b) {
+                           blk.in_off = in_off[b];
+                           blk.out_off = out_elem_off[b];
+                           blk.valid_start = valid_start[b];
+                           blk.valid_count = valid_elems[b];
+                           blk.flat = 1;
+                           blk.flat_sub = first_elem;
                        });
 }
 

@@ -306,6 +306,12 @@ struct OsmBlock {
     int valid_count;    // number of block samples kept
     int shift;          // fused channelizer: circular shift o (see k_osm_rowpass), else 0
     int index;          // fused channelizer: index of the block within the call (seam slots)
+    int flat;           // k_osm_small only: 1 = the kept range is given in ELEMENTS of the (row, stream)
+                        // matrix, not in rows: out_off = element offset in `out` of the first kept
+                        // element, valid_count = kept elements, flat_sub = elements of row valid_start
+                        // that come before the first kept one (InversePolyphaseFilterBank keeps from
+                        // the middle of a row of the block axis)
+    int flat_sub;
 };
 
 // Where the fused channelizer's column pass puts its spectra.
@@ -548,6 +554,14 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
     const cf* h1 = resp + (long long)c1 * N + tau;
     apply_resp<T>(v, h0, h1, c0 == c1);
     wg_fft<N, +1, CM>(v, lds, tau, pl, tw0, tw1);
+    if (blk.flat) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long long e = (long long)(tau + T * j - blk.valid_start) * S + 2 * sp - blk.flat_sub;
+            if (e >= 0 && e < blk.valid_count) st_ext(out + (blk.out_off + e), v[j]);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int r = tau + T * j - blk.valid_start;

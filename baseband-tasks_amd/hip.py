@@ -68,6 +68,7 @@ SIGNATURES = {
     'bbt_osm_plan_fusable': [_vp, _int],
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_prefiltered': [_vp, _vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
+    'bbt_osm_execute_flat': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
     'bbt_osm_execute_channelized_detect': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int,
@@ -101,7 +102,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 131
+MIN_LIB_VERSION = 132
 
 _lib = None
 _lock = threading.Lock()
@@ -554,6 +555,18 @@ class OsmPlan(_Plan):
                                     in_off.ctypes.data_as(_pi64), out_off.ctypes.data_as(_pi64),
                                     valid_start.ctypes.data_as(_pi32),
                                     valid_count.ctypes.data_as(_pi32), _stream))
+
+    def execute_flat(self, in_dev, out_dev, in_off, out_elem_off, valid_start, first_elem, valid_elems):
+        """`execute` with the kept range in elements of the (row, stream) matrix (plans of one
+        kernel: power-of-two n_fft <= 4096): see bbt_osm_execute_flat."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
+        out_elem_off = np.ascontiguousarray(out_elem_off, dtype=np.int64)
+        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
+        valid_elems = np.ascontiguousarray(valid_elems, dtype=np.int32)
+        check(lib().bbt_osm_execute_flat(self._h, in_dev.ptr, out_dev.ptr, in_off.shape[0],
+                                         in_off.ctypes.data_as(_pi64), out_elem_off.ctypes.data_as(_pi64),
+                                         valid_start.ctypes.data_as(_pi32), int(first_elem),
+                                         valid_elems.ctypes.data_as(_pi32), _stream))
 
     def execute_prefiltered(self, fir, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
         """`execute` on blocks that first pass through the direct filter

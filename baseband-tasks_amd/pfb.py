@@ -328,6 +328,16 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         if self._real:
             x = hip.real_to_complex(x)
         x = x.reshape(x.shape[0] // n, n * s)
+        geo = plan.info()
+        n_rows = self._reshape[0]
+        if (not self._real and geo['n1'] == 1 and n_rows <= 4096 and not n_rows & (n_rows - 1)
+                and int(counts.max()) * s < 2**31 and (off * s) % 2 == 0):
+            # one kernel per block: it writes the kept samples -- from the middle of a row of the
+            # block axis on -- straight to their place (no intermediate rows, no copy)
+            flat = out.reshape(out.shape[0], s)
+            plan.execute_flat(x, flat, (starts - in0) // n, (frames * spf - first * spf) * s, keep // n,
+                              off * s, counts * s)
+            return
         tmp = hip.DeviceArray((int(n_blk.sum()), n * s), np.complex64)
         plan.execute(x, tmp, (starts - in0) // n, tmp_off, keep // n, n_blk)
         tmp = tmp.reshape(int(n_blk.sum()) * n, s)

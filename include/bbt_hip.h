@@ -151,6 +151,16 @@ int bbt_osm_plan_fusable(const bbt_osm_plan* plan, int n_chan);
 int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
                     const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
                     const int32_t* valid_count, bbt_stream stream);
+/* bbt_osm_execute with the kept range given in ELEMENTS of the (row, stream)
+ * matrix instead of whole rows, for plans of one kernel (power-of-two n_fft <=
+ * 4096, S even): block b keeps valid_elems[b] elements starting at element
+ * first_elem (even, < S) of row valid_start[b], written contiguously to out_dev
+ * from element out_elem_off[b].  InversePolyphaseFilterBank (pfb.py:255-269) runs
+ * its transform along the block axis with one stream per polyphase phase and
+ * keeps from the middle of a row: ifft(...)[pad_slice] on the flattened frame. */
+int bbt_osm_execute_flat(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
+                         const int64_t* in_off, const int64_t* out_elem_off, const int32_t* valid_start,
+                         int32_t first_elem, const int32_t* valid_elems, bbt_stream stream);
 /* The same with a short FIR in front of every block (Resample / Convolve with a
  * short response feeding Dedisperse): block b reads input
  * samples [in_off[b], in_off[b] + N + n_tap - 1) of `in_dev`, the filter

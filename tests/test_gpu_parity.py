@@ -1655,6 +1655,25 @@ def test_random_block_descriptors_through_the_c_abi():
         got = plain.to_host()
         assert_parity(got[out0:], stream[out0:].astype(np.complex64), 'plain ' + what)
         assert not got[:out0].any()
+        if geo['n1'] == 1 and S > 1 and not n_fft & (n_fft - 1):
+            # the kept range in elements of the (row, stream) matrix (bbt_osm_execute_flat)
+            first_elem = 2 * int(rng.integers(0, S // 2))
+            fvs = rng.integers(0, n_fft // 4, size=n_blocks)
+            room = (n_fft - fvs) * S - first_elem
+            felems = np.array([2 * int(rng.integers(1, r // 2 + 1)) for r in room])
+            foff = 2 * int(rng.integers(0, 8)) + np.concatenate([[0], np.cumsum(felems)[:-1]])
+            flat_out = hip.DeviceArray((int(foff[-1] + felems[-1]) + 6,), np.complex64).fill_bytes(0)
+            plan.execute_flat(x_dev, flat_out, in_off, foff, fvs, first_elem, felems)
+            want_flat = np.zeros(flat_out.shape, np.complex128)
+            for b in range(n_blocks):
+                blk = x[in_off[b]:in_off[b] + n_fft].astype(np.complex128)
+                y = np.fft.ifft(np.fft.fft(blk, axis=0) * h.T, axis=0).reshape(-1)
+                a = fvs[b] * S + first_elem
+                want_flat[foff[b]:foff[b] + felems[b]] = y[a:a + felems[b]]
+            got_flat = flat_out.to_host()
+            keep = want_flat != 0
+            assert_parity(got_flat[keep], want_flat[keep].astype(np.complex64), 'flat ' + what)
+            assert not got_flat[~keep].any()
         if not choices:
             continue
         first = -(-out0 // n_chan)
