@@ -1102,6 +1102,11 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     } else {
         p->work_bytes = per_block * chunk;
     }
+    if (p->n1 == 1 && !getenv("BBT_OSM_CHUNK")) {
+        // one kernel, no work buffer: nothing bounds a launch but the descriptor array
+        chunk = BBT_MAX_CHUNK;
+        while (chunk > 1 && (long long)chunk * p->npair >= (1ll << 31)) --chunk;
+    }
     p->chunk = chunk;
     p->lanes = lanes;
     if (p->n1 == 1) p->work_bytes = 0;        // one kernel, no work buffer
