@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, 'include', 'bbt_hip.h')).read()
+    with open(os.path.join(ROOT, 'include', 'bbt_hip.h')) as f:
+        text = f.read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(bbt_[a-z0-9_]+)\s*\(', text)))
 

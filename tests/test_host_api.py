@@ -324,7 +324,8 @@ def test_package_never_imports_the_oracle():
     for root, _, files in os.walk(pkg):
         for name in files:
             if name.endswith(('.py', '.hip', '.hpp', '.h')):
-                text = open(os.path.join(root, name)).read()
+                with open(os.path.join(root, name)) as f:
+                    text = f.read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', text, re.M), name
                 assert 'bbt_oracle' not in text, name
 
