@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 132
+#define BBT_VERSION 133
 
 // ---------------------------------------------------------------------------
 // errors
@@ -523,6 +523,17 @@ struct bbt_osm_plan {
     hipEvent_t ev_fork = nullptr, ev_join[BBT_MAX_LANES] = {};
     hipEvent_t ev_done = nullptr;   // end of the previous execute call (on whatever stream it ran)
     bool ev_done_set = false;
+    // Stage schedule (two-level power-of-two plans): instead of whole chunks
+    // alternating between lanes, each of the three passes has its own stream and
+    // chunk c goes through them on work buffer c % lanes -- first column pass of
+    // chunk c + 1, row pass of chunk c and last column pass of chunk c - 1 are in
+    // flight together, whatever the phase the lanes would have drifted into, and
+    // a pass never waits at a kernel boundary of its own chunk.  Dependencies
+    // between the streams are events per work buffer: ev_pass[k][w] = pass k has
+    // finished with buffer w.
+    bool stages = false;
+    hipStream_t stage_stream[3] = {};
+    hipEvent_t ev_pass[3][BBT_MAX_LANES] = {};
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     cf* wroot = nullptr;
@@ -549,6 +560,14 @@ struct bbt_osm_plan {
     bool timing_isolated = false;   // mode 2: single lane, passes do not overlap
     std::vector<hipEvent_t> ev;  // 4 per chunk launch: t0, tA, tB, tC
     std::vector<hipEvent_t> ev_free;   // recycled events
+    // stage schedule: (start, stop) around the launch of one pass on its stream, for
+    // every timing_stride-th chunk (a sample: events cost queue slots of their own)
+    struct PassSample { int pass; int nblk; hipEvent_t a, b; };
+    std::vector<PassSample> ev_pass_samples;
+    int timing_stride = 4;
+    int64_t pass_launches[3] = {0, 0, 0};
+    int64_t pass_blocks[3] = {0, 0, 0};      // blocks the timed launches of each pass covered
+    std::vector<int> ev_nblk;                // lanes schedule: blocks of each timed chunk launch
     double acc_ms[3] = {0, 0, 0};
     int64_t launches = 0;
 };
@@ -615,17 +634,31 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
 }
 
 static int osm_flush_timing(bbt_osm_plan* p) {
+    for (auto& s : p->ev_pass_samples) {
+        HIP_TRY(hipEventSynchronize(s.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        p->acc_ms[s.pass] += ms;
+        p->pass_launches[s.pass] += 1;
+        p->pass_blocks[s.pass] += s.nblk;
+        p->ev_free.push_back(s.a);
+        p->ev_free.push_back(s.b);
+    }
+    p->ev_pass_samples.clear();
     for (size_t i = 0; i + 3 < p->ev.size(); i += 4) {
         HIP_TRY(hipEventSynchronize(p->ev[i + 3]));
         for (int k = 0; k < 3; ++k) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, p->ev[i + k], p->ev[i + k + 1]));
             p->acc_ms[k] += ms;
+            p->pass_launches[k] += 1;
+            p->pass_blocks[k] += p->ev_nblk[i / 4];
         }
         p->launches += 1;
     }
     for (auto e : p->ev) p->ev_free.push_back(e);
     p->ev.clear();
+    p->ev_nblk.clear();
     return 0;
 }
 
@@ -726,6 +759,51 @@ static int launch_col4096(bbt_osm_plan* p, const float2* in, float2* out, float2
         hipLaunchKernelGGL((k_osm_col4096<FIRST, SPEC, 1>), dim3(p->n2 / 4 * p->npair, ch.nblk),
                            dim3(1024), lds, st, in, out, work, ch, p->S, p->n2, p->tab1.tw0,
                            p->tab1.tw1, so);
+    }
+    return 0;
+}
+
+// One pass of a two-level power-of-two plan (n1 == 16 or 256, outer == 1) over a chunk:
+// 0 = first column pass (stream -> work), 1 = row pass (in place), 2 = last column pass
+// (work -> kept samples or spectra).
+static int osm_launch_pass(bbt_osm_plan* p, int pass, const float2* in, float2* out, const OsmChunk& ch,
+                           const SpecOut& so, float2* work, hipStream_t st) {
+    const int nch = so.n_chan;
+    OsmChunk pairs_view;               // one stream: the work buffers hold pairs of blocks
+    if (p->single) {
+        pairs_view = ch;
+        pairs_view.nblk = (ch.nblk + 1) / 2;
+    }
+    const OsmChunk& chw = p->single ? pairs_view : ch;       // what the row pass counts
+    const dim3 g16(p->n2 / 256 * p->npair, chw.nblk);
+    if (pass == 0) {
+        if (p->n1 == 16 && p->single)
+            hipLaunchKernelGGL((k_osm_col16<true, false, true>), g16, dim3(256), 0, st, in, out, work, ch,
+                               1, p->n2, so);
+        else if (p->n1 == 16)
+            hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
+                               p->S, p->n2, so);
+        else if (launch_col256<true, false>(p, in, out, work, ch, p->n2, so, st))
+            return 1;
+    } else if (pass == 1) {
+        if (launch_rowpass(p, work, chw, nch, st)) return 1;
+    } else if (p->n1 == 16) {
+        if (p->single && nch)
+            hipLaunchKernelGGL((k_osm_col16<false, true, true>), g16, dim3(256), 0, st, in, out,
+                               work, ch, 1, p->n2, so);
+        else if (p->single)
+            hipLaunchKernelGGL((k_osm_col16<false, false, true>), g16, dim3(256), 0, st, in, out,
+                               work, ch, 1, p->n2, so);
+        else if (nch)
+            hipLaunchKernelGGL((k_osm_col16<false, true>), g16, dim3(256), 0, st, in, out,
+                               work, ch, p->S, p->n2, so);
+        else
+            hipLaunchKernelGGL((k_osm_col16<false, false>), g16, dim3(256), 0, st, in, out,
+                               work, ch, p->S, p->n2, so);
+    } else {
+        if (nch ? launch_col256<false, true>(p, in, out, work, ch, p->n2, so, st)
+                : launch_col256<false, false>(p, in, out, work, ch, p->n2, so, st))
+            return 1;
     }
     return 0;
 }
@@ -845,41 +923,17 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
                 : launch_col256<false, false>(p, in, out, work, ch, m_len, so, st))
             return 1;
     } else {
-        const dim3 g16(p->n2 / 256 * p->npair, chw.nblk);
-        if (p->n1 == 16 && p->single)
-            hipLaunchKernelGGL((k_osm_col16<true, false, true>), g16, dim3(256), 0, st, in, out, work, ch,
-                               1, p->n2, so);
-        else if (p->n1 == 16)
-            hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
-                               p->S, p->n2, so);
-        else if (launch_col256<true, false>(p, in, out, work, ch, p->n2, so, st))
-            return 1;
+        if (osm_launch_pass(p, 0, in, out, ch, so, work, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        if (launch_rowpass(p, work, chw, nch, st)) return 1;
+        if (osm_launch_pass(p, 1, in, out, ch, so, work, st)) return 1;
         if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
-        if (p->n1 == 16) {
-            if (p->single && nch)
-                hipLaunchKernelGGL((k_osm_col16<false, true, true>), g16, dim3(256), 0, st, in, out,
-                                   work, ch, 1, p->n2, so);
-            else if (p->single)
-                hipLaunchKernelGGL((k_osm_col16<false, false, true>), g16, dim3(256), 0, st, in, out,
-                                   work, ch, 1, p->n2, so);
-            else if (nch)
-                hipLaunchKernelGGL((k_osm_col16<false, true>), g16, dim3(256), 0, st, in, out,
-                                   work, ch, p->S, p->n2, so);
-            else
-                hipLaunchKernelGGL((k_osm_col16<false, false>), g16, dim3(256), 0, st, in, out,
-                                   work, ch, p->S, p->n2, so);
-        } else {
-            if (nch ? launch_col256<false, true>(p, in, out, work, ch, p->n2, so, st)
-                    : launch_col256<false, false>(p, in, out, work, ch, p->n2, so, st))
-                return 1;
-        }
+        if (osm_launch_pass(p, 2, in, out, ch, so, work, st)) return 1;
     }
     HIP_TRY(hipGetLastError());
     if (p->timing) {
         HIP_TRY(hipEventRecord(e[3], st));
         for (int i = 0; i < 4; ++i) p->ev.push_back(e[i]);
+        p->ev_nblk.push_back(ch_arg.nblk);
         if (p->ev.size() >= 65536) return osm_flush_timing(p);   // (a flush waits for the events)
     }
     return 0;
@@ -907,6 +961,53 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
                        const SpecOut& so, hipStream_t st, FillChunk fill) {
     const int64_t n_chunks = (n_blocks + p->chunk - 1) / p->chunk;
     const bool fork = p->lanes > 1 && !(p->timing && p->timing_isolated) && n_chunks > 1;
+    if (fork && p->stages && !p->pre) {
+        // Stage schedule: chunk c on work buffer w = c % lanes; pass k of it on stage stream k,
+        // after pass k - 1 of the same chunk (first pass: after the last pass of the chunk that
+        // had the buffer before).
+        HIP_TRY(hipEventRecord(p->ev_fork, st));
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamWaitEvent(p->stage_stream[k], p->ev_fork, 0));
+        auto timing_event = [&](hipEvent_t* e) -> int {
+            if (!p->ev_free.empty()) {
+                *e = p->ev_free.back();
+                p->ev_free.pop_back();
+                return 0;
+            }
+            HIP_TRY(hipEventCreate(e));
+            return 0;
+        };
+        int64_t c = 0;
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
+            OsmChunk ch = {};
+            ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
+            for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
+            const int w = (int)(c % p->lanes);
+            const bool sample = p->timing && c % p->timing_stride == 0;
+            for (int k = 0; k < 3; ++k) {
+                hipStream_t sk = p->stage_stream[k];
+                if (k > 0) HIP_TRY(hipStreamWaitEvent(sk, p->ev_pass[k - 1][w], 0));
+                else if (c >= p->lanes) HIP_TRY(hipStreamWaitEvent(sk, p->ev_pass[2][w], 0));
+                bbt_osm_plan::PassSample s = {k, ch.nblk, nullptr, nullptr};
+                if (sample) {
+                    if (timing_event(&s.a) || timing_event(&s.b)) return 1;
+                    HIP_TRY(hipEventRecord(s.a, sk));
+                }
+                if (osm_launch_pass(p, k, in, out, ch, so, p->lane_work[w], sk)) return 1;
+                if (sample) {
+                    HIP_TRY(hipEventRecord(s.b, sk));
+                    p->ev_pass_samples.push_back(s);
+                }
+                HIP_TRY(hipEventRecord(p->ev_pass[k][w], sk));
+            }
+            HIP_TRY(hipGetLastError());
+            if (p->ev_pass_samples.size() >= 16384 && osm_flush_timing(p)) return 1;
+        }
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipEventRecord(p->ev_join[k], p->stage_stream[k]));
+            HIP_TRY(hipStreamWaitEvent(st, p->ev_join[k], 0));
+        }
+        return 0;
+    }
     if (fork) {
         HIP_TRY(hipEventRecord(p->ev_fork, st));
         for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
@@ -1079,8 +1180,16 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     // resident ones, while 2 x 12 (384 MiB) falls out of the 256 MiB Infinity
     // Cache and loses 6 % although every pass alone is faster.
     int lanes = 2;
+    // Stage schedule (see bbt_osm_plan::stages): two-level power-of-two plans; `lanes` is then
+    // the number of work buffers in rotation (three: one per pass in flight).
+    // BBT_OSM_SCHED=lanes|stages overrides the default.
+    bool stages = fast && !p->generic && p->outer == 1 && (p->n1 == 16 || p->n1 == 256);
+    if (const char* env = getenv("BBT_OSM_SCHED")) stages = stages && strcmp(env, "lanes") != 0;
+    if (stages) lanes = 3;
     if (const char* env = getenv("BBT_OSM_LANES")) lanes = atoi(env);
     lanes = lanes < 1 ? 1 : (lanes > BBT_MAX_LANES ? BBT_MAX_LANES : lanes);
+    if (lanes < 2) stages = false;
+    if (const char* env = getenv("BBT_OSM_TIMING_STRIDE")) p->timing_stride = std::max(1, atoi(env));
     const size_t per_block = (size_t)p->npair * n_fft * 16;
     int chunk = (int)((192u << 20) / per_block / lanes);
     if (const char* env = getenv("BBT_OSM_CHUNK")) chunk = atoi(env);
@@ -1124,6 +1233,19 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if (p->lanes > 1 &&
             hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess)
             return bail(fail("bbt_osm_plan_create: creating the fork event failed"));
+        p->stages = stages && p->lanes >= 2;
+        if (p->stages) {
+            for (int k = 0; k < 3; ++k) {
+                if (!p->ev_join[k] &&
+                    hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) != hipSuccess)
+                    return bail(fail("bbt_osm_plan_create: creating the join events failed"));
+                if (hipStreamCreateWithFlags(&p->stage_stream[k], hipStreamNonBlocking) != hipSuccess)
+                    return bail(fail("bbt_osm_plan_create: creating the stage streams failed"));
+                for (int w = 0; w < p->lanes; ++w)
+                    if (hipEventCreateWithFlags(&p->ev_pass[k][w], hipEventDisableTiming) != hipSuccess)
+                        return bail(fail("bbt_osm_plan_create: creating the stage events failed"));
+            }
+        }
     } else {
         p->lanes = 1;
     }
@@ -1149,6 +1271,18 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
         if (p->ev_join[l]) hipEventDestroy(p->ev_join[l]);
         if (p->lane_work[l]) hipFree(p->lane_work[l]);
         if (p->lane_stage[l]) hipFree(p->lane_stage[l]);
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (p->stage_stream[k]) {
+            hipStreamSynchronize(p->stage_stream[k]);
+            hipStreamDestroy(p->stage_stream[k]);
+        }
+        for (int w = 0; w < BBT_MAX_LANES; ++w)
+            if (p->ev_pass[k][w]) hipEventDestroy(p->ev_pass[k][w]);
+    }
+    for (auto& s : p->ev_pass_samples) {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
     }
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->ev_done) hipEventDestroy(p->ev_done);
@@ -1425,6 +1559,8 @@ int bbt_osm_timing_enable(bbt_osm_plan* p, int enable) {
     p->timing_isolated = enable == 2;
     p->acc_ms[0] = p->acc_ms[1] = p->acc_ms[2] = 0;
     p->launches = 0;
+    p->pass_launches[0] = p->pass_launches[1] = p->pass_launches[2] = 0;
+    p->pass_blocks[0] = p->pass_blocks[1] = p->pass_blocks[2] = 0;
     return 0;
 }
 
@@ -1433,7 +1569,19 @@ int bbt_osm_timing_read(bbt_osm_plan* p, double ms[3], int64_t* launches) {
     std::lock_guard<std::mutex> lock(p->mu);
     if (osm_flush_timing(p)) return 1;
     for (int k = 0; k < 3; ++k) ms[k] = p->acc_ms[k];
-    if (launches) *launches = p->launches;
+    if (launches) *launches = p->pass_launches[0];
+    return 0;
+}
+
+int bbt_osm_timing_read_passes(bbt_osm_plan* p, double ms[3], int64_t launches[3], int64_t blocks[3]) {
+    ARG_TRY(p && ms && launches && blocks, "bbt_osm_timing_read_passes: null argument");
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (osm_flush_timing(p)) return 1;
+    for (int k = 0; k < 3; ++k) {
+        ms[k] = p->acc_ms[k];
+        launches[k] = p->pass_launches[k];
+        blocks[k] = p->pass_blocks[k];
+    }
     return 0;
 }
 

@@ -35,6 +35,7 @@ namespace bbt {
 
 typedef float2 cf;                                        // one complex number (tables)
 typedef float v2 __attribute__((ext_vector_type(2)));     // the same component of streams A, B
+typedef float f4v __attribute__((ext_vector_type(4)));
 struct c2 {                                               // one complex number per stream
     v2 re, im;
 };
@@ -338,7 +339,6 @@ __device__ __forceinline__ void st_ext(float2* p, c2 a) {
 // stores of the last column pass +10 %, Channelize alone 165 -> 185 Gsamples/s,
 // because the stream stops displacing the work buffers from L2 / Infinity
 // Cache.  Not for S > 2 (pairs share lines: -40 %) nor for re-read inputs (PFB).
-typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ c2 ld_ext_nt(const float2* p) {
     const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
     return c2{v2{x.x, x.z}, v2{x.y, x.w}};
@@ -354,8 +354,24 @@ __device__ __forceinline__ c2 ld_int(const float2* p) {
     const float4 x = *reinterpret_cast<const float4*>(p);
     return c2{v2{x.x, x.y}, v2{x.z, x.w}};
 }
+// Work-buffer stores.  BBT_WORK_ST selects the cache policy: 0 plain (the lines stay dirty in
+// the XCD's L2 until evicted or written back at the end of the kernel), 1 non-temporal,
+// 2 write-through (sc1: the next pass reads them from other XCDs anyway, and a kernel that
+// ends with nothing dirty hands over to the next one sooner), 3 both.
+#ifndef BBT_WORK_ST
+#define BBT_WORK_ST 0
+#endif
 __device__ __forceinline__ void st_int(float2* p, c2 a) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.re.x, a.re.y, a.im.x, a.im.y);
+    const f4v x = {a.re.x, a.re.y, a.im.x, a.im.y};
+#if BBT_WORK_ST == 1
+    __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(p));
+#elif BBT_WORK_ST == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+#elif BBT_WORK_ST == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+#else
+    *reinterpret_cast<f4v*>(p) = x;
+#endif
 }
 
 }  // namespace bbt

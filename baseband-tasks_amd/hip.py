@@ -77,6 +77,7 @@ SIGNATURES = {
     'bbt_osm_execute_regular': [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
     'bbt_osm_timing_enable': [_vp, _int],
     'bbt_osm_timing_read': [_vp, C.POINTER(C.c_double), _pi64],
+    'bbt_osm_timing_read_passes': [_vp, C.POINTER(C.c_double), _pi64, _pi64],
     'bbt_chan_plan_create': [_pvp, _int, _int, _int],
     'bbt_chan_plan_destroy': [_vp],
     'bbt_chan_execute': [_vp, _vp, _vp, _i64, _vp],
@@ -627,6 +628,13 @@ class OsmPlan(_Plan):
         n = _i64()
         check(lib().bbt_osm_timing_read(self._h, ms, C.byref(n)))
         return list(ms), n.value
+
+    def timing_read_passes(self):
+        """Per pass: accumulated ms, timed launches, overlap-save blocks those launches covered."""
+        ms = (C.c_double * 3)()
+        launches, blocks = (_i64 * 3)(), (_i64 * 3)()
+        check(lib().bbt_osm_timing_read_passes(self._h, ms, launches, blocks))
+        return list(ms), list(launches), list(blocks)
 
 
 class ChanPlan(_Plan):

@@ -478,7 +478,7 @@ def run_rank(args):
         for _ in range(n_steps_timed):
             z = step()
         fence()
-    ms, launches = plan.timing_read()
+    ms, pass_launches, pass_blocks = plan.timing_read_passes()
     plan.timing_enable(0)
 
     # ---- the timed call shape, checked against the oracle (outside the timed region)
@@ -499,14 +499,16 @@ def run_rank(args):
     for _ in range(n_iso):
         step()
     fence()
-    ms_iso, _ = plan.timing_read()
+    ms_iso, _, blocks_iso = plan.timing_read_passes()
     plan.timing_enable(0)
     info = plan.info()
     names = ['osm_col_forward', 'osm_rowpass', 'osm_col_inverse']
-    k = int(np.argmax(ms))
-    blocks_timed = n_steps_timed * blocks
+    # (the stage schedule puts events on a sample of the launches only: per-pass counts)
+    per_block = [m / max(b, 1) for m, b in zip(ms, pass_blocks)]
+    k = int(np.argmax(per_block))
+    launches = pass_launches[k]
     avg_ms = ms[k] / max(launches, 1)
-    units_per_launch = blocks_timed / max(launches, 1) * spf      # launches may be ragged
+    units_per_launch = pass_blocks[k] / max(launches, 1) * spf      # launches may be ragged
     achieved = units_per_launch * alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
@@ -524,15 +526,18 @@ def run_rank(args):
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
                     traffic_note=traffic_note,
                     avg_launch_ms=round(avg_ms, 5), launches=launches,
-                    blocks_per_launch=round(blocks_timed / max(launches, 1), 3),
+                    blocks_per_launch=round(pass_blocks[k] / max(launches, 1), 3),
+                    launches_per_step=-(-blocks // info['chunk_blocks']),
                     alg_bytes_per_unit=round(alg_bytes, 2),
-                    pass_ms_per_block={n: round(m / blocks_timed, 6) for n, m in zip(names, ms)},
-                    pass_ms_per_block_isolated={n: round(m / (n_iso * blocks), 6)
-                                                for n, m in zip(names, ms_iso)},
+                    pass_ms_per_block={n: round(m, 6) for n, m in zip(names, per_block)},
+                    pass_ms_per_block_isolated={n: round(m / max(b, 1), 6)
+                                                for n, m, b in zip(names, ms_iso, blocks_iso)},
                     note='launch durations from HIP events inside the timed region on the stream each '
-                         'pass runs on, all lanes active (a pass shares the GPU with passes of the other '
-                         'lanes); isolated = one lane; achieved = alg_bytes_per_unit x valid samples per '
-                         'launch / avg launch duration of the dominant pass')
+                         'pass runs on, in the normal schedule (a pass shares the GPU with the other '
+                         'passes in flight; with one stream per pass the events sit on every '
+                         'BBT_OSM_TIMING_STRIDE-th launch, `launches` of them); isolated = one stream, '
+                         'nothing else running; achieved = alg_bytes_per_unit x valid samples per launch '
+                         '/ avg launch duration of the dominant pass')
     path_gbps = value * 1e6 / world * alg_bytes / 1e9
     roofline_path = dict(bound='hbm', achieved=round(path_gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
                          frac=round(path_gbps / HBM_PEAK_GBPS, 4),

@@ -221,6 +221,12 @@ int bbt_osm_execute_regular(bbt_osm_plan* plan, const void* in_dev, void* out_de
  * column-inverse pass time, launches = launches of each pass since enabling. */
 int bbt_osm_timing_enable(bbt_osm_plan* plan, int enable);
 int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
+/* The same per pass, with the number of timed launches and the overlap-save
+ * blocks they covered: in the stage schedule (each pass on a stream of its
+ * own) only every BBT_OSM_TIMING_STRIDE-th launch carries events, so the
+ * per-launch mean is ms[k] / launches[k] and the time per block
+ * ms[k] / blocks[k]. */
+int bbt_osm_timing_read_passes(bbt_osm_plan* plan, double ms[3], int64_t launches[3], int64_t blocks[3]);
 
 /* ---- channelizer: Channelize / Dechannelize -----------------------------
  * Replaces Channelize.task (channelize.py:73-74): FFT over each group of
