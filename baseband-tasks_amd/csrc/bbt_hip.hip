@@ -763,6 +763,30 @@ static int launch_col4096(bbt_osm_plan* p, const float2* in, float2* out, float2
     return 0;
 }
 
+// Can the last column pass of one chunk and the first of the next share a launch
+// (k_osm_col256_ca)?  Two-level plans with 256-point columns whose two column passes both use
+// the plain 16-column tiles of one stream pair (launch_col256 picks other tiles for many pairs).
+static bool osm_ca_ok(const bbt_osm_plan* p, const SpecOut& so) {
+    // Measured on MI355X (headline, round 3): 46.4-46.9 Gsamples/s with it, 46.6-46.9 without --
+    // the lanes were already busy 94 % of the time -- so it is opt-in (BBT_OSM_CA=1).
+    static const bool on = [] { const char* e = getenv("BBT_OSM_CA"); return e && atoi(e) == 1; }();
+    return on && !p->generic && !p->single && !p->pre && p->outer == 1 && p->n1 == 256 && !so.det &&
+           p->npair % 4 != 0 && col_tile() == 16 && p->lanes > 1;
+}
+static int launch_col256_ca(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
+                            const OsmChunk& chc, const OsmChunk& cha, const SpecOut& so, hipStream_t st) {
+    constexpr size_t lds = FftGeo<256>::LDS_ELEMS * sizeof(v2) * 16;
+    const int rows = std::max(chc.nblk, cha.nblk);
+    const dim3 grid(p->n2 / 16 * p->npair, rows);
+    if (so.n_chan)
+        hipLaunchKernelGGL((k_osm_col256_ca<true>), grid, dim3(256), lds, st, in, out, work, chc, cha, p->S,
+                           p->n2, p->tab1.tw0, so);
+    else
+        hipLaunchKernelGGL((k_osm_col256_ca<false>), grid, dim3(256), lds, st, in, out, work, chc, cha, p->S,
+                           p->n2, p->tab1.tw0, so);
+    return 0;
+}
+
 // One pass of a two-level power-of-two plan (n1 == 16 or 256, outer == 1) over a chunk:
 // 0 = first column pass (stream -> work), 1 = row pass (in place), 2 = last column pass
 // (work -> kept samples or spectra).
@@ -1008,6 +1032,74 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
         }
         return 0;
     }
+    if (fork && osm_ca_ok(p, so)) {
+        // Lanes whose launches alternate between the row pass of a chunk and ONE column kernel that
+        // finishes that chunk and starts the lane's next one (k_osm_col256_ca).  Lane l > 0 starts
+        // once lane l - 1 has done its first column pass, so that the lanes are out of phase: a row
+        // pass runs beside a column kernel, not beside another row pass.
+        static const bool stagger = [] { const char* e = getenv("BBT_OSM_STAGGER"); return !(e && atoi(e) == 0); }();
+        HIP_TRY(hipEventRecord(p->ev_fork, st));
+        for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
+        std::vector<OsmChunk> pend(p->lanes);
+        std::vector<char> has(p->lanes, 0);
+        auto timing_event = [&](hipEvent_t* e) -> int {
+            if (!p->ev_free.empty()) {
+                *e = p->ev_free.back();
+                p->ev_free.pop_back();
+                return 0;
+            }
+            HIP_TRY(hipEventCreate(e));
+            return 0;
+        };
+        bool sample = false;           // events on every timing_stride-th chunk of a lane
+        auto timed = [&](int pass, int nblk, hipStream_t sl, auto&& launch) -> int {
+            bbt_osm_plan::PassSample s = {pass, nblk, nullptr, nullptr};
+            if (sample) {
+                if (timing_event(&s.a) || timing_event(&s.b)) return 1;
+                HIP_TRY(hipEventRecord(s.a, sl));
+            }
+            if (launch()) return 1;
+            if (sample) {
+                HIP_TRY(hipEventRecord(s.b, sl));
+                p->ev_pass_samples.push_back(s);
+            }
+            return 0;
+        };
+        int64_t c = 0;
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
+            OsmChunk ch = {};
+            ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
+            for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
+            const int l = (int)(c % p->lanes);
+            sample = p->timing && (c / p->lanes) % p->timing_stride == 0;
+            hipStream_t sl = p->lane_stream[l];
+            float2* work = p->lane_work[l];
+            if (has[l]) {
+                if (timed(0, ch.nblk, sl, [&] { return launch_col256_ca(p, in, out, work, pend[l], ch, so, sl); }))
+                    return 1;
+            } else {
+                if (stagger && l > 0) HIP_TRY(hipStreamWaitEvent(sl, p->ev_join[l - 1], 0));
+                if (timed(0, ch.nblk, sl, [&] { return osm_launch_pass(p, 0, in, out, ch, so, work, sl); })) return 1;
+                if (stagger && l + 1 < p->lanes) HIP_TRY(hipEventRecord(p->ev_join[l], sl));
+            }
+            if (timed(1, ch.nblk, sl, [&] { return osm_launch_pass(p, 1, in, out, ch, so, work, sl); })) return 1;
+            pend[l] = ch;
+            has[l] = 1;
+            HIP_TRY(hipGetLastError());
+            if (p->ev_pass_samples.size() >= 16384 && osm_flush_timing(p)) return 1;
+        }
+        sample = p->timing;
+        for (int l = 0; l < p->lanes; ++l) {
+            hipStream_t sl = p->lane_stream[l];
+            if (has[l] &&
+                timed(2, pend[l].nblk, sl, [&] { return osm_launch_pass(p, 2, in, out, pend[l], so, p->lane_work[l], sl); }))
+                return 1;
+            HIP_TRY(hipEventRecord(p->ev_join[l], sl));
+            HIP_TRY(hipStreamWaitEvent(st, p->ev_join[l], 0));
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (fork) {
         HIP_TRY(hipEventRecord(p->ev_fork, st));
         for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
@@ -1183,8 +1275,14 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     // Stage schedule (see bbt_osm_plan::stages): two-level power-of-two plans; `lanes` is then
     // the number of work buffers in rotation (three: one per pass in flight).
     // BBT_OSM_SCHED=lanes|stages overrides the default.
+    // Measured on MI355X (headline, round 3): 37-40 Gsamples/s against 46 for the lanes -- a
+    // cross-stream event dependency costs 10-20 us of idle stream per hop -- so it is off
+    // unless BBT_OSM_SCHED=stages asks for it.
     bool stages = fast && !p->generic && p->outer == 1 && (p->n1 == 16 || p->n1 == 256);
-    if (const char* env = getenv("BBT_OSM_SCHED")) stages = stages && strcmp(env, "lanes") != 0;
+    {
+        const char* env = getenv("BBT_OSM_SCHED");
+        stages = stages && env && strcmp(env, "stages") == 0;
+    }
     if (stages) lanes = 3;
     if (const char* env = getenv("BBT_OSM_LANES")) lanes = atoi(env);
     lanes = lanes < 1 ? 1 : (lanes > BBT_MAX_LANES ? BBT_MAX_LANES : lanes);

@@ -23,6 +23,14 @@
 #include <hip/hip_runtime.h>
 #include "fft_core.hpp"
 
+// Timing-only experiment switches (never set in the product build; results are wrong with any
+// of them): 1 the row pass skips the four-step twiddles, 2 the last column pass stores nothing,
+// 4 the first column pass reads block 0's samples for every block, 8 the row pass only loads
+// and stores, 16 the row pass skips the fused channelizer transform.
+#ifndef BBT_DBG
+#define BBT_DBG 0
+#endif
+
 namespace bbt {
 
 // Blocks dispatched round-robin over the 8 XCDs: give each XCD one contiguous
@@ -807,6 +815,75 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     }
 }
 
+// Last column pass of one chunk and first column pass of the next chunk of the same lane in
+// ONE launch.  Both passes of a workgroup touch the same 16-column x 256-row tile of the work
+// buffer -- the last pass reads it, the first pass writes it -- and every thread stores exactly
+// where it loaded, so the workgroup can empty its tile (inverse transform over k1, kept samples
+// or spectra out) and refill it at once (next block in, forward transform over n1): the lane
+// has two kernel boundaries per chunk instead of three, its launches alternate between a
+// stream-bound kernel (this one) and the row pass, and the second lane, started half a period
+// later, always has the other kind in flight.  chc: blocks whose last pass this is (block b of
+// the chunk in work slot b); cha: the blocks that take the slots over.  Either may hold fewer
+// blocks than the grid has rows.  Two-stream tiles (PP == 1) of 16 columns.
+template <bool SPEC>
+__global__ __launch_bounds__(256) void k_osm_col256_ca(const float2* __restrict__ in,
+                                                       float2* __restrict__ out,
+                                                       float2* __restrict__ work, OsmChunk chc,
+                                                       OsmChunk cha, int S, int N2,
+                                                       const cf* __restrict__ tw0, SpecOut so) {
+    constexpr int FCOL = 16;
+    extern __shared__ v2 col256_lds[];                   // FftGeo<256>::LDS_ELEMS * FCOL elements
+    v2* lds = col256_lds;
+    const int f = threadIdx.x % FCOL, tau = threadIdx.x / FCOL;
+    const int npair = S >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int n2 = (vb / npair) * FCOL + f;
+    const int b = blockIdx.y, sp = vb % npair;
+    float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
+    c2 v[16];
+    if (b < chc.nblk) {
+        const OsmBlock blk = chc.b[b];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+        wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
+#if BBT_DBG & 2
+        if (v[0].re.x == 1.2345e-30f)
+#endif
+        if constexpr (SPEC) {
+            const SpecCursor cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, so), S, sp, npair);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) emit_spectrum(v[j], cur, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
+                if (r >= 0 && r < blk.valid_count)
+                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
+            }
+        }
+    }
+    if (b < cha.nblk) {
+        OsmBlock blk = cha.b[b];
+#if BBT_DBG & 4
+        blk.in_off = 0;
+#endif
+        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);
+        const long long wrap = (tau == 15 && n2 + blk.shift >= N2) ? (long long)256 * N2 * S : 0;
+        if (S == 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_ext(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
+        }
+        wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);     // (its exchanges open with a barrier)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
+    }
+}
+
 // Column pass, N1 == 4096 (blocks longer than 2^20 as 4096 x N2, N2 = 512 ..
 // 4096): one 4096-point transform is 256 threads x 16 points; a 1024-thread
 // workgroup runs four of them interleaved in LDS (136 KiB), the four lanes of a
@@ -1006,10 +1083,19 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         if (M <= 4096) return wroot[x * rstride];
         return cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
     };
+#if !(BBT_DBG & 1)
     if (N1 > 1) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, wrow(j)));
     }
+#endif
+#if BBT_DBG & 8
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st_int(row + (long long)(tau + T * j) * 2, v[j]);
+        return;
+    }
+#endif
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
     const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
@@ -1044,7 +1130,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
             const cf wi = wrow(j);
             v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
         }
-    } else if (N1 > 1) {
+    } else if (N1 > 1 && !(BBT_DBG & 1)) {
         // Evaluate the twiddles again instead of keeping the 16 products of the
         // forward step alive through both transforms (the compiler did: 199
         // VGPRs / 2 waves per SIMD for the plain row pass): the row index goes
@@ -1066,7 +1152,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     // stay alive from the first instruction to the last -- that, with the tables
     // above, is what made the plain row pass 199 VGPRs / 2 waves per SIMD and
     // plain Dedisperse slower than the fused pipeline; now 148 / 3.)
-    if constexpr (NCH == 0) {
+    if constexpr (NCH == 0 || (BBT_DBG & 16)) {
         float2* row2 = row;
         asm volatile("" : "+s"(row2));
 #pragma unroll
