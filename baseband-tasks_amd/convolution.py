@@ -1,5 +1,7 @@
 """Overlap-save convolution in the Fourier domain on the GPU (reference
 baseband_tasks/convolution.py:65-127)."""
+import os
+
 import numpy as np
 
 from . import hip
@@ -86,10 +88,49 @@ class Convolve(SpectralMultiplyTask):
                 self._fir = hip.FirPlan(np.ascontiguousarray(full))
         return self._fir is not False
 
+    # -- medium responses: Fourier domain on short blocks, one kernel ----------------
+    #: The linear convolution does not depend on the block length, so a response that
+    #: fits a transform one workgroup holds in LDS (bbt_osm plans of <= 4096 samples:
+    #: transform, multiply and inverse in ONE kernel, one read and one write of the
+    #: stream) need not go through frame-sized blocks (three passes) nor through the
+    #: direct filter (time in proportion to the taps).  SHORT_BLOCK: block length, or
+    #: 'auto' = the power of two in [1024, 4096] that keeps the padding at or below an
+    #: eighth of the block, or 0 to disable the route.  Measured on MI355X (config 5:
+    #: 129 real taps, 8 streams, then Dedisperse): direct filter 6.6, blocks of 4096
+    #: 6.9, 2048 7.3, 1024 8.0 G complete samples/s; the resampler alone 15 -> 21 (2048).
+    SHORT_BLOCK = os.environ.get('BBT_SHORT_BLOCK', 'auto')
+    SHORT_BLOCK_MIN_TAPS = 48
+    _short = None
+
+    def _short_block_length(self):
+        n, pad = self.SHORT_BLOCK, self._response.shape[0] - 1
+        if n == 'auto':
+            n = 1024
+            while n < 8 * pad:
+                n *= 2
+        n = int(n)
+        return n if 256 <= n <= 4096 and 2 * pad <= n else 0
+
+    def _short_blocks(self):
+        """The inner task that convolves on short blocks, or None."""
+        if self._short is None:
+            n, taps = self._short_block_length(), self._response.shape[0]
+            ok = n and taps >= self.SHORT_BLOCK_MIN_TAPS and self._ih_samples_per_frame > n
+            if ok:
+                inner = Convolve(self.ih, self._time_response(), offset=self._pad_end,
+                                 samples_per_frame=n - (taps - 1))
+                inner.FIR_MAX_TAPS = inner.FIR_MAX_TAPS_COMPLEX = inner.SHORT_BLOCK = 0
+                ok = inner._ih_samples_per_frame == n
+            self._short = inner if ok else False
+        return self._short or None
+
     def _compute_frames(self, first, last, out):
+        start, stop = self._frame_span(first, last)
+        short = self._short_blocks()
+        if short is not None and stop - start + self._pad_start + self._pad_end >= short._ih_samples_per_frame:
+            return short._compute_span(start, stop - start, out)
         if not self._use_fir():
             return super()._compute_frames(first, last, out)
-        start, stop = self._frame_span(first, last)
         n_out, pad = stop - start, self._pad_start + self._pad_end
         x = fetch_device(self.ih, start, n_out + pad)
         s, final = self._n_stream, None
@@ -113,11 +154,21 @@ class Convolve(SpectralMultiplyTask):
             hip.real_part(out, final)
 
     def close(self):
+        if self._short:
+            self._short._plan_close()
+        self._short = None
         super().close()
         self._ft_response_cache = None
         if self._fir:
             self._fir.close()
         self._fir = None
+
+    def _plan_close(self):
+        """Release the plan of an inner short-block task (its stream stays open:
+        it is the outer task's)."""
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
 
 
 class ConvolveSamples(Convolve):
@@ -128,3 +179,4 @@ class ConvolveSamples(Convolve):
     Fourier-domain plan, which gives the same linear convolution."""
     FIR_MAX_TAPS = 1024
     FIR_MAX_TAPS_COMPLEX = 1024
+    SHORT_BLOCK = 0

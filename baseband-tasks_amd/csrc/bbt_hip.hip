@@ -573,26 +573,28 @@ struct bbt_osm_plan {
 };
 
 template <int N2, int NCH>
-static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, hipStream_t st) {
+static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, hipStream_t st,
+                             int y0 = 0, int ny = -1) {
     // BBT_ROWPASS_REMAP=0: the older (rows, blocks * pairs) grid
     static const bool remap = [] { const char* e = getenv("BBT_ROWPASS_REMAP"); return !(e && atoi(e) == 0); }();
     const bool flat = remap && p->outer == 1 && ch.nblk * p->npair > 1 &&
                       (long long)p->n1 * ch.nblk * p->npair < (1ll << 31);
+    // (three-level plans may launch a range [y0, y0 + ny) of the outer rows)
+    const int rows = ny >= 0 ? ny : ch.nblk * p->npair * p->outer;
     hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>),
-                       flat ? dim3(p->n1 * ch.nblk * p->npair, 1)
-                            : dim3(p->n1, ch.nblk * p->npair * p->outer),
+                       flat ? dim3(p->n1 * ch.nblk * p->npair, 1) : dim3(p->n1, rows),
                        dim3(N2 / 16), 0,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
-                       p->wroot, p->wroot + 4096, ch, p->outer);
+                       p->wroot, p->wroot + 4096, ch, p->outer, y0);
 }
 
 // (row length, channels) -> instantiation; nch == 0 is the plain row pass.
 static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int nch,
-                          hipStream_t st) {
-#define BBT_RP(N2_, NCH_)                               \
-    if (p->n2 == N2_ && nch == NCH_) {                  \
-        launch_rowpass_t<N2_, NCH_>(p, work, ch, st);   \
-        return 0;                                       \
+                          hipStream_t st, int y0 = 0, int ny = -1) {
+#define BBT_RP(N2_, NCH_)                                       \
+    if (p->n2 == N2_ && nch == NCH_) {                          \
+        launch_rowpass_t<N2_, NCH_>(p, work, ch, st, y0, ny);   \
+        return 0;                                               \
     }
     BBT_RP(256, 0) BBT_RP(512, 0) BBT_RP(1024, 0) BBT_RP(2048, 0) BBT_RP(4096, 0)
     BBT_RP(256, 16) BBT_RP(256, 32) BBT_RP(256, 64) BBT_RP(256, 128)
@@ -616,18 +618,19 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
     // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
     constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
     constexpr size_t lds1 = FftGeo<N>::LDS_ELEMS * sizeof(v2);
+    const int nblk = ch.reg_count ? ch.reg_count : ch.nblk;
     if (p->single) {
-        hipLaunchKernelGGL((k_osm_small<N, 1, true>), dim3((ch.nblk + 1) / 2), dim3(N / 16), lds1, st, in,
+        hipLaunchKernelGGL((k_osm_small<N, 1, true>), dim3((nblk + 1) / 2), dim3(N / 16), lds1, st, in,
                            out, ch, 1, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
         return 0;
     }
     if (p->npair % PP == 0) {
         if (ensure_dyn_lds((const void*)k_osm_small<N, PP>, lds1 * PP)) return 1;
-        hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(ch.nblk * (p->npair / PP)), dim3(PP * N / 16),
+        hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(nblk * (p->npair / PP)), dim3(PP * N / 16),
                            lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0,
                            p->tab2.tw1);
     } else {
-        hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(ch.nblk * p->npair), dim3(N / 16), lds1, st, in, out,
+        hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(nblk * p->npair), dim3(N / 16), lds1, st, in, out,
                            ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
     }
     return 0;
@@ -933,16 +936,32 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
     } else if (p->outer > 1) {
         // three levels: outer 256-point column pass over rows of M = 16 * n2, then
         // the two-level machinery in place on every outer row
+        // The three middle passes (outer twiddle + 16-point step, row pass, and back) act on
+        // every outer row by itself, in place: they go over the work buffer in pieces of
+        // BBT_OSM_MID_MIB (default 128 MiB), so that a piece can still be in the Infinity Cache
+        // when the next pass comes for it.  Measured on MI355X (config 4's share, two runs each):
+        // whole buffer 2.67 / 2.69, pieces of 32 MiB 2.57, 64 MiB 2.70 / 2.71, 128 MiB 2.75 / 2.75,
+        // 256 MiB 2.70 / 2.76 G complete samples/s -- +3 %, not the 1.5x fewer HBM bytes would give:
+        // the other lane's outer column passes stream 4 GiB through the cache meanwhile (making
+        // those accesses non-temporal cost 7 %, one lane 8 %).
         const int m_len = 16 * p->n2;
-        const dim3 gmid(p->n2 / 256, chw.nblk * p->npair * 256);
+        const int rows_all = chw.nblk * p->npair * 256;
+        static const long long mid_bytes = [] { const char* e = getenv("BBT_OSM_MID_MIB"); return (long long)(e ? atoi(e) : 128) << 20; }();
+        const long long row_bytes = 16ll * p->n2 * 16;
+        int step = mid_bytes > 0 ? (int)std::max<long long>(1, mid_bytes / row_bytes) : rows_all;
+        if (p->timing) step = rows_all;            // (per-pass events: the passes one after the other)
         if (launch_col256<true, false>(p, in, out, work, ch, m_len, so, st)) return 1;
-        hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
-                           p->wroot, 0);
-        if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        if (launch_rowpass(p, work, chw, nch, st)) return 1;
-        if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
-        hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
-                           p->wroot, nch ? 1 : 0);
+        for (int y0 = 0; y0 < rows_all; y0 += step) {
+            const int ny = std::min(step, rows_all - y0);
+            const dim3 gmid(p->n2 / 256, ny);
+            hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
+                               p->wroot, 0, y0);
+            if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+            if (launch_rowpass(p, work, chw, nch, st, y0, ny)) return 1;
+            if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+            hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
+                               p->wroot, nch ? 1 : 0, y0);
+        }
         if (nch ? launch_col256<false, true>(p, in, out, work, ch, m_len, so, st)
                 : launch_col256<false, false>(p, in, out, work, ch, m_len, so, st))
             return 1;
@@ -1639,6 +1658,29 @@ int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, 
     ARG_TRY(p, "bbt_osm_execute_regular: null plan");
     ARG_TRY(n_blocks >= 0 && hop > 0 && hop <= p->n, "bbt_osm_execute_regular: bad hop %lld",
             (long long)hop);
+    if (!p->generic && p->n1 == 1 && p->outer == 1 && n_blocks > 0) {
+        // one-kernel plans: the whole run as regular descriptors, up to 2^20 blocks per launch
+        ARG_TRY(in_dev && out_dev && in_off0 >= 0 && out_off0 >= 0 && valid_start >= 0 &&
+                    valid_start + hop <= p->n,
+                "bbt_osm_execute_regular: blocks keep [%d, %lld) outside [0, %lld)", valid_start,
+                (long long)(valid_start + hop), (long long)p->n);
+        hipStream_t st = (hipStream_t)stream;
+        SpecOut so = {};
+        PlanCall call(p, st);
+        const int64_t per_launch = std::min<int64_t>(1 << 20, ((1ll << 31) - 1) / p->npair);
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += per_launch) {
+            OsmChunk ch = {};
+            ch.reg_count = (int)std::min(per_launch, n_blocks - b0);
+            ch.reg_hop = hop;
+            ch.nblk = 1;
+            ch.b[0].in_off = in_off0 + b0 * hop;
+            ch.b[0].out_off = out_off0 + b0 * hop;
+            ch.b[0].valid_start = valid_start;
+            ch.b[0].valid_count = (int)hop;
+            if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, nullptr, st)) return 1;
+        }
+        return 0;
+    }
     std::vector<int64_t> io(n_blocks), oo(n_blocks);
     std::vector<int32_t> vs(n_blocks, valid_start), vc(n_blocks, (int32_t)hop);
     for (int64_t b = 0; b < n_blocks; ++b) {

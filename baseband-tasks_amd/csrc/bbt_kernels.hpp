@@ -456,8 +456,20 @@ __device__ __forceinline__ void emit_spectrum_single(float2 val, const SpecCurso
 
 struct OsmChunk {
     int nblk;
+    // Regular runs (k_osm_small only): reg_count > 0 blocks that all look like b[0] with input
+    // and output offsets advancing by reg_hop samples per block -- one launch takes any number
+    // of them (the descriptor array holds 16); nblk is then not used.
+    int reg_count;
+    long long reg_hop;
     OsmBlock b[BBT_MAX_CHUNK];
 };
+__device__ __forceinline__ OsmBlock osm_block(const OsmChunk& ch, int i) {
+    if (!ch.reg_count) return ch.b[i];
+    OsmBlock blk = ch.b[0];
+    blk.in_off += i * ch.reg_hop;
+    blk.out_off += i * ch.reg_hop;
+    return blk;
+}
 
 // One-stream plans (S == 1, SINGLE kernels): the two transforms a thread carries
 // side by side are two consecutive BLOCKS of the one stream -- blocks 2q and
@@ -471,9 +483,9 @@ struct SinglePair {
 };
 __device__ __forceinline__ SinglePair single_pair(const OsmChunk& ch, int q) {
     SinglePair sp;
-    sp.a = ch.b[2 * q];
-    sp.has_b = 2 * q + 1 < ch.nblk;
-    sp.b = ch.b[sp.has_b ? 2 * q + 1 : 2 * q];
+    sp.a = osm_block(ch, 2 * q);
+    sp.has_b = 2 * q + 1 < (ch.reg_count ? ch.reg_count : ch.nblk);
+    sp.b = osm_block(ch, sp.has_b ? 2 * q + 1 : 2 * q);
     return sp;
 }
 __device__ __forceinline__ c2 ld_single(const float2* __restrict__ in, const SinglePair& sp, long long e) {
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
     const int npg = (S >> 1) / PP;
     const int pl = threadIdx.x % PP, tau = threadIdx.x / PP;
     const int sp = (vb % npg) * PP + pl;
-    const OsmBlock blk = ch.b[vb / npg];
+    const OsmBlock blk = osm_block(ch, vb / npg);
     const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
@@ -943,10 +955,13 @@ __global__ __launch_bounds__(1024) void k_osm_col4096(const float2* __restrict__
 // conjugated and applied after the butterfly.  One thread per (row, n2).
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_osm_mid16(float2* __restrict__ work, int N2, int n_fft,
-                                                   const cf* __restrict__ wroot, int skip_base) {
+                                                   const cf* __restrict__ wroot, int skip_base, int y0) {
+    // (y0: first outer row of this launch -- the middle passes run over pieces of the work
+    // buffer that stay in the Infinity Cache from one pass to the next)
     const int n2 = blockIdx.x * 256 + threadIdx.x;
-    const int k1o = blockIdx.y & 255;
-    float2* w = work + ((long long)blockIdx.y * 16 * N2 + n2) * 2;
+    const int yrow = blockIdx.y + y0;
+    const int k1o = yrow & 255;
+    float2* w = work + ((long long)yrow * 16 * N2 + n2) * 2;
     // W_N^{(N2 a + n2) k1o} = W_N^{n2 k1o} * W_4096^{a k1o}      (N / N2 = 4096)
     cf base;
     {
@@ -1033,7 +1048,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
     const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
-    OsmChunk ch, int outer) {
+    OsmChunk ch, int outer, int y0) {
     // Three-level transforms (N > 2^20) run this pass once per row k1o of the
     // outer 256-point level: blockIdx.y = (block * npair + pair) * outer + k1o;
     // the full frequency index is k = k1o + outer * (k1 + N1 * k2).  outer == 1
@@ -1057,7 +1072,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         by = vb - k1 * nbp;
     } else {
         k1 = blockIdx.x;
-        by = blockIdx.y;
+        by = blockIdx.y + y0;          // (y0: first outer row of this launch, three-level plans)
     }
     const int k1o = by % outer;
     const int bp = by / outer;                    // block * npair + pair

@@ -110,9 +110,10 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             self._plan = hip.OsmPlan(self._ih_samples_per_frame, n_plan, columns, index)
         return self._plan
 
-    def _run_plan(self, x, out, n_in, n_out, *block_args):
+    def _run_plan(self, x, out, n_in, n_out, *block_args, executor=None):
         """plan.execute on (n_in, S) input / (n_out, S) output in this task's
-        dtype, taking care of real streams and odd stream counts."""
+        dtype, taking care of real streams and odd stream counts.
+        ``executor(plan, x, target)`` replaces the one ``plan.execute`` call."""
         plan = self._get_plan()
         s = self._n_stream
         if self._real and self._paired:
@@ -131,7 +132,10 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             target = hip.DeviceArray((n_out, se), np.complex64)
         else:
             target = out
-        plan.execute(x, target, *block_args)
+        if executor is None:
+            plan.execute(x, target, *block_args)
+        else:
+            executor(plan, x, target)
         if se != s:
             hip.strip_stream_pad(target, n_out, s, out)
         if final is not None:
@@ -187,6 +191,26 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             return
         x = fetch_device(self.ih, in0, in_len)
         self._run_plan(x, out, in_len, out.shape[0], starts - in0, out_off, keep, counts)
+
+    def _compute_span(self, start, n_out, out):
+        """Output samples [start, start + n_out) into ``out``, whatever the frame
+        boundaries: a run of regular blocks (one launch for plans of one kernel,
+        bbt_osm_execute_regular) and a last block re-aligned to end with the
+        input.  For tasks whose result does not depend on the block geometry
+        (exact linear convolutions).  Needs ``n_out + pad >= block length``."""
+        n, pad = self._ih_samples_per_frame, self._pad_start + self._pad_end
+        hop, n_in, keep = n - pad, n_out + pad, self._keep_from
+        assert n_in >= n
+        x = fetch_device(self.ih, start, n_in)
+        n_full, rest = divmod(n_out, hop)
+
+        def run(plan, x, target):
+            if n_full:
+                plan.execute_regular(x, target, n_full, 0, 0, hop, keep)
+            if rest:
+                plan.execute(x, target, [n_in - n], [n_full * hop], [keep + hop - rest], [rest])
+
+        self._run_plan(x, out, n_in, n_out, executor=run)
 
     def close(self):
         super().close()

@@ -377,10 +377,54 @@ def main():
     out['r5_tail'] = r[-1024:]
     out['r5_stats'] = stats(r)
 
+    out.update(config4())
     np.savez_compressed('reference_vectors.npz', **out)
     total = sum(v.nbytes for v in out.values())
     print('wrote reference_vectors.npz with %d arrays, %.2f MB raw' % (len(out), total / 1e6))
 
 
+def config4():
+    """Config 4: ONE sub-band (k = 0, 403.125 MHz, the worst case) of 6.25 MHz, 2 pol,
+    DM 557 with the sub-band centre as reference frequency, blocks of 2^24 samples; one full block
+    and a re-aligned last one; then Channelize(64).  Added in round 3 (`make_golden.py --only c4`
+    merges these arrays into the existing file)."""
+    out = {}
+    n_fft, pad = 2**24, 2756522
+    spf = n_fft - pad
+    nh = noise((n_fft + 2**20, 2), 6.25 * u.MHz, 2**20, 403.125 * u.MHz, 1)
+    dd = Dedisperse(nh, 557., reference_frequency=403.125 * u.MHz, samples_per_frame=spf)
+    g, shift = geometry(dd, nh)
+    out['c4_geo'] = g
+    out['c4_shift'] = shift
+    pf = dd.phase_factor
+    idx = np.array([0, 1, 4095, 4096, n_fft // 2 - 1, n_fft // 2, n_fft - 4096, n_fft - 1])
+    out['c4_chirp_idx'] = idx
+    out['c4_chirp'] = pf[idx, 0]
+    out['c4_chirp_stats'] = stats(pf)
+    y = dd.read()
+    out['c4_shape'] = np.array(y.shape)
+    out['c4_head'] = y[:1024]
+    out['c4_mid'] = y[spf // 2:spf // 2 + 1024]
+    out['c4_seam'] = y[spf - 512:spf + 512]
+    out['c4_tail'] = y[-1024:]
+    out['c4_stats_blocks'] = np.stack([stats(y[:spf]), stats(y[spf:])])
+    dd.seek(0)
+    ch = Channelize(dd, 64, samples_per_frame=4096)
+    z = ch.read()
+    out['c4ch_shape'] = np.array(z.shape)
+    out['c4ch_head'] = z[:8]
+    out['c4ch_seam'] = z[spf // 64 - 4:spf // 64 + 4]
+    out['c4ch_tail'] = z[-8:]
+    out['c4ch_stats'] = stats(z)
+    return out
+
+
 if __name__ == '__main__':
-    main()
+    import sys
+    if sys.argv[1:] == ['--only', 'c4']:
+        old = dict(np.load('reference_vectors.npz'))
+        old.update(config4())
+        np.savez_compressed('reference_vectors.npz', **old)
+        print('merged config 4 arrays; %d arrays in all' % len(old))
+    else:
+        main()

@@ -451,6 +451,35 @@ def test_config4_subband_block_2_24():
         assert_parity(z, orc.channelize(want[:z.shape[0] * n], n), f'channelize {n}')
 
 
+def test_config4_subband_golden(golden):
+    """Config 4's worst-case sub-band against the REAL reference's output (golden `c4_*`, made by
+    tests/golden/make_golden.py config4()): NoiseGenerator input, one 2^24 block and a re-aligned last
+    one, three-level plan with the middle passes in cache-sized pieces, then Channelize(64) folded
+    into the row pass."""
+    n_fft, pad = 2**24, 2756522
+    spf = n_fft - pad
+    nh = noise(n_fft + 2**20, (2,), 2**20, fs=6.25 * u.MHz, frequency=403.125 * u.MHz, sideband=1)
+    dd = bt.Dedisperse(nh, 557., reference_frequency=403.125 * u.MHz, samples_per_frame=spf)
+    assert [dd._pad_start, dd._pad_end, dd._ih_samples_per_frame, dd.samples_per_frame, dd.shape[0]] == \
+        list(golden['c4_geo'][:5])
+    assert abs((dd.start_time - nh.start_time) * 6.25e6 - golden['c4_shift'][0]) < 1e-5
+    assert dd._get_plan().info()['n1'] == 16
+    y = dd.read()
+    assert list(y.shape) == list(golden['c4_shape'])
+    for name, sl in (('c4_head', slice(0, 1024)), ('c4_mid', slice(spf // 2, spf // 2 + 1024)),
+                     ('c4_seam', slice(spf - 512, spf + 512)), ('c4_tail', slice(-1024, None))):
+        assert_parity(y[sl], golden[name], name)
+    dd.seek(0)
+    ch = bt.Channelize(dd, 64, samples_per_frame=4096)
+    assert ch._fusable_input() is dd
+    z = ch.read()
+    assert list(z.shape) == list(golden['c4ch_shape'])
+    k = spf // 64
+    assert_parity(z[:8], golden['c4ch_head'], 'golden head')
+    assert_parity(z[k - 4:k + 4], golden['c4ch_seam'], 'golden seam')
+    assert_parity(z[-8:], golden['c4ch_tail'], 'golden tail')
+
+
 def test_config5_resample_dedisperse_8_streams():
     """Config 5: Resample(0.25, pad=64) -> Dedisperse(DM=100), 8 streams, 2^20
     blocks in both stages (two overlap-save stages, as the reference does it)."""
@@ -485,7 +514,10 @@ def test_config5_resample_dedisperse_8_streams():
     assert dd2._prefilter_input() is None
     y2 = dd2.read()
     assert_parity(y2, want, 'config 5, separate tasks')
-    assert rel_l2(y, y2) < 2e-7
+    # (the fused route filters directly, the separate `Resample` on 1024-sample blocks in the
+    # Fourier domain since round 3: both are the reference's linear convolution, each with its own
+    # float32 rounding -- 1.0e-7 and 3e-7 -- under the dedispersion's 3.8e-7)
+    assert rel_l2(y, y2) < 6e-7
     # piecewise reads of the fused task across block seams
     dd.seek(836100 - 500)
     assert np.array_equal(dd.read(1000), y[836100 - 500:836100 + 500])
@@ -1194,6 +1226,36 @@ def test_convolve_equals_numpy_convolve():
         assert_parity(got, want.astype(np.complex64), f'{n_tap} taps')
         # the result is attributed to input sample pad_start = n_tap - 1 - offset
         assert abs((cv.start_time - nh.start_time) * 1e3 - (n_tap - 1 - offset)) < 1e-9
+
+
+@pytest.mark.parametrize('shape', [(2,), (8,), (1,), (3,)])
+def test_convolve_on_short_blocks_matches_numpy_and_direct_filter(shape):
+    """The short-block route of `Convolve` (medium responses: transform, multiply and inverse of
+    2048-sample blocks in one kernel, whatever the frame length) against numpy.convolve and
+    against the direct filter: the linear convolution does not depend on the block geometry
+    (reference convolution.py:116-120).  Ragged ends: the last block is re-aligned."""
+    rng = np.random.default_rng(77)
+    n = 3 * 2**15 + 1234
+    nh = noise(n, shape, 2**15, seed=92, fs=1 * u.kHz)
+    x = nh.read().astype(np.complex128)
+    for n_tap, offset in ((129, 64), (65, 0), (300, 17)):
+        resp = rng.standard_normal((n_tap,) + shape) if n_tap == 65 else rng.standard_normal(n_tap)
+        cv = bt.Convolve(nh, resp, offset=offset)
+        assert cv._short_blocks() is not None
+        assert cv._short_blocks()._ih_samples_per_frame == {129: 1024, 65: 1024, 300: 4096}[n_tap]
+        got = cv.read()
+        full = np.broadcast_to(resp.reshape(n_tap, -1) if resp.ndim > 1 else resp[:, None], (n_tap, shape[0]))
+        want = np.stack([np.convolve(x[:, k], full[:, k], mode='valid') for k in range(shape[0])], axis=1)
+        assert got.shape == want.shape
+        assert_parity(got, want.astype(np.complex64), f'{n_tap} taps on short blocks')
+        if n_tap <= 160:
+            direct = bt.Convolve(nh, resp, offset=offset)
+            direct.SHORT_BLOCK = 0
+            assert direct._short_blocks() is None and direct._use_fir()
+            assert_parity(got, direct.read(), f'{n_tap} taps: short blocks against the direct filter')
+        # piecewise reads (frames of the task, spans that do not start at 0) give the same samples
+        cv.seek(5000)
+        assert np.array_equal(cv.read(40000), got[5000:45000])
 
 
 @pytest.mark.parametrize('three_level', [True, False])

@@ -125,6 +125,39 @@ def test_config2_dedisperse_and_channelize(golden):
     assert f[512] == 992.
 
 
+def test_config4_one_subband_block_2_24(golden):
+    """Config 4: the worst-case sub-band (k = 0, 403.125 MHz) of 6.25 MHz, DM 557 with the
+    sub-band centre as reference frequency, one 2^24-sample block and a re-aligned last one, then
+    Channelize(64) -- against the real reference's output (make_golden.py config4())."""
+    n_fft, pad = 2**24, 2756522
+    spf = n_fft - pad
+    g = orc.disperse_geometry(6.25e6, 403.125, 1, -557., reference_frequency_mhz=403.125)
+    assert (g['pad_start'], g['pad_end']) == (1362235, 1394287) == tuple(golden['c4_geo'][:2])
+    assert list(golden['c4_geo'][2:5]) == [n_fft, spf, n_fft + 2**20 - pad]
+    h = orc.chirp(n_fft, 6.25e6, 403.125, 1, -557., 403.125)
+    assert np.abs(h[golden['c4_chirp_idx'], 0] - golden['c4_chirp']).max() < 2e-7
+    np.testing.assert_allclose(stats(h), golden['c4_chirp_stats'], rtol=0, atol=0.5)
+    del h
+    x = orc.noise_stream(12345, 0, n_fft + 2**20, 2**20, (2,))
+    y, info = orc.dedisperse(x, 6.25e6, 403.125, 1, 557., reference_frequency_mhz=403.125,
+                             samples_per_frame=spf, ih_samples_per_frame=2**20)
+    assert info['ih_spf'] == n_fft and list(y.shape) == list(golden['c4_shape'])
+    assert abs(info['start_shift_samples'] - golden['c4_shift'][0]) < 1e-5     # (astropy Time arithmetic: 2e-6)
+    for name, sl in (('c4_head', slice(0, 1024)), ('c4_mid', slice(spf // 2, spf // 2 + 1024)),
+                     ('c4_seam', slice(spf - 512, spf + 512)), ('c4_tail', slice(-1024, None))):
+        assert rel_l2(y[sl], golden[name]) < TIGHT, name
+        assert max_over_rms(y[sl], golden[name]) < 1e-6, name
+    got = np.stack([stats(y[:spf]), stats(y[spf:])])
+    np.testing.assert_allclose(got, golden['c4_stats_blocks'], rtol=1e-6, atol=0.5)
+    z = orc.channelize(y[:(y.shape[0] // (64 * 4096)) * 64 * 4096], 64)
+    assert list(z.shape) == list(golden['c4ch_shape'])
+    k = spf // 64
+    for name, sl in (('c4ch_head', slice(0, 8)), ('c4ch_seam', slice(k - 4, k + 4)),
+                     ('c4ch_tail', slice(-8, None))):
+        assert rel_l2(z[sl], golden[name]) < TIGHT, name
+    np.testing.assert_allclose(stats(z), golden['c4ch_stats'], rtol=1e-6, atol=0.5)
+
+
 def test_config1_channelize(golden):
     x = orc.noise_stream(12345, 0, 2**20, 2**20, (2,))
     z = orc.channelize(x, 1024)
