@@ -10,7 +10,7 @@ from . import units
 from .units import Time
 from .base import (Base, BaseTaskBase, TaskBase, PaddedTaskBase, Task, SetAttribute, SinglePrecision)
 from .generators import (StreamGenerator, EmptyStreamGenerator, Noise, NoiseGenerator,
-                         DeviceStream)
+                         DeviceStream, HostStream)
 from .dm import DispersionMeasure
 from .fourier import fft_maker, HipFFTMaker
 from .dispersion import Disperse, Dedisperse, DisperseSamples, DedisperseSamples

@@ -580,6 +580,11 @@ class SetAttribute(TaskBase):
         self.offset += count
         return result
 
+    @property
+    def _produces_on_device(self):
+        # (a pass-through: on the device if the stream below is)
+        return self._passthrough and bool(getattr(self.ih, '_produces_on_device', False))
+
     def read_device(self, count=None):
         if not self._passthrough or not hasattr(self.ih, 'read_device'):
             return super().read_device(count)
@@ -614,6 +619,10 @@ class _TimeSlice(Base):
         result = self.ih.read(count, out) if out is not None else self.ih.read(count)
         self.offset += count
         return result
+
+    @property
+    def _produces_on_device(self):
+        return bool(getattr(self.ih, '_produces_on_device', False))
 
     def read_device(self, count=None):
         count = self._prepare_read(count, None)

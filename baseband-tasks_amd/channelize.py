@@ -212,6 +212,18 @@ class Channelize(_RowFFTTask):
             return None
         return dd
 
+    def _input_span(self, first, last):
+        start, stop = self._frame_span(first, last)
+        n = self._n
+        dd = self._fusable_input()
+        if dd is not None:
+            spf = dd.samples_per_frame
+            m0, m1 = (start * n) // spf, (stop * n - 1) // spf + 1
+            in0, in_len, _, _, _, counts = dd._block_descriptors(m0, m1)
+            if np.all(counts >= n):
+                return dd.ih, in0, in_len
+        return self.ih, start * n, (stop - start) * n
+
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
         n_spectra = stop - start
@@ -344,6 +356,10 @@ class Dechannelize(_RowFFTTask):
             hip.real_part(tmp, out)
         else:
             self._run(x.reshape(n_spectra * n, s), n_spectra, out.reshape(n_spectra * n, s))
+
+    def _input_span(self, first, last):
+        start, stop = self._frame_span(first, last)
+        return self.ih, start // self._n, (stop - start) // self._n
 
     def _compute_frames(self, first, last, out):
         if self._mismatch:

@@ -115,7 +115,8 @@ class Convolve(SpectralMultiplyTask):
         """The inner task that convolves on short blocks, or None."""
         if self._short is None:
             n, taps = self._short_block_length(), self._response.shape[0]
-            ok = n and taps >= self.SHORT_BLOCK_MIN_TAPS and self._ih_samples_per_frame > n
+            ok = (n and taps >= self.SHORT_BLOCK_MIN_TAPS and self._ih_samples_per_frame > n
+                  and self.ih.shape[0] >= n)
             if ok:
                 inner = Convolve(self.ih, self._time_response(), offset=self._pad_end,
                                  samples_per_frame=n - (taps - 1))
@@ -124,10 +125,20 @@ class Convolve(SpectralMultiplyTask):
             self._short = inner if ok else False
         return self._short or None
 
+    def _input_span(self, first, last):
+        start, stop = self._frame_span(first, last)
+        pad = self._pad_start + self._pad_end
+        short = self._short_blocks()
+        if short is not None:
+            return (self.ih,) + short._span_blocks(start, stop - start)[:2]
+        if self._use_fir():
+            return self.ih, start, stop - start + pad
+        return super()._input_span(first, last)
+
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
         short = self._short_blocks()
-        if short is not None and stop - start + self._pad_start + self._pad_end >= short._ih_samples_per_frame:
+        if short is not None:
             return short._compute_span(start, stop - start, out)
         if not self._use_fir():
             return super()._compute_frames(first, last, out)

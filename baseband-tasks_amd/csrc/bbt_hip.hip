@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 133
+#define BBT_VERSION 134
 
 // ---------------------------------------------------------------------------
 // errors
@@ -335,8 +335,22 @@ int bbt_pool_trim(void) {
     return 0;
 }
 int bbt_pool_set_stream(bbt_stream stream) {
+    // A change of the pool stream drains the device once: blocks are tagged with the pool
+    // stream at the time they are freed, and a block whose last kernels were queued on the
+    // previous stream may be freed (by a garbage collector, at any time) only after the switch
+    // -- it would then carry the new stream's tag and be handed out unordered.  After the
+    // drain every idle and every live block is safe under the new stream.
+    bool changed;
+    {
+        std::lock_guard<std::mutex> lock(g_pool.mu);
+        changed = g_pool.stream != (hipStream_t)stream;
+    }
+    if (changed) HIP_TRY(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lock(g_pool.mu);
     g_pool.stream = (hipStream_t)stream;
+    if (changed)
+        for (auto& per_dev : g_pool.free_blocks)
+            for (auto& b : per_dev.second) b.second.freed_on = g_pool.stream;
     return 0;
 }
 int bbt_pool_info(int64_t* cached_bytes, int64_t* live_bytes) {
@@ -356,6 +370,15 @@ int bbt_host_alloc(void** host_ptr, size_t nbytes) {
 }
 int bbt_host_free(void* host_ptr) {
     if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return 0;
+}
+int bbt_host_register(void* host_ptr, size_t nbytes) {
+    ARG_TRY(host_ptr && nbytes, "bbt_host_register: null or empty range");
+    HIP_TRY(hipHostRegister(host_ptr, nbytes, hipHostRegisterDefault));
+    return 0;
+}
+int bbt_host_unregister(void* host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostUnregister(host_ptr));
     return 0;
 }
 int bbt_memset(void* dev_ptr, int value, size_t nbytes, bbt_stream stream) {
@@ -475,6 +498,10 @@ int bbt_event_sync(bbt_event ev) {
     HIP_TRY(hipEventSynchronize((hipEvent_t)ev));
     return 0;
 }
+int bbt_stream_wait_event(bbt_stream stream, bbt_event ev) {
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return 0;
+}
 int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms) {
     ARG_TRY(ms, "bbt_event_elapsed_ms: null argument");
     HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
@@ -536,6 +563,10 @@ struct bbt_osm_plan {
     hipEvent_t ev_pass[3][BBT_MAX_LANES] = {};
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
+    // four-step twiddles of two-level plans as tables (owned): W_{16 N1}^{k1 j} [N1][16] and
+    // W_N^{k1 tau} [N1][N2 / 16]
+    cf* tw4row = nullptr;
+    cf* tw4base = nullptr;
     cf* wroot = nullptr;
     // block lengths that are not powers of two (gen_kernels.hpp): N = n1 * n2,
     // n1 == 1 for N <= 8192
@@ -585,7 +616,7 @@ static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, 
                        flat ? dim3(p->n1 * ch.nblk * p->npair, 1) : dim3(p->n1, rows),
                        dim3(N2 / 16), 0,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
-                       p->wroot, p->wroot + 4096, ch, p->outer, y0);
+                       p->wroot, p->wroot + 4096, ch, p->outer, y0, p->tw4row, p->tw4base);
 }
 
 // (row length, channels) -> instantiation; nch == 0 is the plain row pass.
@@ -1255,6 +1286,17 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
         if (p->n1 == 4096 && get_tables(4096, &p->tab1)) return bail(1);
         if (get_wroot(&p->wroot)) return bail(1);
+        static const bool tw4_tables = [] { const char* e = getenv("BBT_OSM_TW4_TABLES"); return !(e && atoi(e) == 0); }();
+        if (tw4_tables && p->outer == 1 && (p->n1 == 16 || p->n1 == 256)) {
+            const int t = p->n2 / 16;
+            std::vector<cf> row((size_t)p->n1 * 16), base((size_t)p->n1 * t);
+            for (int k1 = 0; k1 < p->n1; ++k1) {
+                for (int j = 0; j < 16; ++j) row[(size_t)k1 * 16 + j] = unit_root((long long)k1 * j, 16ll * p->n1);
+                for (int tau = 0; tau < t; ++tau)
+                    base[(size_t)k1 * t + tau] = unit_root((long long)k1 * tau, n_fft);
+            }
+            if (upload(&p->tw4row, row) || upload(&p->tw4base, base)) return bail(1);
+        }
     }
 
     // response: upload (if needed), permute to [C][N1][N2], scale by 1/N
@@ -1378,6 +1420,8 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     for (auto e : p->ev_free) hipEventDestroy(e);
     if (p->resp) hipFree(p->resp);
     if (p->resp_index) hipFree(p->resp_index);
+    if (p->tw4row) hipFree(p->tw4row);
+    if (p->tw4base) hipFree(p->tw4base);
     if (p->tlo) hipFree(p->tlo);
     if (p->thi) hipFree(p->thi);
     for (int l = 0; l < BBT_MAX_LANES; ++l) {

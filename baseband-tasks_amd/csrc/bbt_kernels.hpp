@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
     const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
-    OsmChunk ch, int outer, int y0) {
+    OsmChunk ch, int outer, int y0, const cf* __restrict__ tw4row, const cf* __restrict__ tw4base) {
     // Three-level transforms (N > 2^20) run this pass once per row k1o of the
     // outer 256-point level: blockIdx.y = (block * npair + pair) * outer + k1o;
     // the full frequency index is k = k1o + outer * (k1 + N1 * k2).  outer == 1
@@ -1081,9 +1081,15 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     c2 v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = ld_int(row + (long long)(tau + T * j) * 2);
-    // W_N^{k1 (tau + T j)} = W_N^{k1 tau} * W_{16 N1}^{k1 j},  N = N1 * N2
+    // W_N^{k1 (tau + T j)} = W_N^{k1 tau} * W_{16 N1}^{k1 j},  N = N1 * N2.  Two-level plans bring
+    // both factors as tables (tw4base [N1][T] per thread, tw4row [N1][16] per row: its 16 values
+    // are one or two wide scalar loads, where evaluating them from the W_4096 table was sixteen
+    // scalar loads one waiting for the other, and the thread's factor a sincospif each way).
+    const bool tw4 = tw4row != nullptr;
     cf base;
-    {
+    if (tw4) {
+        base = tw4base[k1 * T + tau];
+    } else {
         float s, c;
         const float ang = -2.0f * (float)(k1 * tau) / ((float)N1 * (float)N2);
         sincospif(ang, &s, &c);
@@ -1099,7 +1105,11 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         return cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
     };
 #if !(BBT_DBG & 1)
-    if (N1 > 1) {
+    if (tw4) {
+        const cf* tr = tw4row + k1 * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, tr[j]));
+    } else if (N1 > 1) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, wrow(j)));
     }
@@ -1145,6 +1155,14 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
             const cf wi = wrow(j);
             v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
         }
+    } else if (tw4 && !(BBT_DBG & 1)) {
+        // (the tables again, through opaque moves: see below)
+        const cf* tr = tw4row + k1 * 16;
+        const cf* tb = tw4base;
+        asm volatile("" : "+s"(tr), "+s"(tb));
+        const cf base2 = tb[k1 * T + tau];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(base2, tr[j]));
     } else if (N1 > 1 && !(BBT_DBG & 1)) {
         // Evaluate the twiddles again instead of keeping the 16 products of the
         // forward step alive through both transforms (the compiler did: 199
@@ -1979,8 +1997,12 @@ __global__ __launch_bounds__(256) void k_fir_blocks(const float2* __restrict__ i
 //   raw   : n_frames frames of frame_bytes, payload after header_bytes
 //   out   : float32 [(set * spf + t) * n_thread + thread][e], e < E; frame f
 //           belongs to set f / n_thread, thread f % n_thread
-//   code 0: VDIF levels -- 1 bit {-1, +1}; 2 bits {-3.3359, -1, +1, +3.3359};
-//           4 bits (v - 8) / 2.95; 8 / 16 bits offset binary v - 2^(bits-1)
+//   code 0: VDIF levels as `baseband` decodes them (its base/encoding.py, restated from the
+//           published source -- the package is not in this image): 1 bit {-1, +1}; 2 bits
+//           {-3.3359, -1, +1, +3.3359} (OPTIMAL_2BIT_HIGH); 4 bits (v - 8) / 2.95
+//           (FOUR_BIT_1_SIGMA); 8 bits (v - 127.5) / 35.5 (EIGHT_BIT_1_SIGMA: 0..255 encode
+//           -127.5..127.5, scaled to look like 2-bit data); 16 bits offset binary v - 2^15
+//           (no `baseband` decoder to follow)
 //   code 1: two's complement integers (8 or 16 bits)
 // One frame per blockIdx.x, 256 * G consecutive components of it per
 // blockIdx.y: a thread decodes G (1, 2 or 4, dividing E) components that are
@@ -1992,6 +2014,7 @@ __device__ __forceinline__ float unpack_level(unsigned v, int bits, int code) {
     if (bits == 1) return v ? 1.f : -1.f;
     if (bits == 2) return v == 0 ? -3.3359f : (v == 1 ? -1.f : (v == 2 ? 1.f : 3.3359f));
     if (bits == 4) return ((float)v - 8.f) / 2.95f;
+    if (bits == 8) return ((float)v - 127.5f) / 35.5f;
     return (float)v - (float)(1u << (bits - 1));
 }
 #define BBT_UNPACK_ITER 4     // groups of G components per thread

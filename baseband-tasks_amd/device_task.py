@@ -9,6 +9,7 @@ the cache (valid until the next read on the same task).
 import numpy as np
 
 from . import hip
+from . import host_pipeline
 from .hip import DeviceArray
 
 __all__ = ['DeviceTaskMixin', 'fetch_device']
@@ -19,12 +20,54 @@ def fetch_device(ih, start, count):
 
     Streams of this package hand over device memory directly; any other
     stream reader (e.g. a `baseband` file handle) is read on the host and
-    uploaded.
+    uploaded -- through the stream's `host_pipeline.HostUploader`, which may
+    have the range on its way already (`prefetch_device`).
     """
-    ih.seek(start)
-    if hasattr(ih, 'read_device'):
+    if produces_on_device(ih):
+        ih.seek(start)
         return ih.read_device(count)
+    up = host_pipeline.uploader_for(ih) if count > 0 else None
+    if up is not None:
+        return up.fetch(start, count)
+    ih.seek(start)
     return DeviceArray.from_host(ih.read(count))
+
+
+def produces_on_device(ih):
+    """Does ``ih.read_device`` hand over samples that are (made) in HBM -- a device task, a
+    `DeviceStream`, an unpacking reader -- rather than upload what ``ih.read`` returns (the
+    fallback every `Base` stream has)?"""
+    return bool(getattr(ih, '_produces_on_device', False))
+
+
+def host_request(ih, start, count):
+    """Follow a chain of device tasks down to the host stream that a fetch of
+    samples [start, start+count) of ``ih`` would read: (host stream, start,
+    count), or None if the chain ends on the device or a task on the way
+    cannot say what it needs (`_input_span`)."""
+    for _ in range(16):
+        if not produces_on_device(ih):
+            return ih, start, count
+        span = getattr(ih, '_input_span_of_samples', None)
+        nxt = span(start, count) if span is not None else None
+        if nxt is None:
+            return None
+        ih, start, count = nxt
+    return None
+
+
+def prefetch_device(ih, start, count):
+    """Start the upload of what `fetch_device(ih, start, count)` will need, if
+    that comes from a host stream (no-op otherwise)."""
+    try:
+        req = host_request(ih, start, count)
+    except Exception:
+        return
+    if req is None:
+        return
+    up = host_pipeline.uploader_for(req[0])
+    if up is not None:
+        up.prefetch(req[1], req[2])
 
 
 class DeviceTaskMixin:
@@ -35,6 +78,7 @@ class DeviceTaskMixin:
     """
     #: upper bound on frames computed by one call (bounds device memory)
     max_frames_per_call = 32
+    _produces_on_device = True
 
     @property
     def _device_dtype(self):
@@ -119,10 +163,84 @@ class DeviceTaskMixin:
         self.offset += count
         return view
 
+    def _input_span(self, first, last):
+        """(upstream, start, count): the one `fetch_device` call that computing
+        frames [first, last) makes, or None if the task cannot tell in advance.
+        Lets ``read`` start the upload of the next run of frames while this one
+        is computed."""
+        return None
+
+    def _input_span_of_samples(self, start, count):
+        """`_input_span` for the frames a ``read_device(count)`` at ``start`` would compute."""
+        spf = self.samples_per_frame
+        first, last = start // spf, (start + count - 1) // spf + 1
+        if self._cache is not None and self._cache_first <= first and last <= self._cache_last:
+            return None
+        if last - first > self.max_frames_per_call:
+            return None
+        return self._input_span(first, last)
+
+    #: Frames per run of the pipelined host path of ``read`` (upload, transforms and
+    #: download of consecutive runs overlap); None: `max_frames_per_call`.
+    host_frames_per_run = None
+
+    def _read_pipelined(self, count, out):
+        """``read`` with the three stages of consecutive runs of frames overlapping
+        (host_pipeline.py): while run m is computed on the current stream, the input
+        of run m + 1 is read and uploaded by the host stream's worker and the result
+        of run m - 1 goes down on a stream of its own, into page-locked memory."""
+        spf = self.samples_per_frame
+        per = self.host_frames_per_run or self.max_frames_per_call
+        runs, pos, done = [], self.offset, 0
+        while done < count:
+            f0 = pos // spf
+            f1 = min((pos + (count - done) - 1) // spf + 1, f0 + per)
+            n = min(count - done, self._frame_span(f0, f1)[1] - pos)
+            runs.append((f0, f1, pos, done, n))
+            pos += n
+            done += n
+        if self._download is None:
+            self._download = host_pipeline.Stream()
+        down = self._download
+        # two result buffers in turn: run m + 2 is computed into the buffer run m came from, once
+        # that run has gone down
+        buffers = [self._cache_buffer, self._cache_buffer_b]
+        gone = [None, None]
+        computed = host_pipeline.StreamEvent()
+        for i, (f0, f1, pos, done, n) in enumerate(runs):
+            if i + 1 < len(runs):
+                nxt = self._input_span(runs[i + 1][0], runs[i + 1][1])
+                if nxt is not None:
+                    prefetch_device(*nxt)
+            b = i % 2
+            self._cache_buffer = buffers[b]
+            if gone[b] is not None:
+                host_pipeline.current_stream_wait(gone[b])
+            cache, c0 = self._ensure_frames(f0, f1)
+            buffers[b] = self._cache_buffer
+            piece = cache[pos - c0:pos - c0 + n]
+            target = out[done:done + n]
+            computed.record()
+            down.wait(computed)
+            hip.check(hip.lib().bbt_memcpy_d2h(target.ctypes.data, piece.ptr, piece.nbytes, down.handle))
+            gone[b] = host_pipeline.StreamEvent().record(down)
+            self.offset = pos + n
+        self._cache_buffer_b = buffers[(len(runs)) % 2]      # (the other one stays the cache's)
+        down.synchronize()
+        return out
+
+    _download = None
+    _cache_buffer_b = None
+
     def read(self, count=None, out=None):
         count = self._prepare_read(count, out)
+        pipelined = host_pipeline.ENABLED and count > 0
         if out is None:
-            out = np.empty((count,) + tuple(self.sample_shape), dtype=self._device_dtype)
+            empty = host_pipeline.pinned_empty if pipelined else np.empty
+            out = empty((count,) + tuple(self.sample_shape), dtype=self._device_dtype)
+        if (pipelined and isinstance(out, np.ndarray) and out.flags.c_contiguous
+                and out.dtype == self._device_dtype and host_pipeline.is_pinned(out)):
+            return self._read_pipelined(count, out)
         spf = self.samples_per_frame
         done = 0
         while done < count:
@@ -155,7 +273,7 @@ class DeviceTaskMixin:
         return self._frame, skip
 
     def _drop_cache(self):
-        self._cache = self._cache_buffer = None
+        self._cache = self._cache_buffer = self._cache_buffer_b = None
         self._cache_first = self._cache_last = 0
 
     def invalidate_cache(self):

@@ -169,9 +169,35 @@ class HipFFTMaker(FFTMakerBase):
         return HipFFT(tuple(shape), dtype, operator.index(axis), direction, ortho, sample_rate)
 
     @staticmethod
-    def next_fast_len(n):
+    def _transformable(n):
+        """Can a plan be made for block length ``n``?  Powers of two up to 2^24; other
+        products of 2, 3, 5, 7 up to 8192, or beyond that if they split into two factors of
+        at most 8192 each (split_7smooth in csrc/bbt_hip.hip).  52 of the 3174 such lengths
+        up to 2^26 do not (the smallest: 20 588 575 = 5^2 7^7)."""
+        if n & (n - 1) == 0 or n <= 8192:
+            return True
+        d = int(np.sqrt(n))
+        while d * d > n:
+            d -= 1
+        while d >= 1:
+            if n % d == 0:
+                return n // d <= 8192
+            d -= 1
+        return False
+
+    @classmethod
+    def next_fast_len(cls, n):
         """Smallest 2^a 3^b 5^c 7^d >= n -- the rule of the reference's NumPy
-        engine (fourier/numpy.py:99-126), so that default block lengths agree."""
+        engine (fourier/numpy.py:99-126), so that default block lengths agree --
+        skipping the few such lengths this library cannot split into two transforms
+        (`_transformable`; the reference has no such limit)."""
+        fast = cls._next_smooth(n)
+        while not cls._transformable(fast):
+            fast = cls._next_smooth(fast + 1)
+        return fast
+
+    @staticmethod
+    def _next_smooth(n):
         n = operator.index(n)
         if n <= 7:
             return n

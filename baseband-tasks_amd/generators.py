@@ -5,7 +5,7 @@ import numpy as np
 from .base import Base
 from .hip import DeviceArray, as_device_array
 
-__all__ = ['StreamGenerator', 'EmptyStreamGenerator', 'Noise', 'NoiseGenerator',
+__all__ = ['StreamGenerator', 'EmptyStreamGenerator', 'Noise', 'NoiseGenerator', 'HostStream',
            'DeviceStream']
 
 
@@ -66,6 +66,52 @@ class NoiseGenerator(StreamGenerator):
                          dtype=dtype, **kwargs)
 
 
+class HostStream(Base):
+    """A stream whose samples sit in a NumPy array (or memory map) on the host:
+    the host-side counterpart of `DeviceStream`, for data that does not come
+    from a file reader.  ``read(out=...)`` is one copy; a device task on top
+    uploads straight from the array when its memory is page-locked (``pin``:
+    lock it in place with hipHostRegister -- on by default for C-contiguous
+    arrays; arrays from `host_pipeline.pinned_empty` are pinned already), run
+    m + 1 going up while run m is transformed (host_pipeline.py)."""
+
+    def __init__(self, data, start_time, sample_rate, samples_per_frame=None, *, pin=True, **kwargs):
+        self._data = data if isinstance(data, np.ndarray) else np.asarray(data)
+        if samples_per_frame is None:
+            samples_per_frame = min(self._data.shape[0], 1 << 20)
+        self._pinned = None
+        self._pin = bool(pin)
+        super().__init__(shape=self._data.shape, start_time=start_time, sample_rate=sample_rate,
+                         samples_per_frame=samples_per_frame, dtype=self._data.dtype, **kwargs)
+
+    def host_view(self, start, count):
+        """The samples [start, start + count) as a view of the array if it is
+        C-contiguous and page-locked, else None."""
+        if self._pinned is None:
+            from . import host_pipeline
+            self._pinned = bool(self._data.flags.c_contiguous and
+                                (host_pipeline.is_pinned(self._data) or
+                                 (self._pin and host_pipeline.pin_array(self._data))))
+        return self._data[start:start + count] if self._pinned else None
+
+    def read(self, count=None, out=None):
+        count = self._prepare_read(count, out)
+        piece = self._data[self.offset:self.offset + count]
+        self.offset += count
+        if out is None:
+            return piece.copy()
+        out[...] = piece
+        return out
+
+    def _read_frame(self, frame_index):
+        start = frame_index * self.samples_per_frame
+        return self._data[start:min(start + self.samples_per_frame, self.shape[0])].copy()
+
+    def close(self):
+        super().close()
+        self._data = None
+
+
 class DeviceStream(Base):
     """A stream resident in HBM.
 
@@ -73,6 +119,7 @@ class DeviceStream(Base):
     array / stream of this package (which is uploaded once).  ``read_device``
     returns zero-copy views, so a task chain on top never touches the host.
     """
+    _produces_on_device = True
 
     def __init__(self, data, start_time, sample_rate, samples_per_frame=None, **kwargs):
         if isinstance(data, np.ndarray):

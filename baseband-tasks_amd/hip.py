@@ -61,6 +61,9 @@ SIGNATURES = {
     'bbt_event_destroy': [_vp],
     'bbt_event_record': [_vp, _vp],
     'bbt_event_sync': [_vp],
+    'bbt_stream_wait_event': [_vp, _vp],
+    'bbt_host_register': [_vp, _sz],
+    'bbt_host_unregister': [_vp],
     'bbt_event_elapsed_ms': [_vp, _vp, C.POINTER(C.c_float)],
     'bbt_osm_plan_create': [_pvp, _i64, _int, _int, _vp, _int, _pi32],
     'bbt_osm_plan_destroy': [_vp],
@@ -189,6 +192,12 @@ def available():
 
 def set_device(index):
     check(lib().bbt_set_device(int(index)))
+
+
+def get_device():
+    index = _int(0)
+    check(lib().bbt_get_device(C.byref(index)))
+    return index.value
 
 
 def device_name():

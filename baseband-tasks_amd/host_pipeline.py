@@ -1,0 +1,329 @@
+"""The host path of ``read()``: NumPy in, NumPy out, PCIe both ways at once.
+
+The reference's ``Base.read`` (base.py:389-438) returns host arrays and pulls
+its input frame by frame from a host reader (base.py:699-706).  Kept as it is
+on a GPU that means: read a run of input blocks, copy them up, compute, copy
+the result down, and only then touch the next run -- the bus idle while the
+GPU computes and the GPU idle while the bus moves data, both through pageable
+memory (0.25-0.30 Gsamples/s for the metric pipeline, round 2).  Here the
+three stages of consecutive runs overlap:
+
+* `HostUploader` (one per host stream that feeds a device task): a worker
+  thread reads run m + 1 from the stream -- straight into page-locked memory,
+  or not at all when the stream's samples already sit in page-locked memory
+  (`HostStream`) -- and queues its upload on a stream of its own, while the
+  caller's stream computes run m;
+* `DeviceTaskMixin.read` queues the download of run m - 1 on a third stream,
+  into a page-locked result array (`pinned_empty`: what ``read`` returns is an
+  ordinary ndarray whose memory happens to be pinned and goes back to a small
+  pool when the array is garbage collected).
+
+Events order the three streams (`bbt_stream_wait_event`); nothing here touches
+the kernels.  ``BBT_HOST_PIPELINE=0`` switches back to the synchronous copies.
+"""
+import ctypes as C
+import os
+import threading
+import weakref
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import hip
+
+__all__ = ['ENABLED', 'pinned_empty', 'is_pinned', 'Stream', 'StreamEvent', 'HostUploader', 'uploader_for']
+
+ENABLED = os.environ.get('BBT_HOST_PIPELINE', '1') != '0'
+
+
+# --------------------------------------------------------------------------- page-locked host arrays
+class _PinnedPool:
+    """Page-locked blocks by size; blocks of garbage-collected arrays come back
+    here instead of going through hipHostFree / hipHostMalloc again (both take
+    milliseconds per GB)."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.free = {}                      # nbytes -> [ptr, ...]
+        self.cached = 0
+        self.ranges = {}                    # ptr -> nbytes of every live or cached block
+        self.limit = int(float(os.environ.get('BBT_PINNED_POOL_GB', '48')) * 2**30)
+
+    def take(self, nbytes):
+        with self.lock:
+            stack = self.free.get(nbytes)
+            if stack:
+                self.cached -= nbytes
+                return stack.pop()
+        ptr = C.c_void_p()
+        hip.check(hip.lib().bbt_host_alloc(C.byref(ptr), nbytes))
+        with self.lock:
+            self.ranges[ptr.value] = nbytes
+        return ptr.value
+
+    def give(self, ptr, nbytes):
+        with self.lock:
+            if self.cached + nbytes <= self.limit:
+                self.free.setdefault(nbytes, []).append(ptr)
+                self.cached += nbytes
+                return
+            self.ranges.pop(ptr, None)
+        try:
+            hip.lib().bbt_host_free(ptr)
+        except Exception:
+            pass
+
+    def trim(self):
+        with self.lock:
+            blocks = [p for stack in self.free.values() for p in stack]
+            self.free.clear()
+            self.cached = 0
+            for p in blocks:
+                self.ranges.pop(p, None)
+        for p in blocks:
+            hip.lib().bbt_host_free(p)
+
+    def covers(self, address, nbytes):
+        with self.lock:
+            for ptr, size in self.ranges.items():
+                if ptr <= address and address + nbytes <= ptr + size:
+                    return True
+        return False
+
+
+_pool = _PinnedPool()
+_registered = {}            # address -> nbytes of ranges page-locked in place (pin_array)
+
+
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.nbytes = nbytes
+        self.ptr = _pool.take(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _pool.give(self.ptr, self.nbytes)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.complex64):
+    """``np.empty(shape, dtype)`` in page-locked memory (sizes rounded up to 2 MiB so that
+    repeated reads of about the same size find their block in the pool)."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(s) for s in (shape if np.ndim(shape) else (shape,)))
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if n == 0:
+        return np.empty(shape, dtype)
+    block = _PinnedBlock(-(-n // (2 << 20)) * (2 << 20))
+    buf = (C.c_ubyte * n).from_address(block.ptr)
+    buf._bbt_block = block                       # the array's base keeps the block alive
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def pin_array(array):
+    """Page-lock the memory of ``array`` in place (hipHostRegister); returns True if it is
+    pinned afterwards.  The registration is undone when ``array`` is garbage collected."""
+    if not isinstance(array, np.ndarray) or not array.flags.c_contiguous or array.nbytes == 0:
+        return False
+    address = array.ctypes.data
+    if is_pinned(array):
+        return True
+    try:
+        hip.check(hip.lib().bbt_host_register(address, array.nbytes))
+    except hip.HipError:
+        return False
+    _registered[address] = array.nbytes
+
+    def release(address=address):
+        _registered.pop(address, None)
+        try:
+            hip.lib().bbt_host_unregister(address)
+        except Exception:
+            pass
+    try:
+        weakref.finalize(array if array.base is None else array.base, release)
+    except TypeError:
+        pass
+    return True
+
+
+def is_pinned(array):
+    """Does ``array`` (C-contiguous) lie in memory this module page-locked?"""
+    if not isinstance(array, np.ndarray) or not array.flags.c_contiguous:
+        return False
+    address, n = array.ctypes.data, array.nbytes
+    for ptr, size in list(_registered.items()):
+        if ptr <= address and address + n <= ptr + size:
+            return True
+    return _pool.covers(address, n)
+
+
+# --------------------------------------------------------------------------- streams and events
+class Stream:
+    def __init__(self):
+        self._h = C.c_void_p()
+        hip.check(hip.lib().bbt_stream_create(C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h.value
+
+    def synchronize(self):
+        hip.check(hip.lib().bbt_stream_sync(self._h))
+
+    def wait(self, event):
+        hip.check(hip.lib().bbt_stream_wait_event(self._h, event._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                hip.lib().bbt_stream_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class StreamEvent:
+    """An event recorded on an explicit stream (``None``: the package's current stream)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        hip.check(hip.lib().bbt_event_create(C.byref(self._h)))
+
+    def record(self, stream=None):
+        handle = hip.get_stream() if stream is None else stream.handle
+        hip.check(hip.lib().bbt_event_record(self._h, handle))
+        return self
+
+    def synchronize(self):
+        hip.check(hip.lib().bbt_event_sync(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                hip.lib().bbt_event_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def current_stream_wait(event):
+    hip.check(hip.lib().bbt_stream_wait_event(hip.get_stream(), event._h))
+
+
+# --------------------------------------------------------------------------- uploads
+class _Upload:
+    __slots__ = ('start', 'count', 'dev', 'event', 'staging')
+
+
+class HostUploader:
+    """Uploads of sample ranges of one host stream, one range ahead.
+
+    ``fetch(start, count)`` returns the samples as a `hip.DeviceArray`, ordered
+    before later work on the package's current stream; ``prefetch(start,
+    count)`` starts reading and uploading a range in the background (one at a
+    time), for the ``fetch`` of the same range that follows.  The host stream
+    is only ever touched by one thread at a time: ``fetch`` waits for a running
+    prefetch before anything else.
+    """
+
+    def __init__(self, ih):
+        self._ih = weakref.ref(ih)
+        self._row = tuple(ih.shape[1:])
+        self._dtype = np.dtype(ih.dtype)
+        self._stream = Stream()
+        self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='bbt-upload')
+        self._device = hip.get_device() if hasattr(hip, 'get_device') else 0
+        self._pending = None            # (start, count, future)
+        self._staging = [None, None]    # page-locked staging arrays (streams that are not pinned themselves)
+        self._staging_event = [None, None]
+        self._turn = 0
+
+    # -- the one place the host stream is read
+    def _load(self, start, count, after):
+        ih = self._ih()
+        up = _Upload()
+        up.start, up.count, up.staging = start, count, None
+        hip.set_device(self._device)
+        shape = (count,) + self._row
+        view = None
+        if hasattr(ih, 'host_view'):
+            view = ih.host_view(start, count)            # zero copy, if the stream's memory is pinned
+            if view is not None and not is_pinned(view):
+                view = None
+        if view is None:
+            slot = self._turn
+            self._turn ^= 1
+            if self._staging_event[slot] is not None:
+                self._staging_event[slot].synchronize()   # its previous upload has left the buffer
+            buf = self._staging[slot]
+            n = int(np.prod(shape, dtype=np.int64))
+            if buf is None or buf.size < n:
+                buf = self._staging[slot] = pinned_empty((n,), self._dtype)
+            view = buf[:n].reshape(shape)
+            ih.seek(start)
+            got = ih.read(count, out=view)
+            if got is not view:
+                view[...] = got
+            up.staging = slot
+        up.dev = hip.DeviceArray(shape, self._dtype)
+        if after is not None:
+            self._stream.wait(after)                      # the block's previous users (pool reuse)
+        hip.check(hip.lib().bbt_memcpy_h2d(up.dev.ptr, view.ctypes.data, view.nbytes, self._stream.handle))
+        up.event = StreamEvent().record(self._stream)
+        if up.staging is not None:
+            self._staging_event[up.staging] = up.event
+        return up
+
+    def _submit(self, start, count):
+        # device blocks come from the pool, whose reuse is ordered by the current stream: the upload
+        # must not start before what is queued there now (a freed block's last readers) has run
+        after = StreamEvent().record()
+        return self._worker.submit(self._load, int(start), int(count), after)
+
+    def prefetch(self, start, count):
+        ih = self._ih()
+        if ih is None or self._pending is not None or count <= 0 or start < 0 or start + count > ih.shape[0]:
+            return
+        self._pending = (int(start), int(count), self._submit(start, count))
+
+    def fetch(self, start, count):
+        pending, self._pending = self._pending, None
+        up = None
+        if pending is not None:
+            got = pending[2].result()                     # (also: the stream is free again)
+            if (pending[0], pending[1]) == (int(start), int(count)):
+                up = got
+        if up is None:
+            up = self._submit(start, count).result()
+        current_stream_wait(up.event)
+        return up.dev
+
+    def close(self):
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            try:
+                pending[2].result()
+            except Exception:
+                pass
+        self._worker.shutdown(wait=True)
+
+
+_uploaders = weakref.WeakKeyDictionary()
+
+
+def uploader_for(ih):
+    """The `HostUploader` of host stream ``ih`` (created on first use), or None when the
+    pipeline is off or the stream cannot be weakly referenced."""
+    if not ENABLED:
+        return None
+    try:
+        up = _uploaders.get(ih)
+        if up is None:
+            up = _uploaders[ih] = HostUploader(ih)
+        return up
+    except TypeError:
+        return None

@@ -5,11 +5,14 @@ SURVEY 8(f) rank 3.  The reference is fed by `baseband` stream readers
 `baseband` nor any sample file is part of the reference tree or of this image.
 These readers therefore follow the published formats -- VDIF 1.1.1 (header
 words 0-3, extended data version 1/3 sample rate; little-endian 32-bit payload
-words with the first sample in the least significant bits; 2-bit levels
--3.3359, -1, +1, +3.3359; 4-bit (v - 8) / 2.95; 8-bit offset binary) and the
-PSRDADA ASCII header with signed 8-bit samples -- and are checked only against
-this package's own encoder in the tests.  PARITY UNPINNED: nothing here has
-been compared with `baseband` output.
+words with the first sample in the least significant bits; levels as
+`baseband` decodes them: 2-bit -3.3359, -1, +1, +3.3359; 4-bit (v - 8) / 2.95;
+8-bit (v - 127.5) / 35.5; 16-bit offset binary) and the PSRDADA ASCII header
+with signed 8-bit samples -- and are checked only against this package's own
+encoder in the tests.  PARITY UNPINNED: nothing here has been compared with
+`baseband` output, and nothing can be in this image: the reference's tests take
+their VDIF / DADA sample files from that package (tests/common.py:6-25), which
+is absent, so no reference-held vector exists for this row.
 
 The raw bytes are uploaded as they are; unpacking happens in HBM
 (libbbt_hip: bbt_unpack), so a chain ``Dedisperse(open_vdif(...))`` moves
@@ -210,6 +213,8 @@ def encode_vdif_frames(data, bits, *, seconds=0, ref_epoch=40, frame_nr0=0, fram
         codes = np.searchsorted(np.array([-2., 0., 2.]), comp).astype(np.uint32)
     elif bits == 4:
         codes = np.clip(np.rint(comp * 2.95 + 8.), 0, 15).astype(np.uint32)
+    elif bits == 8:
+        codes = np.clip(np.rint(comp * 35.5 + 127.5), 0, 255).astype(np.uint32)
     else:
         codes = np.clip(np.rint(comp + (1 << (bits - 1))), 0, (1 << bits) - 1).astype(np.uint32)
     spf = n if samples_per_frame is None else samples_per_frame

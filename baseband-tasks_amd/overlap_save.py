@@ -179,6 +179,13 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             return None
         return up
 
+    def _input_span(self, first, last):
+        in0, in_len = self._block_descriptors(first, last)[:2]
+        up = self._prefilter_input()
+        if up is not None:
+            return up.ih, in0, in_len + up._pad_start + up._pad_end
+        return self.ih, in0, in_len
+
     def _compute_frames(self, first, last, out):
         in0, in_len, starts, out_abs, keep, counts = self._block_descriptors(first, last)
         out_off = out_abs - first * self.samples_per_frame
@@ -192,25 +199,55 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         x = fetch_device(self.ih, in0, in_len)
         self._run_plan(x, out, in_len, out.shape[0], starts - in0, out_off, keep, counts)
 
+    def _span_blocks(self, start, n_out):
+        """Blocks of the ABSOLUTE grid that hold output samples [start, start + n_out): block k
+        reads input [k hop, k hop + N) and yields outputs [k hop, (k + 1) hop); past the last
+        block that fits the input, one block re-aligned to end with the stream yields the rest
+        (as `PaddedTaskBase._block_start` does for frames).  The same sample is always computed
+        from the same block, whatever the request -- results do not depend on how a caller cuts
+        its reads.  Returns (first input sample, input length, first regular block, number of
+        regular whole blocks, [(in_off, out_off, valid_start, count), ...] for the clipped or
+        re-aligned blocks), offsets relative to the fetched input / to ``start``."""
+        n, pad, keep = self._ih_samples_per_frame, self._pad_start + self._pad_end, self._keep_from
+        hop, total = n - pad, self.ih.shape[0]
+        stop = start + n_out
+        k_fit = (total - n) // hop                       # last block of the grid that fits the input
+        k0, k1 = start // hop, (stop - 1) // hop
+        in0 = min(k0 * hop, total - n)
+        in_end = min(k1 * hop + n, total)
+        odd = []
+
+        def clipped(block_in, first_out, last_out):      # outputs [first_out, last_out) of a block at block_in
+            lo, hi = max(first_out, start), min(last_out, stop)
+            if hi > lo:
+                odd.append((block_in - in0, lo - start, keep + lo - block_in, hi - lo))
+        ka, kb = k0, min(k1, k_fit)                       # regular blocks ka .. kb
+        if ka <= kb and (ka * hop < start or (ka + 1) * hop > stop):
+            clipped(ka * hop, ka * hop, (ka + 1) * hop)
+            ka += 1
+        if ka <= kb and (kb + 1) * hop > stop:
+            clipped(kb * hop, kb * hop, (kb + 1) * hop)
+            kb -= 1
+        if k1 > k_fit:                                    # the end of the stream: one re-aligned block
+            clipped(total - n, (k_fit + 1) * hop, total - pad)
+        return in0, in_end - in0, ka, max(kb - ka + 1, 0), odd
+
     def _compute_span(self, start, n_out, out):
-        """Output samples [start, start + n_out) into ``out``, whatever the frame
-        boundaries: a run of regular blocks (one launch for plans of one kernel,
-        bbt_osm_execute_regular) and a last block re-aligned to end with the
-        input.  For tasks whose result does not depend on the block geometry
-        (exact linear convolutions).  Needs ``n_out + pad >= block length``."""
-        n, pad = self._ih_samples_per_frame, self._pad_start + self._pad_end
-        hop, n_in, keep = n - pad, n_out + pad, self._keep_from
-        assert n_in >= n
-        x = fetch_device(self.ih, start, n_in)
-        n_full, rest = divmod(n_out, hop)
+        """Output samples [start, start + n_out) into ``out``, whatever this task's frame
+        boundaries, on the absolute block grid of `_span_blocks` (whole blocks in one launch for
+        plans of one kernel, bbt_osm_execute_regular).  For tasks whose result does not depend
+        on the block geometry (exact linear convolutions)."""
+        hop = self._ih_samples_per_frame - self._pad_start - self._pad_end
+        in0, in_len, ka, n_regular, odd = self._span_blocks(start, n_out)
+        x = fetch_device(self.ih, in0, in_len)
 
         def run(plan, x, target):
-            if n_full:
-                plan.execute_regular(x, target, n_full, 0, 0, hop, keep)
-            if rest:
-                plan.execute(x, target, [n_in - n], [n_full * hop], [keep + hop - rest], [rest])
+            if n_regular:
+                plan.execute_regular(x, target, n_regular, ka * hop - in0, ka * hop - start, hop, self._keep_from)
+            if odd:
+                plan.execute(x, target, *(list(col) for col in zip(*odd)))
 
-        self._run_plan(x, out, n_in, n_out, executor=run)
+        self._run_plan(x, out, in_len, n_out, executor=run)
 
     def close(self):
         super().close()

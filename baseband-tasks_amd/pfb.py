@@ -282,9 +282,19 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         self._ft_inverse_cache = None
 
     def next_fast_len(self, m):
-        """A fast length that is a whole number of blocks of n samples (reference
-        pfb.py:236-241), the number of blocks itself being a length the engine
-        transforms (the transform here runs along the block axis)."""
+        """A fast length that is a whole number of blocks of n samples, the number
+        of blocks itself being a length the engine transforms (the transform here
+        runs along the block axis).
+
+        DEVIATION from the reference (pfb.py:236-241), which only rounds the fast
+        length up to a multiple of n: its number of blocks can be any integer
+        (6208 = 97 x 64 samples for m = 6144 + 1, n = 64), here it is the next
+        product of 2, 3, 5, 7 (6272 = 98 x 64).  The Wiener deconvolution is
+        circular along the block axis, so with default arguments the frame
+        geometry -- and the samples near frame edges, below the padding's
+        accuracy -- can differ from the reference's; pass ``samples_per_frame``
+        such that ``(samples_per_frame + pad) / n`` is 7-smooth (as the reference's
+        own tests do) for identical frames."""
         blocks = -(-self._FFT.next_fast_len(m) // self._n)
         return self._FFT.next_fast_len(blocks) * self._n
 
@@ -330,8 +340,11 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         x = x.reshape(x.shape[0] // n, n * s)
         geo = plan.info()
         n_rows = self._reshape[0]
-        if (not self._real and geo['n1'] == 1 and n_rows <= 4096 and not n_rows & (n_rows - 1)
-                and int(counts.max()) * s < 2**31 and (off * s) % 2 == 0):
+        if (not self._real and geo['n1'] == 1 and 256 <= n_rows <= 4096 and not n_rows & (n_rows - 1)
+                and int(counts.max()) * s < 2**31 and (off * s) % 2 == 0
+                and (spf * s) % 2 == 0 and np.all((counts * s) % 2 == 0)):
+            # (bbt_osm_execute_flat takes even element offsets and counts: one stream with an
+            # odd number of kept samples -- a short last frame -- takes the route below)
             # one kernel per block: it writes the kept samples -- from the middle of a row of the
             # block axis on -- straight to their place (no intermediate rows, no copy)
             flat = out.reshape(out.shape[0], s)

@@ -172,12 +172,15 @@ def SubbandDedisperse(ih, dm, *, band_frequency, band_reference_frequency=None,
                               samples_per_frame=samples_per_frame, **kwargs)
 
 
-def gather_subbands(local, torch, dist, comm=None):
-    """Concatenate equally shaped per-rank results ``(n, k, ...)`` along the
-    sub-band axis, in rank order: ``(n, world * k, ...)`` on every rank."""
+def gather_subbands(local, torch, dist, comm=None, axis=1):
+    """Concatenate equally shaped per-rank results along the sub-band axis, in
+    rank order: ``(n, k, ...)`` -> ``(n, world * k, ...)`` on every rank
+    (``axis`` = 1, a dedispersed stream), or along any later axis -- a
+    channelized stream ``(n, n_chan, k, ...)`` has its sub-bands on axis 2."""
     world = dist.get_world_size()
-    flat = gather_frames(local, torch, dist, comm)                 # (world * n, k, ...)
+    flat = gather_frames(local, torch, dist, comm)                 # (world * n, ...)
     n = local.shape[0]
-    stacked = flat.reshape((world, n) + tuple(local.shape[1:]))
-    order = (1, 0) + tuple(range(2, stacked.dim()))
-    return stacked.permute(*order).reshape((n, world * local.shape[1]) + tuple(local.shape[2:]))
+    stacked = flat.reshape((world, n) + tuple(local.shape[1:]))     # (world, n, a1, a2, ...)
+    order = tuple(range(1, axis + 1)) + (0,) + tuple(range(axis + 1, stacked.dim()))
+    shape = tuple(local.shape[:axis]) + (world * local.shape[axis],) + tuple(local.shape[axis + 1:])
+    return stacked.permute(*order).reshape(shape)

