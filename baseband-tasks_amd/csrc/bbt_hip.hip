@@ -121,18 +121,53 @@ static bool fft_len_ok(int64_t n) { return is_pow2(n) && n >= 256 && n <= 4096; 
 
 // ---- lengths 2^a 3^b 5^c 7^d (fft_generic.hpp) ------------------------------
 static bool factor_7smooth(int64_t n, GenGeo* g) {
+    // Stages of the LDS Stockham transform: radices from {2..10, 12, 14, 15, 16} (the composite
+    // ones are small Cooley-Tukey transforms on registers, fft_generic.hpp), as few as possible --
+    // every stage is a round trip of the whole tile through LDS with two barriers -- and among
+    // the shortest lists the one with the smallest largest radix (registers).
+    // BBT_GEN_SMALL_RADICES=1: primes and 4, 8 only (round 2's rule).
     if (n < 1 || n > BBT_GEN_MAX_LEN) return false;
+    static const bool small_only = [] { const char* e = getenv("BBT_GEN_SMALL_RADICES"); return e && atoi(e) == 1; }();
+    static const int all[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    static const int few[] = {8, 7, 5, 4, 3, 2};
+    static const int max_radix = [] { const char* e = getenv("BBT_GEN_MAX_RADIX"); return e ? atoi(e) : BBT_GEN_MAXR; }();
+    const int* radices = small_only ? few : all;
+    int nrad = small_only ? 6 : 13;
+    while (nrad > 1 && radices[0] > max_radix) {      // (lists are in descending order)
+        ++radices;
+        --nrad;
+    }
     g->n = (int)n;
     g->nfac = 0;
-    int64_t m = n;
-    auto take = [&](int r) {
-        while (m % r == 0 && g->nfac < BBT_GEN_MAX_FACTORS) {
-            g->fac[g->nfac++] = r;
-            m /= r;
+    if (n == 1) return true;
+    // dynamic programme over the divisors of n: best[d] = (stages, largest radix) to reach d
+    std::map<int64_t, std::pair<int, int>> best;
+    std::map<int64_t, int> step;
+    best[1] = {0, 0};
+    std::vector<int64_t> divisors;
+    for (int64_t d = 1; d <= n; ++d)
+        if (n % d == 0) divisors.push_back(d);
+    for (int64_t d : divisors) {
+        auto it = best.find(d);
+        if (it == best.end()) continue;
+        for (int i = 0; i < nrad; ++i) {
+            const int r = radices[i];
+            const int64_t e = d * r;
+            if (n % e) continue;
+            const std::pair<int, int> cand = {it->second.first + 1, std::max(it->second.second, r)};
+            auto jt = best.find(e);
+            if (jt == best.end() || cand < jt->second) {
+                best[e] = cand;
+                step[e] = r;
+            }
         }
-    };
-    take(8); take(4); take(2); take(3); take(5); take(7);
-    return m == 1;
+    }
+    if (!best.count(n) || best[n].first > BBT_GEN_MAX_FACTORS) return false;
+    std::vector<int> fac;
+    for (int64_t d = n; d > 1; d /= step[d]) fac.push_back(step[d]);
+    std::sort(fac.begin(), fac.end(), std::greater<int>());      // (large radices first: fewer twiddles)
+    for (int r : fac) g->fac[g->nfac++] = r;
+    return true;
 }
 static bool is_7smooth(int64_t n) {
     if (n < 1) return false;
@@ -140,18 +175,25 @@ static bool is_7smooth(int64_t n) {
         while (n % r == 0) n /= r;
     return n == 1;
 }
-// N = N1 * N2 with N1 <= N2 <= BBT_GEN_MAX_LEN, as balanced as possible
+// N = N1 * N2 with N1 <= N2 <= BBT_GEN_MAX_LEN: the largest N1 up to BBT_GEN_SPLIT_N1 (default
+// 512: the column passes then hold 16 columns of N1 points in their LDS tile, i.e. move 256-byte
+// runs), else as balanced as possible.
 static bool split_7smooth(int64_t n, int* n1, int* n2) {
-    int64_t best = 0;
+    static const int64_t prefer = [] { const char* e = getenv("BBT_GEN_SPLIT_N1"); return (int64_t)(e ? atoi(e) : 512); }();
+    int64_t best = 0, wide = 0;
     for (int64_t d = 1; d * d <= n; ++d)
-        if (n % d == 0 && n / d <= BBT_GEN_MAX_LEN) best = d;
+        if (n % d == 0 && n / d <= BBT_GEN_MAX_LEN) {
+            best = d;
+            if (d <= prefer) wide = d;
+        }
+    if (wide) best = wide;
     if (!best) return false;
     *n1 = (int)best;
     *n2 = (int)(n / best);
     return true;
 }
-static int gen_threads(int elements) {          // elements <= 8 * threads, whole waves
-    int t = ((elements + 7) / 8 + 63) / 64 * 64;
+static int gen_threads(int elements) {          // elements <= BBT_GEN_EPT * threads, whole waves
+    int t = ((elements + BBT_GEN_EPT - 1) / BBT_GEN_EPT + 63) / 64 * 64;
     return t < 64 ? 64 : (t > 1024 ? 1024 : t);
 }
 static std::map<std::pair<int, int>, cf*> g_gen_tables;    // (device, n) -> W_n^k, k < n
@@ -1279,7 +1321,12 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if (p->n1 > 1) {
             if (get_gen_table(p->n1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
                 return bail(1);
-            p->gen_ct = std::max(1, std::min(8, BBT_GEN_MAX_LEN / p->n1));
+            // columns per tile: a power of two (gen_stage), as many as fit the LDS tile up to 8
+            // (128-byte runs of the stream and of the work buffer; measured: 8 columns 18.9, 16
+            // columns 18.1, 4 columns 17.3 Gsamples/s for the 1 666 980-sample block)
+            static const int ct_cap = [] { const char* e = getenv("BBT_GEN_CT"); return e ? atoi(e) : 8; }();
+            p->gen_ct = 1;
+            while (p->gen_ct < ct_cap && 2 * p->gen_ct * p->n1 <= BBT_GEN_MAX_LEN) p->gen_ct *= 2;
         }
     } else {
         if (get_tables(p->n2, &p->tab2)) return bail(1);
@@ -1884,7 +1931,7 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
             delete p;
             return 1;
         }
-        for (int ct = 8; ct >= 1; --ct)
+        for (int ct = 8; ct >= 1; ct /= 2)           // (a power of two: gen_stage)
             if (p->npair % ct == 0 && (int64_t)n_chan * ct <= BBT_GEN_MAX_LEN) {
                 p->ct = ct;
                 break;

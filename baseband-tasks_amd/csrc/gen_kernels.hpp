@@ -18,6 +18,14 @@
 
 namespace bbt {
 
+// A thread's share of a tile of `total` <= BBT_GEN_EPT * nthr elements: idx = tid + e * nthr.
+// The loops below are written over e with a fixed trip count so that all of a thread's global
+// loads are in flight together (a loop over idx with a run-time bound issued them one by one,
+// each waiting for the one before: these kernels hold one to three workgroups per CU and have
+// nothing else to hide that latency with).
+#define BBT_GEN_FOR(e, idx, total) \
+    _Pragma("unroll") for (int e = 0, idx = tid; e < BBT_GEN_EPT; ++e, idx += nthr)
+
 __device__ __forceinline__ f4 ld_ext_f4(const float2* p) {
     const float4 x = *reinterpret_cast<const float4*>(p);
     return f4{x.x, x.z, x.y, x.w};
@@ -31,7 +39,7 @@ __device__ __forceinline__ f4 f4_mul_resp(f4 a, cf x, cf y) {     // stream A ti
 __device__ __forceinline__ f4 f4_twmul(f4 a, cf w) { return f4_mul_resp(a, w, w); }
 
 // One workgroup per (block, pair): n = g.n <= 8192 elements of dynamic LDS.
-__global__ __launch_bounds__(1024) void k_gen_osm_small(const float2* __restrict__ in,
+__global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_osm_small(const float2* __restrict__ in,
                                                         float2* __restrict__ out, OsmChunk ch, int S,
                                                         const cf* __restrict__ resp,
                                                         const int* __restrict__ resp_index, GenGeo g,
@@ -42,24 +50,35 @@ __global__ __launch_bounds__(1024) void k_gen_osm_small(const float2* __restrict
     const int sp = blockIdx.x % npair;
     const OsmBlock blk = ch.b[blockIdx.x / npair];
     const float2* src = in + (blk.in_off * S + 2 * sp);
-    for (int i = tid; i < n; i += nthr) gen_lds[i] = ld_ext_f4(src + (long long)i * S);
+    {
+        f4 x[BBT_GEN_EPT];
+        BBT_GEN_FOR(e, i, n) x[e] = i < n ? ld_ext_f4(src + (long long)i * S) : f4{0.f, 0.f, 0.f, 0.f};
+        BBT_GEN_FOR(e, i, n) if (i < n) gen_lds[i] = x[e];
+    }
     __syncthreads();
-    gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
     const cf* h0 = resp + (long long)resp_index[2 * sp] * n;
     const cf* h1 = resp + (long long)resp_index[2 * sp + 1] * n;
-    for (int i = tid; i < n; i += nthr) gen_lds[i] = f4_mul_resp(gen_lds[i], h0[i], h1[i]);
+    gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
+    {
+        cf ha[BBT_GEN_EPT], hb[BBT_GEN_EPT];
+        BBT_GEN_FOR(e, i, n) {
+            ha[e] = i < n ? h0[i] : make_float2(0.f, 0.f);
+            hb[e] = i < n ? h1[i] : make_float2(0.f, 0.f);
+        }
+        BBT_GEN_FOR(e, i, n) if (i < n) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], hb[e]);
+    }
     __syncthreads();
     gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
-    for (int i = tid; i < n; i += nthr) {
+    BBT_GEN_FOR(e, i, n) {
         const int r = i - blk.valid_start;
-        if (r >= 0 && r < blk.valid_count) st_ext_f4(out + ((blk.out_off + r) * S + 2 * sp), gen_lds[i]);
+        if (i < n && r >= 0 && r < blk.valid_count) st_ext_f4(out + ((blk.out_off + r) * S + 2 * sp), gen_lds[i]);
     }
 }
 
 // Column pass: tile of `ct` columns n2 of one (block, pair), all N1 = g.n rows.
 //   grid (tiles * npair, blocks); work element (k1, n2) at ((b*npair+sp)*N1 + k1)*N2 + n2.
 template <bool FIRST>
-__global__ __launch_bounds__(1024) void k_gen_col(const float2* __restrict__ in,
+__global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_col(const float2* __restrict__ in,
                                                   float2* __restrict__ out,
                                                   float2* __restrict__ work, OsmChunk ch, int S,
                                                   int N2, int ct, GenGeo g,
@@ -72,20 +91,28 @@ __global__ __launch_bounds__(1024) void k_gen_col(const float2* __restrict__ in,
     const OsmBlock blk = ch.b[b];
     f4* w = reinterpret_cast<f4*>(work) + ((long long)(b * npair + sp) * N1) * N2;
     const int total = N1 * ct;
-    for (int idx = tid; idx < total; idx += nthr) {
-        const int n1 = idx / ct, n2 = n2_0 + (idx - n1 * ct);
-        f4 x = f4{0.f, 0.f, 0.f, 0.f};
-        if (n2 < N2) {
-            if (FIRST) x = ld_ext_f4(in + ((blk.in_off + (long long)n1 * N2 + n2) * S + 2 * sp));
-            else x = w[(long long)n1 * N2 + n2];
+    const int lg = __ffs(ct) - 1;                  // (ct is a power of two that divides nthr)
+    const int n2 = n2_0 + (tid & (ct - 1)), row_step = nthr >> lg;
+    if (n2 < N2) {
+        // (four loads in flight per thread; with all eight the allocator spilled 700 dwords)
+        const long long step = (long long)row_step * N2;
+        if (FIRST) {
+            const float2* src = in + ((blk.in_off + (long long)(tid >> lg) * N2 + n2) * S + 2 * sp);
+#pragma unroll 4
+            for (int idx = tid; idx < total; idx += nthr, src += step * S) gen_lds[idx] = ld_ext_f4(src);
+        } else {
+            const f4* src = w + (long long)(tid >> lg) * N2 + n2;
+#pragma unroll 4
+            for (int idx = tid; idx < total; idx += nthr, src += step) gen_lds[idx] = *src;
         }
-        gen_lds[idx] = x;
+    } else {
+        for (int idx = tid; idx < total; idx += nthr) gen_lds[idx] = f4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     gen_fft<FIRST ? -1 : +1>(gen_lds, g, ct, wn, tid, nthr);
-    for (int idx = tid; idx < total; idx += nthr) {
-        const int n1 = idx / ct, n2 = n2_0 + (idx - n1 * ct);
-        if (n2 >= N2) continue;
+    if (n2 >= N2) return;
+    int n1 = tid >> lg;
+    for (int idx = tid; idx < total; idx += nthr, n1 += row_step) {
         if (FIRST) {
             w[(long long)n1 * N2 + n2] = gen_lds[idx];
         } else {
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_gen_col(const float2* __restrict__ in,
 // Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair).
 //   resp  : [C][N1][N2] = H[c][k1 + N1 k2] / N
 //   wn    : W_{N2}^k ;  tlo / thi : W_N^m tables (big_twiddle)
-__global__ __launch_bounds__(1024) void k_gen_row(float2* __restrict__ work, int N1,
+__global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restrict__ work, int N1,
                                                   const cf* __restrict__ resp,
                                                   const int* __restrict__ resp_index, int npair,
                                                   GenGeo g, const cf* __restrict__ wn,
@@ -109,17 +136,31 @@ __global__ __launch_bounds__(1024) void k_gen_row(float2* __restrict__ work, int
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int k1 = blockIdx.x, sp = blockIdx.y % npair;
     f4* row = reinterpret_cast<f4*>(work) + ((long long)blockIdx.y * N1 + k1) * N2;
-    for (int i = tid; i < N2; i += nthr) gen_lds[i] = f4_twmul(row[i], big_twiddle(tlo, thi, k1 * i));
+    {
+        f4 x[BBT_GEN_EPT];
+        cf tw[BBT_GEN_EPT];                              // the four-step twiddles W_N^{k1 n2}
+        BBT_GEN_FOR(e, i, N2) x[e] = i < N2 ? row[i] : f4{0.f, 0.f, 0.f, 0.f};
+        BBT_GEN_FOR(e, i, N2) tw[e] = i < N2 ? big_twiddle(tlo, thi, k1 * i) : make_float2(1.f, 0.f);
+        BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_twmul(x[e], tw[e]);
+    }
     __syncthreads();
     gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
-    const cf* h0 = resp + ((long long)resp_index[2 * sp] * N1 + k1) * N2;
-    const cf* h1 = resp + ((long long)resp_index[2 * sp + 1] * N1 + k1) * N2;
-    for (int i = tid; i < N2; i += nthr) gen_lds[i] = f4_mul_resp(gen_lds[i], h0[i], h1[i]);
+    {
+        const cf* h0 = resp + ((long long)resp_index[2 * sp] * N1 + k1) * N2;
+        const cf* h1 = resp + ((long long)resp_index[2 * sp + 1] * N1 + k1) * N2;
+        cf ha[BBT_GEN_EPT], hb[BBT_GEN_EPT];
+        BBT_GEN_FOR(e, i, N2) {
+            ha[e] = i < N2 ? h0[i] : make_float2(0.f, 0.f);
+            hb[e] = i < N2 ? h1[i] : make_float2(0.f, 0.f);
+        }
+        BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], hb[e]);
+    }
     __syncthreads();
     gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
-    for (int i = tid; i < N2; i += nthr) {
-        const cf w = big_twiddle(tlo, thi, k1 * i);
-        row[i] = f4_twmul(gen_lds[i], make_float2(w.x, -w.y));
+    {
+        cf tw[BBT_GEN_EPT];
+        BBT_GEN_FOR(e, i, N2) tw[e] = i < N2 ? big_twiddle(tlo, thi, k1 * i) : make_float2(1.f, 0.f);
+        BBT_GEN_FOR(e, i, N2) if (i < N2) row[i] = f4_twmul(gen_lds[i], make_float2(tw[e].x, -tw[e].y));
     }
 }
 
@@ -127,7 +168,7 @@ __global__ __launch_bounds__(1024) void k_gen_row(float2* __restrict__ work, int
 // tile of `ct` stream pairs (ct * 16 contiguous bytes per complete sample).
 //   grid (n_fft * (npair / ct))
 template <int SIGN>
-__global__ __launch_bounds__(1024) void k_gen_fft_rows(const float2* __restrict__ in,
+__global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_fft_rows(const float2* __restrict__ in,
                                                        float2* __restrict__ out, int S, int ct,
                                                        float scale, GenGeo g,
                                                        const cf* __restrict__ wn) {
@@ -138,17 +179,19 @@ __global__ __launch_bounds__(1024) void k_gen_fft_rows(const float2* __restrict_
     const int sp0 = (blockIdx.x % npg) * ct;
     const int total = n * ct;
     const float2* src = in + (i * n * S + 2 * sp0);
-    for (int idx = tid; idx < total; idx += nthr) {
-        const int e = idx / ct, c = idx - e * ct;
-        gen_lds[idx] = ld_ext_f4(src + ((long long)e * S + 2 * c));
+    const int lg = __ffs(ct) - 1;                  // (ct is a power of two that divides nthr)
+    const int c = tid & (ct - 1), row0 = tid >> lg, row_step = nthr >> lg;
+    {
+        f4 x[BBT_GEN_EPT];
+        BBT_GEN_FOR(e, idx, total)
+            x[e] = idx < total ? ld_ext_f4(src + ((long long)(row0 + e * row_step) * S + 2 * c)) : f4{0.f, 0.f, 0.f, 0.f};
+        BBT_GEN_FOR(e, idx, total) if (idx < total) gen_lds[idx] = x[e];
     }
     __syncthreads();
     gen_fft<SIGN>(gen_lds, g, ct, wn, tid, nthr);
     float2* dst = out + (i * n * S + 2 * sp0);
-    for (int idx = tid; idx < total; idx += nthr) {
-        const int e = idx / ct, c = idx - e * ct;
-        st_ext_f4(dst + ((long long)e * S + 2 * c), gen_lds[idx] * scale);
-    }
+    BBT_GEN_FOR(e, idx, total)
+        if (idx < total) st_ext_f4(dst + ((long long)(row0 + e * row_step) * S + 2 * c), gen_lds[idx] * scale);
 }
 
 // Splice the spectrum that straddles a block seam (see k_seam_fix) for any
@@ -156,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_gen_fft_rows(const float2* __restrict_
 // side by side (tile of two), samples [0, split) are taken from the earlier
 // block, the rest from the later one, and the result is transformed again.
 // One workgroup per (seam, pair); 2 n elements of dynamic LDS.
-__global__ __launch_bounds__(1024) void k_seam_fix_gen(const float2* __restrict__ seam,
+__global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_seam_fix_gen(const float2* __restrict__ seam,
                                                        float2* __restrict__ out, SeamJobs jobs, int S,
                                                        int npair, GenGeo g,
                                                        const cf* __restrict__ wn, SpecOut so) {

@@ -87,6 +87,8 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='keep the HIP-event kernel timing out of the timed region (A/B check)')
     ap.add_argument('--no-gather', action='store_true', help='skip the timed all-gather (N > 1)')
+    ap.add_argument('--no-host-path', action='store_true',
+                    help='skip the host-to-host (.read()) measurement of the metric pipeline')
     return ap.parse_args()
 
 
@@ -175,6 +177,67 @@ def usable_cores():
     if quota:
         n = max(1, min(n, int(quota + 0.5)))
     return n, total, quota
+
+
+def host_path(bt, torch, blocks=96, reps=3):
+    """The metric pipeline host to host: samples in (page-locked) host memory -> ``read()`` ->
+    NumPy array, i.e. the reference's own calling convention (base.py:389-438), PCIe both ways.
+    Upload of run m + 1, transforms of run m and download of run m - 1 overlap
+    (baseband-tasks_amd/host_pipeline.py).  Never part of `value`."""
+    from baseband_tasks_amd import host_pipeline as hp
+    spf = N_FFT - PAD_START - PAD_END
+    n_in = (blocks - 1) * spf + N_FFT
+    x = hp.pinned_empty((n_in, 2), np.complex64)
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((N_FFT, 4), dtype=np.float32).view(np.complex64)
+    for s in range(0, n_in, N_FFT):
+        x[s:s + N_FFT] = base[:min(N_FFT, n_in - s)]
+    nh = bt.HostStream(x, '2020-01-01T00:00:00', FS_HZ, samples_per_frame=N_FFT, frequency=FC_HZ,
+                       sideband=1, polarization=['X', 'Y'])
+    dd = bt.Dedisperse(nh, DM)
+    ch = bt.Channelize(dd, N_CHAN, samples_per_frame=512)
+    run = 16
+    dd.max_frames_per_call = run + 2
+    ch.max_frames_per_call = run * spf // (512 * N_CHAN) + 1
+    ch.read(ch.samples_per_frame)                    # plan, first touch of the pinned pools
+    best, z = None, None
+    for _ in range(reps):
+        ch.invalidate_cache()
+        dd.invalidate_cache()
+        ch.seek(0)
+        z = None
+        t0 = time.perf_counter()
+        z = ch.read()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    n_valid = z.shape[0] * N_CHAN
+    # the bus by itself, both directions at once (what bounds this path)
+    m = 256 << 20
+    a, b = hp.pinned_empty((m,), np.uint8), hp.pinned_empty((m,), np.uint8)
+    da, db = bt.hip.DeviceArray((m,), np.uint8), bt.hip.DeviceArray((m,), np.uint8)
+    s1, s2 = hp.Stream(), hp.Stream()
+    lib = bt.hip.lib()
+
+    def both():
+        bt.hip.check(lib.bbt_memcpy_h2d(da.ptr, a.ctypes.data, m, s1.handle))
+        bt.hip.check(lib.bbt_memcpy_d2h(b.ctypes.data, db.ptr, m, s2.handle))
+    both()
+    s1.synchronize(), s2.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        both()
+    s1.synchronize(), s2.synchronize()
+    duplex = 4 * m / (time.perf_counter() - t0) / 1e9
+    res = dict(value=round(n_valid / best / 1e6, 1), unit='Msamples/s', blocks=blocks, blocks_per_run=run,
+               seconds=round(best, 4), h2d_gbps=round(x.nbytes / best / 1e9, 2),
+               d2h_gbps=round(z.nbytes / best / 1e9, 2), pcie_duplex_gbps_each_way=round(duplex, 1),
+               what='Channelize(Dedisperse(HostStream over page-locked memory)).read() -> NumPy array: '
+                    'PCIe both ways, three streams (upload / transforms / download of consecutive runs '
+                    'overlap); bounded by the bus with both directions busy (pcie_duplex_gbps_each_way, '
+                    'measured here with two 256 MiB copies at once)')
+    ch.close()
+    dd.close()
+    return res
 
 
 def cpu_baseline(target_seconds):
@@ -600,6 +663,12 @@ def run_rank(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.workload == 'headline':
         cpu = cpu_baseline(args.cpu_seconds)
+    host = None
+    if rank == 0 and world == 1 and not args.no_host_path and args.workload == 'headline':
+        try:
+            host = host_path(bt, torch)
+        except Exception as exc:            # (reported, never fails the resident number)
+            host = dict(error=f'{type(exc).__name__}: {exc}'[:300])
 
     failed = bool(verified and not verified['all_ranks_ok'])
     if rank == 0:
@@ -618,7 +687,7 @@ def run_rank(args):
                         outputs='left sharded on the ranks (value); with_gather includes the all-gather',
                         sharding=sharding_note),
             roofline=roofline, roofline_path=roofline_path, cpu_baseline=cpu, verified=verified,
-            with_gather=with_gather)
+            with_gather=with_gather, host_path=host)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
