@@ -197,7 +197,7 @@ static int gen_threads(int elements) {          // elements <= BBT_GEN_EPT * thr
     return t < 64 ? 64 : (t > 1024 ? 1024 : t);
 }
 static std::map<std::pair<int, int>, cf*> g_gen_tables;    // (device, n) -> W_n^k, k < n
-static int get_gen_table(int n, cf** out);
+static int get_gen_table(GenGeo* g, cf** out);
 static int make_big_twiddle(int64_t n, cf** lo, cf** hi);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a
@@ -215,17 +215,37 @@ static int ensure_dyn_lds(const void* func, size_t bytes) {
     return 0;
 }
 
-static int get_gen_table(int n, cf** out) {
+// Stage twiddles of the LDS Stockham transform of g->n points, stage after stage: stage s (radix
+// R, Ns = product of the earlier radices) has its W_{Ns R}^{r k} at [g->woff[s] + (r - 1) Ns + k],
+// r = 1 .. R - 1, k < Ns -- contiguous in k, which is what neighbouring lanes differ in, so a
+// stage's twiddle loads are coalesced (gathered from one W_n^k table they touched up to 64 cache
+// lines per wave instruction).  The first stage (Ns = 1) has none.  Fills g->woff.
+static int get_gen_table(GenGeo* g, cf** out) {
     int dev;
     HIP_TRY(hipGetDevice(&dev));
+    const int n = g->n;
+    int ns = 1, total = 0;
+    for (int s = 0; s < g->nfac; ++s) {
+        g->woff[s] = total;
+        if (s > 0) total += (g->fac[s] - 1) * ns;
+        ns *= g->fac[s];
+    }
     std::lock_guard<std::mutex> lock(g_tab_mutex);
     auto it = g_gen_tables.find({dev, n});
     if (it != g_gen_tables.end()) {
         *out = it->second;
         return 0;
     }
-    std::vector<cf> h(n);
-    for (int k = 0; k < n; ++k) h[k] = unit_root(k, n);
+    std::vector<cf> h((size_t)std::max(total, 1));
+    ns = 1;
+    for (int s = 0; s < g->nfac; ++s) {
+        const int r_s = g->fac[s];
+        if (s > 0)
+            for (int r = 1; r < r_s; ++r)
+                for (int k = 0; k < ns; ++k)
+                    h[(size_t)g->woff[s] + (size_t)(r - 1) * ns + k] = unit_root((long long)r * k, (long long)ns * r_s);
+        ns *= r_s;
+    }
     cf* d;
     if (upload(&d, h)) return 1;
     g_gen_tables[{dev, n}] = d;
@@ -1317,9 +1337,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (p->generic) {
         if (!factor_7smooth(p->n2, &p->g2) || (p->n1 > 1 && !factor_7smooth(p->n1, &p->g1)))
             return bail(fail("bbt_osm_plan_create: cannot factor %d x %d", p->n1, p->n2));
-        if (get_gen_table(p->n2, &p->wn2)) return bail(1);
+        if (get_gen_table(&p->g2, &p->wn2)) return bail(1);
         if (p->n1 > 1) {
-            if (get_gen_table(p->n1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
+            if (get_gen_table(&p->g1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
                 return bail(1);
             // columns per tile: a power of two (gen_stage), as many as fit the LDS tile up to 8
             // (128-byte runs of the stream and of the work buffer; measured: 8 columns 18.9, 16
@@ -1627,7 +1647,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
     FftTables tabc;
     GenGeo gsmall = {};
     cf* wsmall = nullptr;
-    if (small ? (!factor_7smooth(n_chan, &gsmall) || get_gen_table(n_chan, &wsmall))
+    if (small ? (!factor_7smooth(n_chan, &gsmall) || get_gen_table(&gsmall, &wsmall))
               : get_tables(n_chan, &tabc))
         return 1;
     // seam slots and jobs
@@ -1926,7 +1946,7 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     p->split_real = split_real;
     if (!fast) {
         p->generic = true;
-        if (!factor_7smooth(n_chan, &p->g) || get_gen_table(n_chan, &p->wn)) {
+        if (!factor_7smooth(n_chan, &p->g) || get_gen_table(&p->g, &p->wn)) {
             if (g_err.empty()) fail("bbt_chan_plan_create: cannot factor n_chan=%d", n_chan);
             delete p;
             return 1;
@@ -1997,6 +2017,7 @@ struct bbt_pfb_plan {
     int n = 0, S = 0, npair = 0, n_tap = 0;
     bool split_real = false;    // n_stream -1: one stream z = a + i b of two real streams, half spectra out
     float* taps = nullptr;
+    float* taps_quads = nullptr;   // window kernels: [column group][tap quad][thread] float4
     FftTables tab;
     FftTables tab4096;   // for the sliding-window kernel
     bool window = false;
@@ -2010,19 +2031,19 @@ static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* o
         const unsigned gx = (unsigned)((n_spec + 2 * NG - 1) / (2 * NG));
         if (p->split_real)
             hipLaunchKernelGGL((k_pfb_window<N, NTAP, true, true>), dim3(gx), dim3(256), 0, st, in, out,
-                               (long long)n_spec, 1, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+                               (long long)n_spec, 1, p->taps_quads, p->tab4096.tw0, p->tab4096.tw1);
         else
             hipLaunchKernelGGL((k_pfb_window<N, NTAP, true>), dim3(gx), dim3(256), 0, st, in, out,
-                               (long long)n_spec, 1, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+                               (long long)n_spec, 1, p->taps_quads, p->tab4096.tw0, p->tab4096.tw1);
         return;
     }
     const unsigned gx = (unsigned)((n_spec + NG - 1) / NG);
     if (p->split_real)          // every stream z = a + i b of two real streams: half spectra out
         hipLaunchKernelGGL((k_pfb_window<N, NTAP, false, true>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
-                           (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+                           (long long)n_spec, p->S, p->taps_quads, p->tab4096.tw0, p->tab4096.tw1);
     else
         hipLaunchKernelGGL((k_pfb_window<N, NTAP>), dim3(gx * p->npair), dim3(256), 0, st, in, out,
-                           (long long)n_spec, p->S, p->taps, p->tab4096.tw0, p->tab4096.tw1);
+                           (long long)n_spec, p->S, p->taps_quads, p->tab4096.tw0, p->tab4096.tw1);
 }
 
 // sliding-window variants exist for these (n_chan, n_tap)
@@ -2087,12 +2108,30 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
         bbt_pfb_plan_destroy(p);
         return 1;
     }
+    if (p->window) {
+        // taps of column tau + 256 c, four at a time: quads[((c * n_tap / 4) + q) * 256 + tau][k] = h[4 q + k]
+        const int cols = n_chan / 256, quads = n_tap / 4;
+        std::vector<float> perm((size_t)n_tap * n_chan);
+        for (int c = 0; c < cols; ++c)
+            for (int q = 0; q < quads; ++q)
+                for (int tau = 0; tau < 256; ++tau)
+                    for (int k = 0; k < 4; ++k)
+                        perm[(((size_t)c * quads + q) * 256 + tau) * 4 + k] =
+                            taps_host[(size_t)(4 * q + k) * n_chan + tau + 256 * c];
+        if (hipMalloc((void**)&p->taps_quads, tb) != hipSuccess ||
+            hipMemcpy(p->taps_quads, perm.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
+            fail("bbt_pfb_plan_create: tap upload failed");
+            bbt_pfb_plan_destroy(p);
+            return 1;
+        }
+    }
     *plan = p;
     return 0;
 }
 
 int bbt_pfb_plan_destroy(bbt_pfb_plan* p) {
     if (!p) return 0;
+    if (p->taps_quads) hipFree(p->taps_quads);
     if (p->taps) hipFree(p->taps);
     delete p;
     return 0;

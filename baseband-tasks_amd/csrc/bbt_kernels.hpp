@@ -1449,11 +1449,23 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
     // column are issued together (the kernel is bound by load latency at 2
     // waves/SIMD: this keeps 15 loads per thread in flight instead of ~4), then
     // each row feeds the accumulators of the spectra it belongs to.
+    // taps: the window variants read them as float4 over four consecutive taps of a column,
+    // permuted by the host to [column group c][tap quad][thread] (bbt_pfb_plan_create): NTAP / 4
+    // fully coalesced 16-byte loads per column instead of NTAP 4-byte ones -- the kernel is short
+    // of vector-memory issue slots, not of bytes.
+    static_assert(NTAP % 4 == 0, "window kernels: taps in quads");
+    const float4* taps4 = reinterpret_cast<const float4*>(taps);
 #pragma unroll
     for (int c = 0; c < P; ++c) {
         float h[NTAP];
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) h[t] = taps[t * N + tau + T * c];
+        for (int q = 0; q < NTAP / 4; ++q) {
+            const float4 hq = taps4[(c * (NTAP / 4) + q) * T + tau];
+            h[4 * q] = hq.x;
+            h[4 * q + 1] = hq.y;
+            h[4 * q + 2] = hq.z;
+            h[4 * q + 3] = hq.w;
+        }
         // rows past the end of the stream (last workgroup only): read the last
         // existing row instead and zero it, so the loads stay branch free
         constexpr int NR = NTAP + NG - 1;
@@ -1479,20 +1491,17 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
             for (int i = 0; i < RB; ++i) {
                 const int r = r0 + i;
                 if (r < NR) {
+                    // rows past the end of the stream count as zeros (once per row, not per tap)
                     const float keep = r < rows_left ? 1.f : 0.f;
                     const float keep_b = (!SINGLE || r + NG < rows_left) ? 1.f : 0.f;
+                    const v2 kk = SINGLE ? v2{keep, keep_b} : v2{keep, keep};
+                    const c2 xr = c2{x[i].re * kk, x[i].im * kk};
 #pragma unroll
                     for (int q = 0; q < NG; ++q) {
                         const int t = r - q;                  // tap index for spectrum i0 + q
                         if (t >= 0 && t < NTAP) {
-                            if constexpr (SINGLE) {
-                                const v2 hk = v2{h[t] * keep, h[t] * keep_b};
-                                v[q * P + c].re += x[i].re * hk;
-                                v[q * P + c].im += x[i].im * hk;
-                            } else {
-                                v[q * P + c].re += x[i].re * (h[t] * keep);
-                                v[q * P + c].im += x[i].im * (h[t] * keep);
-                            }
+                            v[q * P + c].re += xr.re * h[t];
+                            v[q * P + c].im += xr.im * h[t];
                         }
                     }
                 }

@@ -220,27 +220,35 @@ __device__ __forceinline__ void fft_butterfly_twiddle(c2 (&v)[16], const cf (&w)
 }
 
 // exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
+// (timing-only experiment, BBT_DBG & 32: the exchanges of the transform without their
+// workgroup barriers -- wrong results, an upper bound on what the barriers cost)
+#if defined(BBT_DBG) && (BBT_DBG & 32)
+#define BBT_FFT_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define BBT_FFT_SYNC() __syncthreads()
+#endif
+
 template <int N, int COLMODE, int IMOFF>
 __device__ __forceinline__ void fft_exchange0(c2 (&v)[16], v2* __restrict__ lds, int tau, int f) {
     typedef FftGeo<N> G;
     constexpr int R2 = G::R2;
     const int c0s = tau / R2, b1 = tau % R2;
     v2* __restrict__ lds_im = lds + IMOFF;
-    __syncthreads();
+    BBT_FFT_SYNC();
 #pragma unroll
     for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].re;
     if (IMOFF) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds_im[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
     }
-    __syncthreads();
+    BBT_FFT_SYNC();
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a].re = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
     if (!IMOFF) {
-        __syncthreads();
+        BBT_FFT_SYNC();
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
-        __syncthreads();
+        BBT_FFT_SYNC();
     }
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a].im = lds_im[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
@@ -258,7 +266,7 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
         const int c0r = tau & 15, g = tau >> 4;
         v2* __restrict__ lds_im = lds + IMOFF;
         c2 t[NU][R2];
-        __syncthreads();
+        BBT_FFT_SYNC();
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].re;
         if (IMOFF) {
@@ -266,18 +274,18 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
             for (int c = 0; c < 16; ++c)
                 lds_im[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
         }
-        __syncthreads();
+        BBT_FFT_SYNC();
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int bb = 0; bb < R2; ++bb)
                 t[u][bb].re = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
         if (!IMOFF) {
-            __syncthreads();
+            BBT_FFT_SYNC();
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
-            __syncthreads();
+            BBT_FFT_SYNC();
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
@@ -343,9 +351,22 @@ __device__ __forceinline__ c2 ld_ext_nt(const float2* p) {
     const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
     return c2{v2{x.x, x.z}, v2{x.y, x.w}};
 }
+// (BBT_OUT_ST, experiment switch for the whole-line output stream: 0 non-temporal (default),
+// 1 plain, 2 write-through sc1, 3 sc1 nt)
+#ifndef BBT_OUT_ST
+#define BBT_OUT_ST 0
+#endif
 __device__ __forceinline__ void st_ext_nt(float2* p, c2 a) {
     const f4v x = {a.re.x, a.im.x, a.re.y, a.im.y};
+#if BBT_OUT_ST == 1
+    *reinterpret_cast<f4v*>(p) = x;
+#elif BBT_OUT_ST == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+#elif BBT_OUT_ST == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+#else
     __builtin_nontemporal_store(x, reinterpret_cast<f4v*>(p));
+#endif
 }
 __device__ __forceinline__ void st_ext(float2* p, c2 a, bool nt) {
     if (nt) st_ext_nt(p, a); else st_ext(p, a);

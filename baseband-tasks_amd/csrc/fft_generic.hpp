@@ -28,8 +28,8 @@
 // dword instead of 3-6 --: Channelize(1000) 114 against 61, default-geometry Dedisperse at
 // 800 MHz 18.9 against 15.2 Gsamples/s).
 //
-// Twiddles come from a table wn[k] = exp(-2 pi i k / n), k < n, evaluated in
-// double on the host.  Butterflies for 2, 4, 8 are those of fft_core.hpp; 3, 5
+// Twiddles come from per-stage tables W_{Ns R}^{r k} at [(r - 1) Ns + k] (contiguous in k,
+// so neighbouring lanes read neighbouring entries), evaluated in double on the host.  Butterflies for 2, 4, 8 are those of fft_core.hpp; 3, 5
 // and 7 use the symmetric form (pairs v[k] +- v[p-k], real coefficient sums).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -44,12 +44,13 @@ namespace bbt {
 #endif
 #define BBT_GEN_MAX_THREADS (BBT_GEN_MAX_LEN / BBT_GEN_EPT)
 #ifndef BBT_GEN_MAXR
-#define BBT_GEN_MAXR 16               // largest radix of a stage
+#define BBT_GEN_MAXR 12               // largest radix of a stage (14 .. 16: spilled registers; measured 5 % slower)
 #endif
 struct GenGeo {
     int n;                            // transform length
     int nfac;                         // number of stages
     int fac[BBT_GEN_MAX_FACTORS];     // radices in {2..10, 12, 14, 15, 16}, product n
+    int woff[BBT_GEN_MAX_FACTORS];    // where stage s finds its twiddles in the table (host: get_gen_table)
 };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -199,7 +200,6 @@ __device__ __forceinline__ void gen_stage(f4* __restrict__ lds, int n, int ns, i
                                           const cf* __restrict__ wn, int tid, int nthr) {
     constexpr int MAXB = (BBT_GEN_EPT + R - 1) / R;
     const int m = n / R;               // butterflies per transform
-    const int wstep = n / (ns * R);    // W_{ns R}^x = wn[x * wstep]
     const int lg = __ffs(ct) - 1;
     const int col = tid & (ct - 1), j_first = tid >> lg, j_step = nthr >> lg;
     const int k_step = j_step % ns;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void gen_stage(f4* __restrict__ lds, int n, int ns, i
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 c2 t = f4_to_c2(src[r * mstride]);
-                if (r > 0) t = twmul<SIGN>(t, wn[(r * k) * wstep]);
+                if (r > 0 && ns > 1) t = twmul<SIGN>(t, wn[(r - 1) * ns + k]);
                 v[b][r] = t;
             }
             gen_butterfly<SIGN, R>(v[b]);
@@ -248,8 +248,10 @@ template <int SIGN>
 __device__ __forceinline__ void gen_fft(f4* __restrict__ lds, const GenGeo& g, int ct,
                                         const cf* __restrict__ wn, int tid, int nthr) {
     int ns = 1;
+    const cf* wall = wn;
     for (int s = 0; s < g.nfac; ++s) {
         const int r = g.fac[s];
+        wn = wall + g.woff[s];
         switch (r) {
             case 2: gen_stage<SIGN, 2>(lds, g.n, ns, ct, wn, tid, nthr); break;
             case 3: gen_stage<SIGN, 3>(lds, g.n, ns, ct, wn, tid, nthr); break;
