@@ -23,5 +23,6 @@ from .functions import Square, Power
 from .integration import Integrate
 from .ingest import RawFrameStream, open_vdif, open_dada
 from . import hip
+from . import hdf5
 
 __version__ = '0.1.0'

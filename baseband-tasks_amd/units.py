@@ -108,6 +108,19 @@ class Time:
     def unix(self):
         return self.sec + self.frac
 
+    def jd1_jd2(self):
+        """Julian date as two doubles whose sum is exact to the float: whole days (as
+        ``x.5``) and the fraction of the day -- the pair astropy's `Time` stores."""
+        days, rest = divmod(self.sec, 86400)
+        return 2440587.5 + days, (rest + self.frac) / 86400.
+
+    @classmethod
+    def from_jd(cls, jd1, jd2=0.0):
+        days = math.floor(jd1 - 2440587.5)
+        seconds = ((jd1 - 2440587.5) - days + jd2) * 86400.
+        whole = math.floor(seconds + 0.5e-9)
+        return cls(days * 86400 + int(whole), max(seconds - whole, 0.0))
+
     def __add__(self, seconds):
         seconds = to_seconds(seconds)
         whole = math.floor(seconds)

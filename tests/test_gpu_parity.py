@@ -180,6 +180,33 @@ def test_host_path_pipelined_reads_are_bit_identical(monkeypatch):
     assert hp.pinned_empty((1 << 20,), np.float32).ctypes.data == address
 
 
+def test_pipeline_output_into_the_hdf5_sink(tmp_path):
+    """SURVEY 8f rank 3, downstream side: a task's output goes into the reference's intermediate HDF5
+    format the way the reference writes it -- ``task.read(out=writer)``, the writer taking slices in order
+    (io/hdf5/base.py:102-126) -- for spectra and for detected, integrated power; read back, the samples
+    and the header are the task's."""
+    from baseband_tasks_amd import hdf5
+    n_fft, pad = 2**14, 767 + 771
+    nh = noise(9 * (n_fft - pad) + pad, (2,), 5000, seed=41, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
+    ch = bt.Channelize(bt.Dedisperse(nh, 5., samples_per_frame=n_fft - pad), 256, samples_per_frame=4)
+    pw = bt.Integrate(bt.Power(bt.SetAttribute(ch, polarization=np.array(['X', 'Y']))), 8)
+    for task in (ch, pw):
+        task.seek(0)
+        want = task.read()
+        name = str(tmp_path / f'{type(task).__name__}.h5')
+        task.seek(0)
+        with hdf5.open(name, 'w', template=task) as fw:
+            task.read(out=fw)
+            assert fw.tell() == task.shape[0]
+        fr = hdf5.open(name)
+        assert fr.shape == task.shape and fr.dtype == task.dtype
+        assert abs(fr.sample_rate - task.sample_rate) < 1e-9 * task.sample_rate
+        assert abs(fr.start_time - task.start_time) < 1e-9
+        assert np.array_equal(fr.read(), want)
+        assert np.allclose(np.ravel(fr.frequency), np.ravel(np.broadcast_to(task.frequency, fr.frequency.shape)))
+        fr.close()
+
+
 def test_fused_and_unfused_channelizer_agree(golden, monkeypatch):
     """Channelize on top of a GPU overlap-save task folds its FFT into that
     task's row pass; both routes must match the oracle (and each other to

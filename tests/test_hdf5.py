@@ -1,0 +1,105 @@
+"""The HDF5 sink (baseband_tasks_amd/hdf5.py; reference io/hdf5/base.py:102-126, header.py, payload.py).
+CPU tests: the writer against this package's own reader, the checksum against bytes libhdf5 wrote, and --
+where the build container's second interpreter is present -- the written file read back with the REAL
+h5py and astropy YAML loader (tests/golden/check_hdf5.py)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import baseband_tasks_amd as bt
+from baseband_tasks_amd import hdf5
+
+CONDA = '/opt/conda/bin/python3.9'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_lookup3_matches_libhdf5():
+    # the first 44 bytes of a file h5py wrote with libver='latest' (version-3 superblock) and the checksum
+    # libhdf5 stored behind them; and the empty / short inputs of Jenkins' own self-test
+    sb = bytes.fromhex('894844460d0a1a0a03080800' + '00' * 8 + 'ff' * 8 + '3d08000000000000' + '3000000000000000')
+    assert len(sb) == 44 and hdf5.lookup3(sb) == 0x422ce116
+    assert hdf5.lookup3(b'') == 0xdeadbeef
+    assert hdf5.lookup3(b'Four score and seven years ago') == 0x17770551
+    assert hdf5.lookup3(b'Four score and seven years ago', 1) == 0xcd628161
+
+
+def _example(tmp_path, dtype=np.complex64, shape=(1000, 2)):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape + (2,)).astype(np.float32)
+    x = x.view(np.complex64)[..., 0] if np.dtype(dtype).kind == 'c' else x[..., 0]
+    name = str(tmp_path / 'stream.h5')
+    kw = dict(shape=x.shape, start_time='2020-01-01T00:00:00.5', sample_rate=16e6, dtype=x.dtype)
+    if len(shape) > 1:
+        kw.update(frequency=np.array([1000e6, 1001e6]), sideband=np.array([1, -1]), polarization=np.array(['X', 'Y']))
+    return name, x, kw
+
+
+@pytest.mark.parametrize('dtype', [np.complex64, np.float32])
+def test_writer_and_reader_round_trip(tmp_path, dtype):
+    name, x, kw = _example(tmp_path, dtype)
+    with hdf5.open(name, 'w', **kw) as fw:
+        assert fw.shape == x.shape and fw.sample_shape == (2,)
+        fw.write(x[:300])
+        fw[300:650] = x[300:650]                   # the assignment form Integrate and friends use
+        with pytest.raises(AssertionError):
+            fw[700:800] = x[700:800]               # only right behind the pointer
+        fw.write(x[650:])
+        with pytest.raises(EOFError):
+            fw.write(x[:1])
+    fr = hdf5.open(name)
+    assert fr.shape == x.shape and fr.dtype == x.dtype and fr.sample_rate == 16e6
+    assert fr.start_time == bt.Time('2020-01-01T00:00:00.5')
+    assert np.array_equal(np.ravel(fr.frequency), [1000e6, 1001e6]) and list(np.ravel(fr.sideband)) == [1, -1]
+    assert [str(p) for p in np.ravel(fr.polarization)] == ['X', 'Y']
+    assert np.array_equal(fr.read(), x)
+    fr.seek(123)
+    assert np.array_equal(fr.read(77), x[123:200])
+    fr.close()
+
+
+def test_template_supplies_the_header(tmp_path):
+    nh = bt.NoiseGenerator((5000, 2), '2021-03-04T05:06:07', 1e6, 1000, seed=5, frequency=300e6, sideband=1,
+                           polarization=['L', 'R'])
+    name = str(tmp_path / 'noise.h5')
+    with hdf5.open(name, 'w', template=nh) as fw:
+        nh.read(out=fw)                               # read(out=...) fills anything with shape and slice assignment
+    fr = hdf5.open(name)
+    nh.seek(0)
+    assert np.array_equal(fr.read(), nh.read()) and fr.start_time == nh.start_time
+    assert float(np.ravel(fr.frequency)[0]) == 300e6
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason='needs the build container\'s h5py + astropy interpreter')
+@pytest.mark.parametrize('dtype', [np.complex64, np.float32])
+def test_file_reads_back_with_h5py_and_astropy(tmp_path, dtype):
+    name, x, kw = _example(tmp_path, dtype)
+    with hdf5.open(name, 'w', **kw) as fw:
+        fw.write(x)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    env.pop('PYTHONPATH', None)
+    r = subprocess.run([CONDA, '-W', 'ignore', os.path.join(HERE, 'golden', 'check_hdf5.py'), name],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = json.loads(r.stdout.strip().splitlines()[-1])
+    assert seen['keys'] == ['dtype', 'frequency', 'polarization', 'sample_rate', 'sample_shape',
+                            'samples_per_frame', 'sideband', 'time']
+    assert seen['dtype'] == x.dtype.str and seen['payload_dtype'] == x.dtype.name
+    assert seen['sample_shape'] == [2] and seen['samples_per_frame'] == 1000 and seen['payload_shape'] == [1000, 2]
+    assert seen['sample_rate_hz'] == 16e6 and seen['time_isot'] == '2020-01-01T00:00:00.500000000'
+    assert seen['time_scale'] == 'utc'
+    assert seen['frequency_hz'] == [1000e6, 1001e6] and seen['sideband'] == [1, -1] and seen['polarization'] == ['X', 'Y']
+    assert seen['payload_sha256'] == hashlib.sha256(x.tobytes()).hexdigest()
+
+
+def test_not_an_hdf5_file(tmp_path):
+    name = str(tmp_path / 'junk.h5')
+    with open(name, 'wb') as f:
+        f.write(b'\0' * 4096)
+    with pytest.raises(OSError):
+        hdf5.open(name)
+    with pytest.raises(ValueError):
+        hdf5.open(name, 'a')
