@@ -250,9 +250,10 @@ class DeviceTaskMixin:
             cache, c0 = self._ensure_frames(f0, f1)
             n = min(count - done, self._frame_span(f0, f1)[1] - pos)
             piece = cache[pos - c0:pos - c0 + n]
-            target = out[done:done + n]
-            if isinstance(target, np.ndarray) and target.flags.c_contiguous \
-                    and target.dtype == self._device_dtype:
+            # (``out`` may be anything with a shape and slice assignment -- the HDF5 writer,
+            # Integrate's accumulator: reference base.py:416-433 -- not only an array)
+            target = out[done:done + n] if isinstance(out, np.ndarray) else None
+            if target is not None and target.flags.c_contiguous and target.dtype == self._device_dtype:
                 piece.to_host(target)
             else:
                 out[done:done + n] = piece.to_host()
