@@ -211,30 +211,40 @@ def host_path(bt, torch, blocks=96, reps=3):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     n_valid = z.shape[0] * N_CHAN
-    # the bus by itself, both directions at once (what bounds this path)
+    # the bus by itself: one direction alone, and both directions at once (what bounds this path)
     m = 256 << 20
     a, b = hp.pinned_empty((m,), np.uint8), hp.pinned_empty((m,), np.uint8)
     da, db = bt.hip.DeviceArray((m,), np.uint8), bt.hip.DeviceArray((m,), np.uint8)
     s1, s2 = hp.Stream(), hp.Stream()
     lib = bt.hip.lib()
 
-    def both():
+    def up():
         bt.hip.check(lib.bbt_memcpy_h2d(da.ptr, a.ctypes.data, m, s1.handle))
+
+    def down():
         bt.hip.check(lib.bbt_memcpy_d2h(b.ctypes.data, db.ptr, m, s2.handle))
-    both()
-    s1.synchronize(), s2.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(4):
-        both()
-    s1.synchronize(), s2.synchronize()
-    duplex = 4 * m / (time.perf_counter() - t0) / 1e9
+
+    def rate(*copies, reps=6):
+        for c in copies:
+            c()
+        s1.synchronize(), s2.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for c in copies:
+                c()
+        s1.synchronize(), s2.synchronize()
+        return reps * m / (time.perf_counter() - t0) / 1e9
+    alone = min(rate(up), rate(down))
+    duplex = rate(up, down)
     res = dict(value=round(n_valid / best / 1e6, 1), unit='Msamples/s', blocks=blocks, blocks_per_run=run,
                seconds=round(best, 4), h2d_gbps=round(x.nbytes / best / 1e9, 2),
-               d2h_gbps=round(z.nbytes / best / 1e9, 2), pcie_duplex_gbps_each_way=round(duplex, 1),
+               d2h_gbps=round(z.nbytes / best / 1e9, 2), pcie_gbps_one_way_alone=round(alone, 1),
+               pcie_gbps_each_way_together=round(duplex, 1),
                what='Channelize(Dedisperse(HostStream over page-locked memory)).read() -> NumPy array: '
                     'PCIe both ways, three streams (upload / transforms / download of consecutive runs '
-                    'overlap); bounded by the bus with both directions busy (pcie_duplex_gbps_each_way, '
-                    'measured here with two 256 MiB copies at once)')
+                    'overlap); bounded by the bus with both directions busy (pcie_gbps_each_way_together: '
+                    '256 MiB copies up and down at once, measured here; one direction alone reaches '
+                    'pcie_gbps_one_way_alone)')
     ch.close()
     dd.close()
     return res

@@ -43,6 +43,11 @@ rate('H2D + D2H pinned, two streams (each way)', lambda: (hip.check(L.bbt_memcpy
 rate('H2D registered (hipHostRegister)', lambda: hip.check(L.bbt_memcpy_h2d(dev_a.ptr, reg.ctypes.data, n, s1.handle)))
 rate('H2D pageable', lambda: hip.check(L.bbt_memcpy_h2d(dev_a.ptr, page.ctypes.data, n, s1.handle)), reps=2)
 rate('D2H pageable', lambda: hip.check(L.bbt_memcpy_d2h(page.ctypes.data, dev_b.ptr, n, s2.handle)), reps=2)
+for mib in (64, 256, 512):
+    mm = mib << 20
+    rate(f'H2D + D2H pinned, two streams, {mib} MiB copies (each way)',
+         lambda: (hip.check(L.bbt_memcpy_h2d(dev_a.ptr, pin_a.ctypes.data, mm, s1.handle)),
+                  hip.check(L.bbt_memcpy_d2h(pin_b.ctypes.data, dev_b.ptr, mm, s2.handle))), nbytes=mm)
 # in 64 MiB pieces (the pipeline's granularity is a run of blocks)
 m = 64 << 20
 rate('H2D pinned, 16 x 64 MiB', lambda: [hip.check(L.bbt_memcpy_h2d(dev_a.ptr + i * m, pin_a.ctypes.data + i * m, m, s1.handle)) for i in range(16)])
