@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 134
+#define BBT_VERSION 135
 
 // ---------------------------------------------------------------------------
 // errors
@@ -629,6 +629,11 @@ struct bbt_osm_plan {
     // W_N^{k1 tau} [N1][N2 / 16]
     cf* tw4row = nullptr;
     cf* tw4base = nullptr;
+    // the same twiddles applied by the 256-point column passes instead (col_twiddles):
+    // twa [16][n2] = W_N^{tau n2}, twg [4][n2] = W_N^{16 n2 2^i}; BBT_OSM_TW_COL=0/1
+    bool tw_col = false;
+    cf* twa = nullptr;
+    cf* twg = nullptr;
     cf* wroot = nullptr;
     // block lengths that are not powers of two (gen_kernels.hpp): N = n1 * n2,
     // n1 == 1 for N <= 8192
@@ -643,6 +648,12 @@ struct bbt_osm_plan {
     // per-lane staging buffers (chunk x N x S complex64), allocated on first use
     const bbt_fir_plan* pre = nullptr;      // set for the duration of such a call
     float2* lane_stage[BBT_MAX_LANES] = {};
+    size_t lane_stage_bytes = 0;
+    // bbt_osm_execute_dechan_flat: the blocks of a chunk are first dechannelized (inverse
+    // transform over dechan_nch channels of dechan_s streams) into the lane's staging buffer,
+    // transposed (k_dechan_staged), and the one-kernel overlap-save step reads them from there
+    int dechan_nch = 0, dechan_s = 0;
+    FftTables dechan_tab;
     int stage_lane = 0;                     // lane of the chunk being enqueued
     // fused channelizer
     float2* seam = nullptr;     // [blocks][2][npair][n_chan] float4
@@ -678,7 +689,8 @@ static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, 
                        flat ? dim3(p->n1 * ch.nblk * p->npair, 1) : dim3(p->n1, rows),
                        dim3(N2 / 16), 0,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
-                       p->wroot, p->wroot + 4096, ch, p->outer, y0, p->tw4row, p->tw4base);
+                       p->wroot, p->wroot + 4096, ch, p->outer, y0, p->tw4row, p->tw4base,
+                       p->tw_col ? (NCH ? 1 : 3) : 0);
 }
 
 // (row length, channels) -> instantiation; nch == 0 is the plain row pass.
@@ -706,7 +718,7 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
 
 template <int N>
 static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
-                        hipStream_t st) {
+                        hipStream_t st, bool trans = false) {
     // lanes over groups of pairs when there are many (see k_osm_small); the
     // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
     constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
@@ -717,7 +729,25 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
                            out, ch, 1, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
         return 0;
     }
-    if (p->npair % PP == 0) {
+    if (trans) {
+        if (p->npair % PP) return fail("osm: staged blocks need a multiple of %d stream pairs", PP);
+        static const int variant = [] { const char* e = getenv("BBT_IPFB_VARIANT"); return e ? atoi(e) : 0; }();
+        if (N == 4096 && variant == 0) {
+            constexpr int MINW = N == 4096 ? 4 : 1;
+            if (ensure_dyn_lds((const void*)k_osm_small<N, PP, false, true, MINW>, lds1 * PP)) return 1;
+            hipLaunchKernelGGL((k_osm_small<N, PP, false, true, MINW>), dim3(nblk * (p->npair / PP)),
+                               dim3(PP * N / 16), lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index,
+                               p->tab2.tw0, p->tab2.tw1);
+        } else if (variant == 2) {
+            hipLaunchKernelGGL((k_osm_small<N, 1, false, true>), dim3(nblk * p->npair), dim3(N / 16), lds1, st,
+                               in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
+        } else {
+            if (ensure_dyn_lds((const void*)k_osm_small<N, PP, false, true>, lds1 * PP)) return 1;
+            hipLaunchKernelGGL((k_osm_small<N, PP, false, true>), dim3(nblk * (p->npair / PP)),
+                               dim3(PP * N / 16), lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index,
+                               p->tab2.tw0, p->tab2.tw1);
+        }
+    } else if (p->npair % PP == 0) {
         if (ensure_dyn_lds((const void*)k_osm_small<N, PP>, lds1 * PP)) return 1;
         hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(nblk * (p->npair / PP)), dim3(PP * N / 16),
                            lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0,
@@ -773,8 +803,15 @@ static int col_tile() {
 
 template <bool FIRST, bool SPEC>
 static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
-                          const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
+                          const OsmChunk& ch, int row_len, const SpecOut& so_arg, hipStream_t st) {
     constexpr size_t lds1 = FftGeo<256>::LDS_ELEMS * sizeof(v2);     // per column of a tile
+    SpecOut so = so_arg;
+    // (the row pass then leaves the four-step twiddles to this pass: the forward ones always, the
+    // inverse ones unless the fused channelizer's transform stands between them and this pass)
+    if (p->tw_col && p->outer == 1 && (FIRST || !SPEC)) {
+        so.twa = p->twa;
+        so.twg = p->twg;
+    }
     if (p->single) {
         if (so.det) return fail("osm: one-stream plans have no fused detection");
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 1, true>),
@@ -928,6 +965,20 @@ static int osm_launch_pass(bbt_osm_plan* p, int pass, const float2* in, float2* 
     return 0;
 }
 
+// Dechannelize the blocks of a chunk into a staging buffer, transposed (k_dechan_staged).
+template <int NCH>
+static int launch_dechan_staged(bbt_osm_plan* p, const float2* in, float2* stage, const OsmChunk& ch,
+                                hipStream_t st) {
+    constexpr int R = 8;
+    const size_t lds = (size_t)FftGeo<NCH>::LDS_ELEMS * R * sizeof(v2);
+    if (ensure_dyn_lds((const void*)k_dechan_staged<NCH, R>, lds)) return 1;
+    const int rows = (int)p->n, npp = p->dechan_s / 2;
+    const dim3 grid((unsigned)((rows + R - 1) / R * npp), ch.nblk);
+    hipLaunchKernelGGL((k_dechan_staged<NCH, R>), grid, dim3(R * NCH / 16), lds, st, in, stage, ch, rows,
+                       p->dechan_s, 1.0f / (float)NCH, p->dechan_tab.tw0, p->dechan_tab.tw1);
+    return 0;
+}
+
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch_arg,
                          const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
@@ -966,6 +1017,21 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         for (int i = 0; i < ch_arg.nblk; ++i) staged.b[i].in_off = (long long)i * p->n;
         chp = &staged;
         in = stage;
+    }
+    bool trans = false;
+    if (p->dechan_nch) {
+        float2* stage = p->lane_stage[p->stage_lane];
+        int rc = 0;
+        switch (p->dechan_nch) {
+            case 256: rc = launch_dechan_staged<256>(p, in, stage, ch_arg, st); break;
+            case 512: rc = launch_dechan_staged<512>(p, in, stage, ch_arg, st); break;
+            case 1024: rc = launch_dechan_staged<1024>(p, in, stage, ch_arg, st); break;
+            case 2048: rc = launch_dechan_staged<2048>(p, in, stage, ch_arg, st); break;
+            default: return fail("osm: no staged dechannelizer for %d channels", p->dechan_nch);
+        }
+        if (rc) return rc;
+        in = stage;
+        trans = true;
     }
     const OsmChunk& ch = *chp;         // (block i of a prefiltered chunk reads staging[i * N])
     OsmChunk pairs_view;               // one stream: the work buffers hold pairs of blocks
@@ -1006,11 +1072,11 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
     } else if (p->n1 == 1) {
         int rc = 0;
         switch (p->n2) {
-            case 256: rc = launch_small<256>(p, in, out, ch, st); break;
-            case 512: rc = launch_small<512>(p, in, out, ch, st); break;
-            case 1024: rc = launch_small<1024>(p, in, out, ch, st); break;
-            case 2048: rc = launch_small<2048>(p, in, out, ch, st); break;
-            case 4096: rc = launch_small<4096>(p, in, out, ch, st); break;
+            case 256: rc = launch_small<256>(p, in, out, ch, st, trans); break;
+            case 512: rc = launch_small<512>(p, in, out, ch, st, trans); break;
+            case 1024: rc = launch_small<1024>(p, in, out, ch, st, trans); break;
+            case 2048: rc = launch_small<2048>(p, in, out, ch, st, trans); break;
+            case 4096: rc = launch_small<4096>(p, in, out, ch, st, trans); break;
             default: return fail("osm: unsupported n_fft %lld", (long long)p->n);
         }
         if (rc) return rc;
@@ -1363,6 +1429,19 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
                     base[(size_t)k1 * t + tau] = unit_root((long long)k1 * tau, n_fft);
             }
             if (upload(&p->tw4row, row) || upload(&p->tw4base, base)) return bail(1);
+            // twiddles in the column passes: only with 256-point columns, and not with the
+            // experiment kernel that fuses two column passes (BBT_OSM_CA)
+            static const bool tw_col = [] { const char* e = getenv("BBT_OSM_TW_COL"); return e ? atoi(e) != 0 : true; }();
+            static const bool ca = [] { const char* e = getenv("BBT_OSM_CA"); return e && atoi(e) == 1; }();
+            if (tw_col && !ca && p->n1 == 256) {
+                std::vector<cf> a((size_t)16 * p->n2), g((size_t)4 * p->n2);
+                for (int n2 = 0; n2 < p->n2; ++n2) {
+                    for (int i = 0; i < 4; ++i) g[(size_t)i * p->n2 + n2] = unit_root((16ll << i) * n2, n_fft);
+                    for (int tau = 0; tau < 16; ++tau) a[(size_t)tau * p->n2 + n2] = unit_root((long long)tau * n2, n_fft);
+                }
+                if (upload(&p->twa, a) || upload(&p->twg, g)) return bail(1);
+                p->tw_col = true;
+            }
         }
     }
 
@@ -1489,6 +1568,8 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     if (p->resp_index) hipFree(p->resp_index);
     if (p->tw4row) hipFree(p->tw4row);
     if (p->tw4base) hipFree(p->tw4base);
+    if (p->twa) hipFree(p->twa);
+    if (p->twg) hipFree(p->twg);
     if (p->tlo) hipFree(p->tlo);
     if (p->thi) hipFree(p->thi);
     for (int l = 0; l < BBT_MAX_LANES; ++l) {
@@ -1587,6 +1668,80 @@ int bbt_osm_execute_flat(bbt_osm_plan* p, const void* in_dev, void* out_dev, int
                            blk.flat = 1;
                            blk.flat_sub = first_elem;
                        });
+}
+
+int bbt_osm_execute_dechan_flat(bbt_osm_plan* p, const void* spectra_dev, void* out_dev, int n_chan,
+                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_elem_off,
+                                const int32_t* valid_start, int32_t first_elem,
+                                const int32_t* valid_elems, bbt_stream stream) {
+    const char* who = "bbt_osm_execute_dechan_flat";
+    ARG_TRY(p && spectra_dev && out_dev, "%s: null argument", who);
+    ARG_TRY(!p->generic && !p->single && p->n1 == 1 && p->outer == 1 && p->n >= 256,
+            "%s: only for power-of-two blocks of 256 to 4096 rows with an even stream count", who);
+    ARG_TRY(n_chan == 256 || n_chan == 512 || n_chan == 1024 || n_chan == 2048,
+            "%s: n_chan=%d must be 256, 512, 1024 or 2048", who, n_chan);
+    ARG_TRY(p->S % n_chan == 0 && (p->S / n_chan) % 2 == 0,
+            "%s: the plan's %d streams are not n_chan=%d phases of an even number of streams", who, p->S, n_chan);
+    constexpr int PPN = 8;                    // (the largest lanes-over-pairs group of k_osm_small)
+    ARG_TRY(p->npair % PPN == 0, "%s: %d stream pairs", who, p->npair);
+    ARG_TRY(n_blocks >= 0 && (n_blocks == 0 || (in_off && out_elem_off && valid_start && valid_elems)),
+            "%s: bad descriptors", who);
+    ARG_TRY(first_elem >= 0 && first_elem < p->S && first_elem % 2 == 0,
+            "%s: first_elem=%d must be an even element of a row of %d", who, first_elem, p->S);
+    for (int64_t b = 0; b < n_blocks; ++b)
+        ARG_TRY(in_off[b] >= 0 && out_elem_off[b] >= 0 && out_elem_off[b] % 2 == 0 && valid_start[b] >= 0 &&
+                    valid_elems[b] >= 0 && valid_elems[b] % 2 == 0 &&
+                    (int64_t)valid_start[b] * p->S + first_elem + valid_elems[b] <= p->n * p->S,
+                "%s: block %lld keeps elements outside the block", who, (long long)b);
+    hipStream_t st = (hipStream_t)stream;
+    SpecOut so = {};
+    PlanCall call(p, st);
+    // two lanes, each with a staging buffer of `chunk` dechannelized blocks: 128 MiB together, so
+    // that what the first kernel wrote is still in the Infinity Cache when the second reads it
+    const size_t per_block = (size_t)p->n * p->S * sizeof(float2);
+    int chunk = (int)std::max<size_t>(1, (64u << 20) / per_block);
+    if (const char* env = getenv("BBT_IPFB_CHUNK")) chunk = std::max(1, atoi(env));
+    chunk = std::min(chunk, BBT_MAX_CHUNK);
+    int lanes = 2;
+    if (const char* env = getenv("BBT_IPFB_LANES")) lanes = std::min(std::max(1, atoi(env)), BBT_MAX_LANES);
+    const size_t bytes = per_block * chunk;
+    if (p->lane_stage_bytes < bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int l = 0; l < BBT_MAX_LANES; ++l)
+            if (p->lane_stage[l]) {
+                HIP_TRY(hipFree(p->lane_stage[l]));
+                p->lane_stage[l] = nullptr;
+            }
+        p->lane_stage_bytes = bytes;
+    }
+    for (int l = 0; l < lanes; ++l) {
+        if (!p->lane_stage[l]) HIP_TRY(hipMalloc((void**)&p->lane_stage[l], p->lane_stage_bytes));
+        if (lanes > 1 && !p->lane_stream[l])
+            HIP_TRY(hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
+        if (lanes > 1 && !p->ev_join[l])
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_join[l], hipEventDisableTiming));
+    }
+    if (lanes > 1 && !p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    if (p->dechan_tab.tw0 == nullptr || p->dechan_nch != n_chan)
+        if (get_tables(n_chan, &p->dechan_tab)) return 1;
+    const int chunk_was = p->chunk, lanes_was = p->lanes;
+    p->chunk = chunk;
+    p->lanes = lanes;
+    p->dechan_nch = n_chan;
+    p->dechan_s = p->S / n_chan;
+    const int rc = osm_run_all(p, (const float2*)spectra_dev, (float2*)out_dev, n_blocks, so, st,
+                               [&](OsmBlock& blk, int64_t b) {
+                                   blk.in_off = in_off[b];
+                                   blk.out_off = out_elem_off[b];
+                                   blk.valid_start = valid_start[b];
+                                   blk.valid_count = valid_elems[b];
+                                   blk.flat = 1;
+                                   blk.flat_sub = first_elem;
+                               });
+    p->chunk = chunk_was;
+    p->lanes = lanes_was;
+    p->dechan_nch = 0;
+    return rc;
 }
 
 int bbt_osm_execute_prefiltered(bbt_osm_plan* p, const bbt_fir_plan* fir, const void* in_dev,

@@ -342,7 +342,39 @@ struct SpecOut {
     int small_l;         // 0: natural order (position == q * n_chan + channel)
     int small_row;       // row length N2 of the row pass (a column pass of a three-level
                          // transform sees 16 such rows side by side)
+    // four-step twiddles applied by the 256-point column passes instead of the row pass
+    // (col_twiddles below): twa [16][N2] = W_N^{tau n2}, twg [4][N2] = W_N^{16 n2 2^i}; nullptr:
+    // the row pass applies them
+    const cf* twa;
+    const cf* twg;
 };
+
+// The four-step twiddles W_N^{k1 n2} of a two-level transform (N = 256 N2) on the registers of a
+// 256-point column pass: thread (tau, column n2) holds k1 = tau + 16 j, so the factor is
+// a g^j with a = W_N^{tau n2} and g, g^2, g^4, g^8 (g = W_N^{16 n2}) from tables
+// (float64-derived), the other powers by products at most four roundings deep.  SIGN < 0: multiply (forward, after the
+// column transform); SIGN > 0: by the conjugate (inverse, before it).  The column passes issue
+// 8-22 % of their cycles (profiles/r03_headline_sq_counters.json), the row pass that did this
+// before is bound by its VALU work.
+template <int SIGN>
+__device__ __forceinline__ void col_twiddles(c2 (&v)[16], const cf* __restrict__ twa,
+                                             const cf* __restrict__ twg, int tau, int n2, int N2) {
+    const cf a = twa[tau * N2 + n2], g = twg[n2], g2 = twg[N2 + n2], g4 = twg[2 * N2 + n2],
+             g8 = twg[3 * N2 + n2];
+    cf t[4];                                  // a g^{4 m}, m < 4
+    t[0] = a;
+    t[1] = cmul(a, g4);
+    t[2] = cmul(a, g8);
+    t[3] = cmul(t[2], g4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const cf t1 = cmul(t[m], g), t2 = cmul(t[m], g2);
+        v[4 * m] = twmul<SIGN>(v[4 * m], t[m]);
+        v[4 * m + 1] = twmul<SIGN>(v[4 * m + 1], t1);
+        v[4 * m + 2] = twmul<SIGN>(v[4 * m + 2], t2);
+        v[4 * m + 3] = twmul<SIGN>(v[4 * m + 3], cmul(t2, g));
+    }
+}
 
 // Column position -> q * n_chan + channel for the small-channel-count layout.
 __device__ __forceinline__ int small_channel_slot(int pos, const SpecOut& so) {
@@ -528,13 +560,61 @@ __device__ __forceinline__ void apply_resp(c2 (&v)[16], const cf* __restrict__ h
     }
 }
 
+// Dechannelize for the inverse filter bank (pfb.py:255-269 runs its transform along the block
+// axis of the DEchannelized frame): the inverse transform over the NCH channels of R consecutive
+// spectra per workgroup, written TRANSPOSED into a staging buffer -- sample (row r, phase k,
+// stream pair sp) of block b of the chunk goes to stage[b][k * (s / 2) + sp][r], 16 bytes in the
+// work-buffer format -- so that the overlap-save kernel that follows (k_osm_small<.., TRANS>)
+// reads each of its transforms as one contiguous run instead of 16 or 32 bytes out of every
+// 16 KiB row.  Lanes run over the R spectra first: a wave's loads are R runs of 128 bytes (8
+// channels of one spectrum), its stores runs of R * 16 bytes (R rows of one phase).
+//   in    : (spectra, NCH, s) complex64, s even; block b starts at spectrum ch.b[b].in_off
+//   stage : [ch.nblk][NCH * s / 2][rows] complete samples
+template <int NCH, int R>
+__global__ __launch_bounds__(R * NCH / 16) void k_dechan_staged(const float2* __restrict__ in,
+                                                               float2* __restrict__ stage, OsmChunk ch,
+                                                               int rows, int s, float scale,
+                                                               const cf* __restrict__ tw0,
+                                                               const cf* __restrict__ tw1) {
+    typedef FftGeo<NCH> G;
+    constexpr int T = G::T;
+    extern __shared__ v2 dechan_lds[];             // G::LDS_ELEMS * R elements
+    const int f = threadIdx.x % R, tau = threadIdx.x / R;
+    const int npp = s >> 1;
+    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int sp = vb % npp, r = (vb / npp) * R + f;
+    const int b = blockIdx.y;
+    const OsmBlock blk = osm_block(ch, b);
+    const bool active = r < rows;
+    c2 v[16];
+    if (active) {
+        const float2* src = in + (((blk.in_off + r) * NCH + tau) * s + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * s);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = czero();
+    }
+    wg_fft<NCH, +1, R>(v, dechan_lds, tau, f, tw0, tw1);
+    if (active) {
+        float2* dst = stage + ((((long long)b * NCH + tau) * npp + sp) * rows + r) * 2;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            st_int(dst + (long long)T * j * npp * rows * 2, c2{v[j].re * scale, v[j].im * scale});
+    }
+}
+
 // Single-kernel path, N <= 4096: one workgroup per (block, group of PP pairs).
 // With many streams (InversePolyphaseFilterBank runs this along the block axis
 // with n_chan * S streams) the lanes run over PP pairs first, so a wave touches
 // PP * 16 contiguous bytes of each complete sample instead of 16; the PP
 // transforms are interleaved in LDS (COLMODE = PP).
-template <int N, int PP, bool SINGLE = false>
-__global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restrict__ in,
+// TRANS: the blocks of the chunk come from a staging buffer that holds them transposed, block i
+// of the chunk at [i][pair][N rows] complete two-stream samples in the work-buffer format
+// (k_dechan_staged wrote it): a workgroup's loads are PP contiguous runs of N * 16 bytes instead
+// of PP * 16 bytes out of every row of the (row, stream) matrix.
+template <int N, int PP, bool SINGLE = false, bool TRANS = false, int MINW = 1>
+__global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __restrict__ in,
                                                           float2* __restrict__ out, OsmChunk ch, int S,
                                                           const cf* __restrict__ resp,
                                                           const int* __restrict__ resp_index,
@@ -565,9 +645,15 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
     const int pl = threadIdx.x % PP, tau = threadIdx.x / PP;
     const int sp = (vb % npg) * PP + pl;
     const OsmBlock blk = osm_block(ch, vb / npg);
-    const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
+    if constexpr (TRANS) {
+        const float2* src = in + (((long long)(vb / npg) * (S >> 1) + sp) * N + tau) * 2;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
+        for (int j = 0; j < 16; ++j) v[j] = ld_int(src + T * j * 2);
+    } else {
+        const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
+    }
     wg_fft<N, -1, CM>(v, lds, tau, pl, tw0, tw1);
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (long long)c0 * N + tau;
@@ -701,11 +787,13 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
             for (int j = 0; j < 16; ++j)
                 v[j] = ld_single_shifted(in, pr, (long long)(tau + 16 * j) * N2 + n2, 256ll * N2);
             wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
+            if (so.twa) col_twiddles<-1>(v, so.twa, so.twg, tau, n2, N2);
 #pragma unroll
             for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+            if (so.twa) col_twiddles<+1>(v, so.twa, so.twg, tau, n2, N2);
             wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
             if constexpr (SPEC) {
                 const SpecCursor ca = spec_cursor(out, so, pr.a, tau, 16, N2, n2, 1, 0, 1);
@@ -737,11 +825,13 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                 v[j] = ld_ext(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
         }
         wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
+        if (so.twa) col_twiddles<-1>(v, so.twa, so.twg, tau, n2, N2);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+        if (so.twa) col_twiddles<+1>(v, so.twa, so.twg, tau, n2, N2);
         wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
         SpecCursor cur;
         if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, so), S, sp, npair);
@@ -1048,7 +1138,8 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
     const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
-    OsmChunk ch, int outer, int y0, const cf* __restrict__ tw4row, const cf* __restrict__ tw4base) {
+    OsmChunk ch, int outer, int y0, const cf* __restrict__ tw4row, const cf* __restrict__ tw4base,
+    int tw_in_col) {
     // Three-level transforms (N > 2^20) run this pass once per row k1o of the
     // outer 256-point level: blockIdx.y = (block * npair + pair) * outer + k1o;
     // the full frequency index is k = k1o + outer * (k1 + N1 * k2).  outer == 1
@@ -1085,9 +1176,13 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     // both factors as tables (tw4base [N1][T] per thread, tw4row [N1][16] per row: its 16 values
     // are one or two wide scalar loads, where evaluating them from the W_4096 table was sixteen
     // scalar loads one waiting for the other, and the thread's factor a sincospif each way).
+    // tw_in_col (two-level plans with tables): bit 0, the first column pass has applied the
+    // forward twiddles; bit 1, the last column pass will apply the inverse ones (col_twiddles;
+    // not with the fused channelizer, whose transform over n2 comes after them)
     const bool tw4 = tw4row != nullptr;
-    cf base;
-    if (tw4) {
+    cf base = make_float2(1.f, 0.f);
+    if (tw_in_col & 1) {
+    } else if (tw4) {
         base = tw4base[k1 * T + tau];
     } else {
         float s, c;
@@ -1105,7 +1200,8 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         return cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
     };
 #if !(BBT_DBG & 1)
-    if (tw4) {
+    if (tw_in_col & 1) {
+    } else if (tw4) {
         const cf* tr = tw4row + k1 * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, tr[j]));
@@ -1155,6 +1251,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
             const cf wi = wrow(j);
             v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
         }
+    } else if (tw_in_col & 2) {
     } else if (tw4 && !(BBT_DBG & 1)) {
         // (the tables again, through opaque moves: see below)
         const cf* tr = tw4row + k1 * 16;

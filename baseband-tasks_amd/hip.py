@@ -72,6 +72,7 @@ SIGNATURES = {
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_prefiltered': [_vp, _vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_flat': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
+    'bbt_osm_execute_dechan_flat': [_vp, _vp, _vp, _int, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
     'bbt_osm_execute_channelized_detect': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int,
@@ -106,7 +107,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 132
+MIN_LIB_VERSION = 135
 
 _lib = None
 _lock = threading.Lock()
@@ -577,6 +578,19 @@ class OsmPlan(_Plan):
                                          in_off.ctypes.data_as(_pi64), out_elem_off.ctypes.data_as(_pi64),
                                          valid_start.ctypes.data_as(_pi32), int(first_elem),
                                          valid_elems.ctypes.data_as(_pi32), _stream))
+
+    def execute_dechan_flat(self, spectra_dev, out_dev, n_chan, in_off, out_elem_off, valid_start, first_elem,
+                            valid_elems):
+        """`execute_flat` on blocks of spectra that are dechannelized on the way in: see
+        bbt_osm_execute_dechan_flat."""
+        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
+        out_elem_off = np.ascontiguousarray(out_elem_off, dtype=np.int64)
+        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
+        valid_elems = np.ascontiguousarray(valid_elems, dtype=np.int32)
+        check(lib().bbt_osm_execute_dechan_flat(self._h, spectra_dev.ptr, out_dev.ptr, int(n_chan), in_off.shape[0],
+                                                in_off.ctypes.data_as(_pi64), out_elem_off.ctypes.data_as(_pi64),
+                                                valid_start.ctypes.data_as(_pi32), int(first_elem),
+                                                valid_elems.ctypes.data_as(_pi32), _stream))
 
     def execute_prefiltered(self, fir, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
         """`execute` on blocks that first pass through the direct filter

@@ -170,6 +170,18 @@ int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64
 int bbt_osm_execute_flat(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
                          const int64_t* in_off, const int64_t* out_elem_off, const int32_t* valid_start,
                          int32_t first_elem, const int32_t* valid_elems, bbt_stream stream);
+/* bbt_osm_execute_flat on blocks that are dechannelized on the way in: `spectra_dev` holds
+ * (spectra, n_chan, S / n_chan) complex64 -- the channelized stream InversePolyphaseFilterBank
+ * is given (pfb.py:157-232) -- and block b covers the n_fft spectra from in_off[b] on.  Per
+ * chunk of blocks one kernel does Dechannelize (inverse transform over the channels, 1 / n_chan:
+ * channelize.py:169-178) into a staging buffer of the plan, transposed so that the transform
+ * along the block axis reads contiguous memory; the dechannelized stream is never stored.
+ * n_chan in {256, 512, 1024, 2048}, S / n_chan even; the arithmetic is that of
+ * bbt_chan_execute (direction +1) followed by bbt_osm_execute_flat. */
+int bbt_osm_execute_dechan_flat(bbt_osm_plan* plan, const void* spectra_dev, void* out_dev, int n_chan,
+                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_elem_off,
+                                const int32_t* valid_start, int32_t first_elem,
+                                const int32_t* valid_elems, bbt_stream stream);
 /* The same with a short FIR in front of every block (Resample / Convolve with a
  * short response feeding Dedisperse): block b reads input
  * samples [in_off[b], in_off[b] + N + n_tap - 1) of `in_dev`, the filter
