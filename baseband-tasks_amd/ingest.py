@@ -24,12 +24,41 @@ import os
 import numpy as np
 
 from . import hip
+from . import host_pipeline
 from . import units as u
 from .base import Base
 from .device_task import DeviceTaskMixin
 from .units import Time
 
 __all__ = ['RawFrameStream', 'open_vdif', 'open_dada', 'vdif_header', 'encode_vdif_frames']
+
+
+class _RawFrameSets:
+    """The packed bytes as a host stream of frame sets (one row = the ``n_thread`` frames of a
+    set, uint8): what `host_pipeline.HostUploader` needs to read ahead -- a worker thread copies
+    run m + 1 to page-locked memory (or takes it from there, if ``raw`` was pinned with
+    `host_pipeline.pin_array`) and uploads it while run m is unpacked and processed."""
+
+    def __init__(self, raw, set_nbytes, n_sets):
+        self._rows = raw[:n_sets * set_nbytes].reshape(n_sets, set_nbytes)
+        self.shape = self._rows.shape
+        self.dtype = np.dtype(np.uint8)
+        self._pos = 0
+
+    def seek(self, offset):
+        self._pos = int(offset)
+        return self._pos
+
+    def read(self, count, out=None):
+        rows = self._rows[self._pos:self._pos + count]
+        self._pos += count
+        if out is None:
+            return np.ascontiguousarray(rows)
+        out[...] = rows
+        return out
+
+    def host_view(self, start, count):
+        return self._rows[start:start + count]
 
 
 class RawFrameStream(DeviceTaskMixin, Base):
@@ -67,6 +96,9 @@ class RawFrameStream(DeviceTaskMixin, Base):
         assert int(np.prod(sample_shape)) == self._n_thread * self._n_chan
         if squeeze:
             sample_shape = tuple(d for d in sample_shape if d != 1)
+        self._sets = None
+        if self._frame_map is None and isinstance(self._raw, np.ndarray) and self._raw.flags.c_contiguous:
+            self._sets = _RawFrameSets(self._raw, self._frame_nbytes * self._n_thread, n_sets)
         super().__init__(shape=(n_sets * samples_per_frame,) + sample_shape, start_time=start_time,
                          sample_rate=sample_rate, samples_per_frame=samples_per_frame,
                          dtype=np.complex64 if complex_data else np.float32, **kwargs)
@@ -74,9 +106,23 @@ class RawFrameStream(DeviceTaskMixin, Base):
     #: frame sets unpacked by one call (bounds the upload)
     max_frames_per_call = 4096
 
+    def _input_span(self, first, last):
+        """Frames in file order: the bytes of frame sets [first, last) (host_pipeline read-ahead)."""
+        if self._sets is None:
+            return None
+        return self._sets, first, last - first
+
     def _compute_frames(self, first, last, out):
         nb = self._frame_nbytes * self._n_thread
         valid_dev = None
+        up = host_pipeline.uploader_for(self._sets) if self._sets is not None else None
+        if up is not None:
+            raw_dev = up.fetch(first, last - first)          # (may be on its way already)
+            hip.check(hip.lib().bbt_unpack_masked(raw_dev.ptr, out.ptr, (last - first) * self._n_thread,
+                                                  self._frame_nbytes, self._header_nbytes, self._bits,
+                                                  self.samples_per_frame, self._n_thread, self._n_elem,
+                                                  self._code, None, hip.get_stream()))
+            return
         if self._frame_map is None:
             chunk = np.ascontiguousarray(self._raw[first * nb:last * nb])
         else:
@@ -99,7 +145,7 @@ class RawFrameStream(DeviceTaskMixin, Base):
     def close(self):
         super().close()
         self._drop_cache()
-        self._raw = None
+        self._raw = self._sets = None
 
 
 # --------------------------------------------------------------------------- VDIF

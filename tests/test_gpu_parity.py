@@ -1573,6 +1573,54 @@ def test_vdif_frames_are_unpacked_on_the_device(bits, complex_data):
         (bits, n_chan, complex_data, 49998, 3)
 
 
+def test_packed_frames_are_read_ahead_through_the_host_pipeline(monkeypatch):
+    """Frames in file order go up through `host_pipeline.HostUploader` (run m + 1 copied to
+    page-locked memory and uploaded while run m is unpacked and processed): same samples as the
+    synchronous upload, from pageable and from page-locked bytes, alone and in front of the path."""
+    from baseband_tasks_amd import host_pipeline as hp
+    from baseband_tasks_amd import ingest
+    rng = np.random.default_rng(77)
+    n, per, header = 40 * 1024, 1024, 32
+    frame = header + per * 4
+    raw = rng.integers(0, 256, size=(n // per) * frame, dtype=np.uint8)
+    pinned = hp.pinned_empty(raw.shape, np.uint8)
+    pinned[...] = raw
+
+    def stream(buf):
+        return ingest.RawFrameStream(buf, frame_nbytes=frame, header_nbytes=header, samples_per_frame=per, bits=8,
+                                     n_chan=2, complex_data=True, start_time=T0, sample_rate=1e6,
+                                     frequency=300 * u.MHz, sideband=1)
+
+    def results():
+        out = []
+        for buf in (raw, pinned):
+            fh = stream(buf)
+            fh.max_frames_per_call = 7                      # several runs per read
+            out.append(fh.read())
+            dd = bt.Dedisperse(stream(buf), 5., samples_per_frame=2**13 - 767 - 771)
+            dd.ih.max_frames_per_call = 7
+            dd.max_frames_per_call = 2
+            out.append(dd.read())
+            dd.seek(4321)
+            out.append(dd.read(9999))
+        return out
+
+    assert hp.ENABLED
+    fetched = []
+    real = hp.HostUploader.fetch
+    monkeypatch.setattr(hp.HostUploader, 'fetch', lambda self, *a: (fetched.append(a), real(self, *a))[1])
+    piped = results()
+    assert len(fetched) > 10
+    monkeypatch.setattr(hp, 'ENABLED', False)
+    n_fetched = len(fetched)
+    plain = results()
+    assert len(fetched) == n_fetched
+    for a, b in zip(piped, plain):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    want = (raw.reshape(-1, frame)[:, header:].astype(np.float32) - np.float32(127.5)) / np.float32(35.5)
+    assert np.allclose(piped[0], want.reshape(n, 2, 2).view(np.complex64)[..., 0], rtol=3e-7, atol=0)
+
+
 def test_vdif_frames_out_of_order_invalid_or_missing():
     """open_vdif reads every header: frames shuffled in the file come back in
     time and thread order; a frame flagged invalid and a frame that is not in
