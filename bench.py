@@ -124,11 +124,20 @@ def measure_traffic(args):
     try:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(tmp, counter)
-            r = subprocess.run([exe, '--pmc', counter, '-d', out, '-o', 'run', '--'] + child, cwd='/tmp', env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            # (its own process group, so that a run that overstays can be ended together with its children)
+            proc = subprocess.Popen([exe, '--pmc', counter, '-d', out, '-o', 'run', '--'] + child, cwd='/tmp',
+                                    env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=100)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f'rocprofv3 --pmc {counter} did not finish within 100 s'
             db = os.path.join(out, 'run_results.db')
-            if r.returncode or not os.path.exists(db):
-                return None, f'rocprofv3 --pmc {counter} failed (rc {r.returncode}): ' + r.stderr.decode()[-200:]
+            if proc.returncode or not os.path.exists(db):
+                return None, f'rocprofv3 --pmc {counter} failed (rc {proc.returncode}): ' + err.decode()[-200:]
             import sqlite3
             acc = {}
             for name, cname, disp, value in sqlite3.connect(db).execute(
