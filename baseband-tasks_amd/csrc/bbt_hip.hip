@@ -836,6 +836,29 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
     // 1 KiB runs of input and 256-byte runs of work; 16 streams +3 %, 8 streams
     // -5 %, hence only from 8 pairs on).
     static const int col_pp = [] { const char* e = getenv("BBT_COL_PP"); return e ? atoi(e) : 14; }();
+    // BBT_COL_WIDE (8 pairs or a multiple): 64-lane rows of 8 pairs x 8 columns -- whole 128-byte
+    // lines of the stream (1 KiB per row of the tile) AND 128-byte runs of the work buffer -- for
+    // the first pass (bit 0) and the last pass (bit 1; 18-20 spilled dwords at 1024 threads);
+    // bits 2 / 3: 32-lane rows (8 pairs x 4 columns, 512 threads, 64-byte runs of work).
+    // Measured on MI355X (config 4's share, 2^24 blocks, 8 pairs; round 3): 0: 2.77 / 2.78,
+    // 1: 2.85 / 2.86, 3: 2.89, 9: 2.89, 4: 2.76, 12: 2.81 G complete samples/s -> 9 for the outer
+    // column passes of three-level plans; two-level plans keep the choices below (not measured).
+    static const int col_wide_env = [] { const char* e = getenv("BBT_COL_WIDE"); return e ? atoi(e) : -1; }();
+    const int col_wide = col_wide_env >= 0 ? col_wide_env : (p->outer > 1 ? 9 : 0);
+    if (p->npair % 8 == 0 && (col_wide & (FIRST ? 1 : 2))) {
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 64, false, 8>, 64 * lds1)) return 1;
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 64, false, 8>),
+                           dim3(row_len / 8 * (p->npair / 8), ch.nblk), dim3(1024), 64 * lds1, st, in, out,
+                           work, ch, p->S, row_len, p->tab1.tw0, so);
+        return 0;
+    }
+    if (p->npair % 8 == 0 && (col_wide & (FIRST ? 4 : 8))) {
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 32, false, 8>, 32 * lds1)) return 1;
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32, false, 8>),
+                           dim3(row_len / 4 * (p->npair / 8), ch.nblk), dim3(512), 32 * lds1, st, in, out,
+                           work, ch, p->S, row_len, p->tab1.tw0, so);
+        return 0;
+    }
     if constexpr (FIRST) {
         if ((col_pp & 8) && p->npair % 4 == 0 && p->npair >= 8) {
             if (ensure_dyn_lds((const void*)k_osm_col256<true, SPEC, 64, false, 4>, 64 * lds1)) return 1;
