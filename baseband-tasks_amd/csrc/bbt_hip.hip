@@ -859,6 +859,16 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
                            work, ch, p->S, row_len, p->tab1.tw0, so);
         return 0;
     }
+    // bits 4 / 5: 4 pairs (or a multiple) as 32-lane rows of 4 pairs x 8 columns (512 threads):
+    // 512 contiguous bytes of an 8-stream row and 128-byte runs of work, first / last pass.
+    // Measured (config 5, 8 streams): 8.07 without, first 7.99, last 7.72, both 7.89 G -- off.
+    if (p->npair % 4 == 0 && (col_wide & (FIRST ? 16 : 32))) {
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 32, false, 4>, 32 * lds1)) return 1;
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32, false, 4>),
+                           dim3(row_len / 8 * (p->npair / 4), ch.nblk), dim3(512), 32 * lds1, st, in, out,
+                           work, ch, p->S, row_len, p->tab1.tw0, so);
+        return 0;
+    }
     if constexpr (FIRST) {
         if ((col_pp & 8) && p->npair % 4 == 0 && p->npair >= 8) {
             if (ensure_dyn_lds((const void*)k_osm_col256<true, SPEC, 64, false, 4>, 64 * lds1)) return 1;
