@@ -135,6 +135,14 @@ class Convolve(SpectralMultiplyTask):
             return self.ih, start, stop - start + pad
         return super()._input_span(first, last)
 
+    def read_planar(self, start, count):
+        """Samples [start, start + count) of this (short-block, complex, even-S) convolution as
+        S / 2 arrays of two-stream samples, shape (S / 2, count, 2): what a downstream
+        overlap-save plan reads best (`SpectralMultiplyTask._planar_input`).  Not cached."""
+        out = hip.DeviceArray((self._n_stream // 2, count, 2), np.complex64)
+        self._short_blocks()._compute_span(start, count, out, planar=True)
+        return out
+
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
         short = self._short_blocks()

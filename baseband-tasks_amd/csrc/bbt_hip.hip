@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 135
+#define BBT_VERSION 136
 
 // ---------------------------------------------------------------------------
 // errors
@@ -649,6 +649,8 @@ struct bbt_osm_plan {
     const bbt_fir_plan* pre = nullptr;      // set for the duration of such a call
     float2* lane_stage[BBT_MAX_LANES] = {};
     size_t lane_stage_bytes = 0;
+    // pair-planar hand-over (bbt_osm_plan_set_layout; OsmChunk::in_plane / out_plane)
+    long long in_plane = 0, out_plane = 0;
     // bbt_osm_execute_dechan_flat: the blocks of a chunk are first dechannelized (inverse
     // transform over dechan_nch channels of dechan_s streams) into the lane's staging buffer,
     // transposed (k_dechan_staged), and the one-kernel overlap-save step reads them from there
@@ -845,6 +847,13 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
     // column passes of three-level plans; two-level plans keep the choices below (not measured).
     static const int col_wide_env = [] { const char* e = getenv("BBT_COL_WIDE"); return e ? atoi(e) : -1; }();
     const int col_wide = col_wide_env >= 0 ? col_wide_env : (p->outer > 1 ? 9 : 0);
+    if (FIRST && ch.in_plane) {
+        // pair-planar input: every pair is a two-stream array, the plain 16-column tiles read
+        // 256-byte runs of it (the arrangements below are for interleaved rows)
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
+                           dim3(256), 16 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+        return 0;
+    }
     if (p->npair % 8 == 0 && (col_wide & (FIRST ? 1 : 2))) {
         if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 64, false, 8>, 64 * lds1)) return 1;
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 64, false, 8>),
@@ -937,7 +946,7 @@ static bool osm_ca_ok(const bbt_osm_plan* p, const SpecOut& so) {
     // the lanes were already busy 94 % of the time -- so it is opt-in (BBT_OSM_CA=1).
     static const bool on = [] { const char* e = getenv("BBT_OSM_CA"); return e && atoi(e) == 1; }();
     return on && !p->generic && !p->single && !p->pre && p->outer == 1 && p->n1 == 256 && !so.det &&
-           p->npair % 4 != 0 && col_tile() == 16 && p->lanes > 1;
+           p->npair % 4 != 0 && col_tile() == 16 && p->lanes > 1 && !p->in_plane;
 }
 static int launch_col256_ca(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                             const OsmChunk& chc, const OsmChunk& cha, const SpecOut& so, hipStream_t st) {
@@ -1012,9 +1021,12 @@ static int launch_dechan_staged(bbt_osm_plan* p, const float2* in, float2* stage
     return 0;
 }
 
-static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch_arg,
+static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch_given,
                          const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
+    OsmChunk ch_arg = ch_given;
+    ch_arg.in_plane = p->in_plane;
+    ch_arg.out_plane = p->out_plane;
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     if (p->timing) {
         for (int i = 0; i < 4; ++i) {
@@ -1701,6 +1713,22 @@ int bbt_osm_execute_flat(bbt_osm_plan* p, const void* in_dev, void* out_dev, int
                            blk.flat = 1;
                            blk.flat_sub = first_elem;
                        });
+}
+
+int bbt_osm_plan_set_layout(bbt_osm_plan* p, int64_t in_plane, int64_t out_plane) {
+    ARG_TRY(p, "bbt_osm_plan_set_layout: null plan");
+    ARG_TRY(in_plane >= 0 && out_plane >= 0, "bbt_osm_plan_set_layout: negative plane length");
+    const bool pairs = !p->generic && !p->single && p->outer == 1 && p->S % 2 == 0;
+    ARG_TRY(in_plane == 0 || (pairs && p->n1 == 256 && !p->stages),
+            "bbt_osm_plan_set_layout: pair-planar input needs a two-level plan with 256-point columns "
+            "(blocks of 2^17 to 2^20 samples) of an even number of streams");
+    ARG_TRY(out_plane == 0 || (pairs && p->n1 == 1),
+            "bbt_osm_plan_set_layout: pair-planar output needs a one-kernel plan (blocks of at most "
+            "4096 samples) of an even number of streams");
+    std::lock_guard<std::mutex> lock(p->mu);
+    p->in_plane = in_plane;
+    p->out_plane = out_plane;
+    return 0;
 }
 
 int bbt_osm_execute_dechan_flat(bbt_osm_plan* p, const void* spectra_dev, void* out_dev, int n_chan,

@@ -493,6 +493,13 @@ struct OsmChunk {
     // of them (the descriptor array holds 16); nblk is then not used.
     int reg_count;
     long long reg_hop;
+    // Pair-planar hand-over between two plans (bbt_osm_plan_set_layout): a stream of S = 2 P
+    // streams stored as P arrays of two-stream samples, pair p at [p * plane, (p + 1) * plane)
+    // complete two-stream samples.  out_plane: how the one-kernel plan (k_osm_small) writes its
+    // result; in_plane: how the first 256-point column pass reads its input -- 256-byte runs of
+    // one pair, as with two streams, instead of 16 bytes out of every 8 S-byte row.  0: interleaved.
+    long long in_plane;
+    long long out_plane;
     OsmBlock b[BBT_MAX_CHUNK];
 };
 __device__ __forceinline__ OsmBlock osm_block(const OsmChunk& ch, int i) {
@@ -668,6 +675,15 @@ __global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __
         }
         return;
     }
+    if (ch.out_plane) {
+        float2* dst = out + ((long long)sp * ch.out_plane + blk.out_off) * 2;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = tau + T * j - blk.valid_start;
+            if (r >= 0 && r < blk.valid_count) st_ext(dst + (long long)r * 2, v[j]);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int r = tau + T * j - blk.valid_start;
@@ -813,9 +829,16 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     const OsmBlock blk = ch.b[b];
     if (FIRST) {
         // read circularly shifted by blk.shift (see k_osm_col16): row 255 can wrap
-        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);
-        const long long wrap = (tau == 15 && n2 + blk.shift >= N2) ? (long long)256 * N2 * S : 0;
-        if (S == 2) {
+        // (pair-planar input: this pair's samples are an array of their own, see OsmChunk)
+        const int Si = ch.in_plane ? 2 : S;
+        const float2* src = in + (ch.in_plane ? (long long)sp * ch.in_plane * 2 : 2 * sp) +
+                            (blk.in_off + (long long)tau * N2 + n2 + blk.shift) * Si;
+        const long long wrap = (tau == 15 && n2 + blk.shift >= N2) ? (long long)256 * N2 * Si : 0;
+        if (Si == 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = ld_ext_nt(src + (long long)16 * j * N2 * 2 - (j == 15 ? wrap : 0));
+        } else if (S == 2) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));

@@ -72,6 +72,7 @@ SIGNATURES = {
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_prefiltered': [_vp, _vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_flat': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
+    'bbt_osm_plan_set_layout': [_vp, _i64, _i64],
     'bbt_osm_execute_dechan_flat': [_vp, _vp, _vp, _int, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
@@ -107,7 +108,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 135
+MIN_LIB_VERSION = 136
 
 _lib = None
 _lock = threading.Lock()
@@ -550,6 +551,10 @@ class OsmPlan(_Plan):
         check(lib().bbt_osm_plan_info(self._h, C.byref(ws), C.byref(chunk), C.byref(n1),
                                       C.byref(n2)))
         return dict(workspace_bytes=ws.value, chunk_blocks=chunk.value, n1=n1.value, n2=n2.value)
+
+    def set_layout(self, in_plane=0, out_plane=0):
+        """Pair-planar hand-over between two plans (see bbt_osm_plan_set_layout); 0, 0: interleaved."""
+        check(lib().bbt_osm_plan_set_layout(self._h, int(in_plane), int(out_plane)))
 
     def fusable(self, n_chan):
         """Can `execute_channelized` take Channelize(n_chan) into the row pass?"""

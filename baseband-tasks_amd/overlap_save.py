@@ -179,11 +179,38 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             return None
         return up
 
+    #: When the input is a `Convolve` (`Resample`) on its short-block route and both plans work on
+    #: the same S >= 4 complex streams, the filtered stream -- which only the two plans see -- is
+    #: handed over pair-planar (libbbt_hip: bbt_osm_plan_set_layout): S / 2 arrays of two-stream
+    #: samples, so that this task's first column pass reads 256-byte runs of one pair, as it does
+    #: for two streams, instead of 16 bytes out of every 8 S-byte row.  Same arithmetic, same
+    #: result.  ``BBT_PLANAR=0`` switches it off.
+    PLANAR_HANDOVER = os.environ.get('BBT_PLANAR', '1') != '0'
+
+    def _planar_input(self):
+        """The upstream short-block convolution that can hand its result over pair-planar, else None."""
+        from .convolution import Convolve
+        up = self.ih
+        if not (self.PLANAR_HANDOVER and isinstance(up, Convolve)) or up.closed:
+            return None
+        s = self._n_stream
+        if self._real or up._real or s % 2 or s < 4 or up._n_stream != s:
+            return None
+        n = self._ih_samples_per_frame
+        if n & (n - 1) or not (1 << 17) <= n <= (1 << 20) or self._prefilter_input() is not None:
+            return None
+        if up._short_blocks() is None or self._get_plan().info()['n1'] != 256:
+            return None
+        return up
+
     def _input_span(self, first, last):
         in0, in_len = self._block_descriptors(first, last)[:2]
         up = self._prefilter_input()
         if up is not None:
             return up.ih, in0, in_len + up._pad_start + up._pad_end
+        up = self._planar_input()
+        if up is not None:
+            return (up.ih,) + up._short_blocks()._span_blocks(in0, in_len)[:2]
         return self.ih, in0, in_len
 
     def _compute_frames(self, first, last, out):
@@ -195,6 +222,16 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             taps_less_one = up._pad_start + up._pad_end
             x = fetch_device(up.ih, in0, in_len + taps_less_one)
             self._get_plan().execute_prefiltered(up._fir, x, out, starts - in0, out_off, keep, counts)
+            return
+        up = self._planar_input()
+        if up is not None:
+            x = up.read_planar(in0, in_len)                   # (S / 2, in_len, 2)
+            plan = self._get_plan()
+            plan.set_layout(in_plane=in_len)
+            try:
+                plan.execute(x, out, starts - in0, out_off, keep, counts)
+            finally:
+                plan.set_layout()
             return
         x = fetch_device(self.ih, in0, in_len)
         self._run_plan(x, out, in_len, out.shape[0], starts - in0, out_off, keep, counts)
@@ -232,20 +269,28 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
             clipped(total - n, (k_fit + 1) * hop, total - pad)
         return in0, in_end - in0, ka, max(kb - ka + 1, 0), odd
 
-    def _compute_span(self, start, n_out, out):
+    def _compute_span(self, start, n_out, out, planar=False):
         """Output samples [start, start + n_out) into ``out``, whatever this task's frame
         boundaries, on the absolute block grid of `_span_blocks` (whole blocks in one launch for
         plans of one kernel, bbt_osm_execute_regular).  For tasks whose result does not depend
-        on the block geometry (exact linear convolutions)."""
+        on the block geometry (exact linear convolutions).  ``planar``: ``out`` is (S / 2, n_out, 2),
+        one array of two-stream samples per stream pair (complex streams, S even)."""
         hop = self._ih_samples_per_frame - self._pad_start - self._pad_end
         in0, in_len, ka, n_regular, odd = self._span_blocks(start, n_out)
         x = fetch_device(self.ih, in0, in_len)
 
         def run(plan, x, target):
-            if n_regular:
-                plan.execute_regular(x, target, n_regular, ka * hop - in0, ka * hop - start, hop, self._keep_from)
-            if odd:
-                plan.execute(x, target, *(list(col) for col in zip(*odd)))
+            if planar:
+                plan.set_layout(out_plane=n_out)
+            try:
+                if n_regular:
+                    plan.execute_regular(x, target, n_regular, ka * hop - in0, ka * hop - start, hop,
+                                         self._keep_from)
+                if odd:
+                    plan.execute(x, target, *(list(col) for col in zip(*odd)))
+            finally:
+                if planar:
+                    plan.set_layout()
 
         self._run_plan(x, out, in_len, n_out, executor=run)
 

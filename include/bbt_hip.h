@@ -170,6 +170,17 @@ int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64
 int bbt_osm_execute_flat(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64_t n_blocks,
                          const int64_t* in_off, const int64_t* out_elem_off, const int32_t* valid_start,
                          int32_t first_elem, const int32_t* valid_elems, bbt_stream stream);
+/* Pair-planar hand-over between two plans of the same S = 2 P streams (a short filter in
+ * front of a dispersion, `Dedisperse(Resample(x))`: sampling.py:308-312 + dispersion.py:135-139):
+ * the intermediate stream, which only the two plans see, is laid out as P arrays of two-stream
+ * samples -- pair p at complete two-stream samples [p * plane, (p + 1) * plane) -- so that the
+ * consumer's first column pass reads 256-byte runs of one pair instead of 16 bytes out of every
+ * 8 S-byte row.  out_plane > 0 (one-kernel plans, n_fft <= 4096): bbt_osm_execute /
+ * bbt_osm_execute_regular write sample r of pair p at out_dev[(p * out_plane + r) * 2 ...]
+ * (complex64 units; offsets in the block descriptors count samples of a plane).  in_plane > 0
+ * (two-level plans with 256-point columns, n_fft 2^17 ... 2^20): the executes read their input
+ * that way.  0, 0 restores the interleaved (n, S) layout.  The setting holds until changed. */
+int bbt_osm_plan_set_layout(bbt_osm_plan* plan, int64_t in_plane, int64_t out_plane);
 /* bbt_osm_execute_flat on blocks that are dechannelized on the way in: `spectra_dev` holds
  * (spectra, n_chan, S / n_chan) complex64 -- the channelized stream InversePolyphaseFilterBank
  * is given (pfb.py:157-232) -- and block b covers the n_fft spectra from in_off[b] on.  Per

@@ -611,9 +611,51 @@ def test_config5_resample_dedisperse_8_streams():
     # Fourier domain since round 3: both are the reference's linear convolution, each with its own
     # float32 rounding -- 1.0e-7 and 3e-7 -- under the dedispersion's 3.8e-7)
     assert rel_l2(y, y2) < 6e-7
+    # dd2 took the resampled stream pair-planar (4 arrays of two-stream samples); interleaved,
+    # the same kernels give the same bits
+    assert dd2._planar_input() is rs
+    dd3 = bt.Dedisperse(rs, 100., samples_per_frame=2**20 - 212476)
+    dd3.FUSE_PREFILTER = dd3.PLANAR_HANDOVER = False
+    assert dd3._planar_input() is None
+    assert np.array_equal(dd3.read(), y2)
+    dd2.seek(836100 - 1000)
+    assert np.array_equal(dd2.read(3000), y2[836100 - 1000:836100 + 2000])       # across a frame seam
     # piecewise reads of the fused task across block seams
     dd.seek(836100 - 500)
     assert np.array_equal(dd.read(1000), y[836100 - 500:836100 + 500])
+
+
+def test_planar_handover_small_blocks_and_odd_reads():
+    """Resample -> Dedisperse on 2^17-sample blocks, 4 and 6 streams: the filtered stream goes to
+    the dispersion plan as arrays of stream pairs (bbt_osm_plan_set_layout); results equal the
+    interleaved hand-over bit for bit and the oracle to rounding, for whole reads, reads cut
+    inside frames, and the last (re-aligned) frame."""
+    n_fft, pad = 2**17, 6132 + 6163
+    for n_stream in (4, 6):
+        n_in = 3 * n_fft + 1234
+        rng = np.random.default_rng(n_stream)
+        x = rng.standard_normal((n_in, 2 * n_stream), dtype=np.float32).view(np.complex64)
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=n_fft, frequency=300 * u.MHz, sideband=1)
+
+        def chain(planar):
+            rs = bt.Resample(ds, 0.25, pad=64, samples_per_frame=20000)
+            rs.seek(0)
+            dd = bt.Dedisperse(rs, 40., samples_per_frame=n_fft - pad)
+            dd.PLANAR_HANDOVER = planar
+            assert (dd._pad_start + dd._pad_end, dd._ih_samples_per_frame) == (pad, n_fft)
+            assert (dd._planar_input() is rs) == planar
+            return dd
+
+        a, b = chain(True), chain(False)
+        a.max_frames_per_call = b.max_frames_per_call = 2
+        ya = a.read()
+        assert np.array_equal(ya, b.read())
+        a.seek(12345)
+        assert np.array_equal(a.read(70001), ya[12345:12345 + 70001])
+        r, rinfo = orc.resample(x, 0.25, pad=64, samples_per_frame=20000)
+        want, _ = orc.dedisperse(r, 1e6, 300., 1, 40., samples_per_frame=n_fft - pad,
+                                 ih_samples_per_frame=rinfo['spf'])
+        assert_parity(ya, want, f'planar hand-over, {n_stream} streams')
 
 
 def _close(got, want, rtol=2e-6):
