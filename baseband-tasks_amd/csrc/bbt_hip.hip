@@ -843,10 +843,12 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
     // the first pass (bit 0) and the last pass (bit 1; 18-20 spilled dwords at 1024 threads);
     // bits 2 / 3: 32-lane rows (8 pairs x 4 columns, 512 threads, 64-byte runs of work).
     // Measured on MI355X (config 4's share, 2^24 blocks, 8 pairs; round 3): 0: 2.77 / 2.78,
-    // 1: 2.85 / 2.86, 3: 2.89, 9: 2.89, 4: 2.76, 12: 2.81 G complete samples/s -> 9 for the outer
-    // column passes of three-level plans; two-level plans keep the choices below (not measured).
+    // 1: 2.85 / 2.86, 3: 2.89, 9: 2.89, 4: 2.76, 12: 2.81 G complete samples/s; two-level plans
+    // (2^20 blocks, 16 / 32 streams; tools/bench_streams.py): 0: 4.33 / 2.15, 1: 4.53-4.62 / 2.25,
+    // 3: 4.64 / 2.24, 9: 4.61 / 2.26, 4: 4.42 / 2.01, 12: 4.50 / 2.16 -> 9 whenever the pairs come
+    // in eights.
     static const int col_wide_env = [] { const char* e = getenv("BBT_COL_WIDE"); return e ? atoi(e) : -1; }();
-    const int col_wide = col_wide_env >= 0 ? col_wide_env : (p->outer > 1 ? 9 : 0);
+    const int col_wide = col_wide_env >= 0 ? col_wide_env : 9;
     if (FIRST && ch.in_plane) {
         // pair-planar input: every pair is a two-stream array, the plain 16-column tiles read
         // 256-byte runs of it (the arrangements below are for interleaved rows)

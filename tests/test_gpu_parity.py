@@ -520,6 +520,32 @@ def test_short_channelizer(n):
         assert_parity(z, orc.channelize(x[:z.shape[0] * n], n), f'n={n} streams {shape}')
 
 
+def test_two_level_blocks_on_sixteen_streams():
+    """2^17-sample blocks (256 x 512) on 16 and 24 streams: with the stream pairs in eights the
+    column passes take tiles of 8 pairs x 8 (first) / 4 (last) columns (BBT_COL_WIDE), with 12
+    pairs groups of four; plain, with per-stream responses, and with the channelizer folded in."""
+    n_fft = 2**17
+    for n_stream in (16, 24):
+        n_in = 2 * n_fft + 4321
+        rng = np.random.default_rng(n_stream)
+        x = rng.standard_normal((n_in, 2 * n_stream), dtype=np.float32).view(np.complex64)
+        freq = (300. + 1.0 * np.arange(n_stream)) * u.MHz
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=n_fft, frequency=freq, sideband=1)
+        with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
+            dd = bt.Dedisperse(ds, 40., reference_frequency=freq)
+        assert dd._ih_samples_per_frame == n_fft and dd._get_plan().info()['n1'] == 256
+        y = dd.read()
+        want, info = orc.dedisperse(x, 1e6, 300. + np.arange(n_stream), 1, 40.,
+                                    reference_frequency_mhz=300. + np.arange(n_stream),
+                                    ih_samples_per_frame=n_fft, fast_len=HipFFTMaker(power_of_two=True).next_fast_len)
+        assert info['ih_spf'] == n_fft
+        assert_parity(y, want, f'{n_stream} streams')
+        ch = bt.Channelize(dd, 256, samples_per_frame=4)
+        assert ch._fusable_input() is dd
+        z = ch.read()
+        assert_parity(z, orc.channelize(want[:z.shape[0] * 256], 256), f'{n_stream} streams, fused channelizer')
+
+
 def test_config4_subband_block_2_24():
     """Config 4 (SURVEY 8d restatement), ONE sub-band: 6.25 MHz at 403.125 MHz,
     DM 557, blocks of 2^24 samples (three levels, 256 x 16 x 4096), then
