@@ -899,6 +899,15 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                 p[j] = (full && sj >= 0 && sj < cur.n_out) ? detect_pair(v[j], mode)
                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+#if BBT_DBG & 64
+            {   // timing only: the powers are formed, nothing is reduced or stored
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += p[j].x + p[j].y + p[j].z + p[j].w;
+                if (acc == 12345.678f) unsafeAtomicAdd(so.det, acc);
+                return;
+            }
+#endif
             const int npass = mode ? 2 : 1;
             for (int pass = 0; pass < npass; ++pass) {
                 __syncthreads();                                     // exchange buffer / previous pass done
@@ -919,7 +928,11 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                     if (hi > 256) hi = 256;
                     float sum = 0.f;
                     for (int n1 = lo; n1 < hi; ++n1) sum += pf[n1 * (FCOL * 2) + fc];
+#if BBT_DBG & 128
+                    if (sum == 12345.678f)          // timing only: the sums are formed, not added
+#else
                     if (sum != 0.f)
+#endif
                         unsafeAtomicAdd(so.det + detect_index(bin, ch0 + (fc >> 1), sp, so.lg_chan, npair, mode)
                                             + 2 * pass + (fc & 1),
                                         sum * so.det_scale);
