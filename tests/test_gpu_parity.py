@@ -652,12 +652,12 @@ def test_config5_resample_dedisperse_8_streams():
 
 
 def test_planar_handover_small_blocks_and_odd_reads():
-    """Resample -> Dedisperse on 2^17-sample blocks, 4 and 6 streams: the filtered stream goes to
+    """Resample -> Dedisperse on 2^17-sample blocks, 4, 6 and 16 streams: the filtered stream goes to
     the dispersion plan as arrays of stream pairs (bbt_osm_plan_set_layout); results equal the
     interleaved hand-over bit for bit and the oracle to rounding, for whole reads, reads cut
     inside frames, and the last (re-aligned) frame."""
     n_fft, pad = 2**17, 6132 + 6163
-    for n_stream in (4, 6):
+    for n_stream in (4, 6, 16):
         n_in = 3 * n_fft + 1234
         rng = np.random.default_rng(n_stream)
         x = rng.standard_normal((n_in, 2 * n_stream), dtype=np.float32).view(np.complex64)
