@@ -687,9 +687,14 @@ static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, 
                       (long long)p->n1 * ch.nblk * p->npair < (1ll << 31);
     // (three-level plans may launch a range [y0, y0 + ny) of the outer rows)
     const int rows = ny >= 0 ? ny : ch.nblk * p->npair * p->outer;
+    // BBT_ROWPASS_LDS_PAD: bytes of dynamic LDS asked for on top of the kernel's own (nothing uses
+    // them): fewer row-pass workgroups per CU, i.e. register room for the other lane's column
+    // passes on the same SIMDs (experiment switch)
+    static const int lds_pad = [] { const char* e = getenv("BBT_ROWPASS_LDS_PAD"); return e ? atoi(e) : 0; }();
+    if (lds_pad && ensure_dyn_lds((const void*)k_osm_rowpass<N2, NCH>, (size_t)lds_pad)) return;
     hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>),
                        flat ? dim3(p->n1 * ch.nblk * p->npair, 1) : dim3(p->n1, rows),
-                       dim3(N2 / 16), 0,
+                       dim3(N2 / 16), (size_t)lds_pad,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
                        p->wroot, p->wroot + 4096, ch, p->outer, y0, p->tw4row, p->tw4base,
                        p->tw_col ? (NCH ? 1 : 3) : 0);
@@ -908,8 +913,23 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
                            dim3(512), 32 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
     } else {
+        // BBT_COL_LDS_PAD_FIRST / _LAST: as BBT_ROWPASS_LDS_PAD, for the plain 16-column tiles.  The
+        // first pass (116 VGPRs, 34 KiB of LDS) fits four workgroups per CU, 464 registers per lane
+        // of a SIMD: no row-pass wave (162) can join them.  Asking for 9 KiB more leaves three
+        // (348 + 162 = 510 of 512): measured on MI355X (headline, same-box pairs) +1.8 / +1.3 /
+        // +1.9 % with it on both column passes, +0.9 / +2.3 % on the first alone; final form (first
+        // pass, two streams): headline 48.79 / 49.47 / 49.51 -> 49.62 / 49.36 / 49.65 (within the
+        // noise), config 2 48.58 / 48.72 -> 49.88 / 49.75 (+2.4 %), config 5 (four pairs) -0.5 %,
+        // hence only for one pair; fewer row-pass workgroups per CU (20 KiB more: two) cost 6 %.
+        // The last pass is at three already (148 VGPRs).
+        static const int col_pad_env = [] {
+            const char* e = getenv(FIRST ? "BBT_COL_LDS_PAD_FIRST" : "BBT_COL_LDS_PAD_LAST");
+            return e ? atoi(e) : -1;
+        }();
+        const int col_pad = col_pad_env >= 0 ? col_pad_env : ((FIRST && p->npair == 1) ? 9216 : 0);
+        if (col_pad && ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 16>, 16 * lds1 + col_pad)) return 1;
         hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
-                           dim3(256), 16 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
+                           dim3(256), 16 * lds1 + col_pad, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
     }
     return 0;
 }
