@@ -43,6 +43,15 @@ namespace bbt {
 #define BBT_GEN_EPT 8                 // tile elements per thread
 #endif
 #define BBT_GEN_MAX_THREADS (BBT_GEN_MAX_LEN / BBT_GEN_EPT)
+// Stage twiddles W^{r k}, r < R: 1 = one table value W^k per butterfly and its powers by products
+// (w[r] = w[ceil(r/2)] w[floor(r/2)], at most four roundings deep); 0 = R - 1 table loads.  The
+// loads were what the stages waited for (eight 8-byte loads per radix-9 butterfly against nine
+// 16-byte LDS reads): measured on MI355X (round 3) Dedisperse with default arguments at 800 / 600
+// MHz 19.3 -> 21.9 / 19.1 -> 20.4 G, Channelize 1000 / 6561 / 8192: 125 -> 139 / 70 -> 82 / 71 -> 76 G,
+// 1536 and 3000 unchanged; 4-6 spilled dwords in three of the kernels.
+#ifndef BBT_GEN_TW_POWERS
+#define BBT_GEN_TW_POWERS 1
+#endif
 #ifndef BBT_GEN_MAXR
 #define BBT_GEN_MAXR 12               // largest radix of a stage (14 .. 16: spilled registers; measured 5 % slower)
 #endif
@@ -213,12 +222,26 @@ __device__ __forceinline__ void gen_stage(f4* __restrict__ lds, int n, int ns, i
         if (j < m) {
             const f4* src = lds + (j << lg) + col;
             const int mstride = m << lg;
+#if BBT_GEN_TW_POWERS
+            // one table value W^k per butterfly, its powers by products (depth <= log2 R)
+            cf w[R];
+            w[1] = wn[k];
+#pragma unroll
+            for (int r = 2; r < R; ++r) w[r] = cmul(w[(r + 1) / 2], w[r / 2]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c2 t = f4_to_c2(src[r * mstride]);
+                if (r > 0 && ns > 1) t = twmul<SIGN>(t, w[r]);
+                v[b][r] = t;
+            }
+#else
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 c2 t = f4_to_c2(src[r * mstride]);
                 if (r > 0 && ns > 1) t = twmul<SIGN>(t, wn[(r - 1) * ns + k]);
                 v[b][r] = t;
             }
+#endif
             gen_butterfly<SIGN, R>(v[b]);
         }
         k += k_step;
