@@ -136,30 +136,50 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restr
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int k1 = blockIdx.x, sp = blockIdx.y % npair;
     f4* row = reinterpret_cast<f4*>(work) + ((long long)blockIdx.y * N1 + k1) * N2;
+    // The four-step twiddles W_N^{k1 n2} of a thread's elements n2 = tid + e nthr are
+    // a s^e with a = W_N^{k1 tid} and s = W_N^{k1 nthr} (the same for the whole workgroup): two
+    // table look-ups and products at most four roundings deep instead of a look-up (two loads)
+    // per element and direction -- like the stage twiddles, loads were what this kernel waited for.
+    auto four_step = [&](cf (&tw)[BBT_GEN_EPT]) {
+        const cf a = big_twiddle(tlo, thi, k1 * tid);
+        cf sp_[BBT_GEN_EPT];
+        sp_[1] = big_twiddle(tlo, thi, (int)(((long long)k1 * nthr) % ((long long)N1 * N2)));
+#pragma unroll
+        for (int e = 2; e < BBT_GEN_EPT; ++e) sp_[e] = cmul(sp_[(e + 1) / 2], sp_[e / 2]);
+        tw[0] = a;
+#pragma unroll
+        for (int e = 1; e < BBT_GEN_EPT; ++e) tw[e] = cmul(a, sp_[e]);
+    };
     {
         f4 x[BBT_GEN_EPT];
-        cf tw[BBT_GEN_EPT];                              // the four-step twiddles W_N^{k1 n2}
+        cf tw[BBT_GEN_EPT];
         BBT_GEN_FOR(e, i, N2) x[e] = i < N2 ? row[i] : f4{0.f, 0.f, 0.f, 0.f};
-        BBT_GEN_FOR(e, i, N2) tw[e] = i < N2 ? big_twiddle(tlo, thi, k1 * i) : make_float2(1.f, 0.f);
+        four_step(tw);
         BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_twmul(x[e], tw[e]);
     }
     __syncthreads();
     gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
     {
-        const cf* h0 = resp + ((long long)resp_index[2 * sp] * N1 + k1) * N2;
-        const cf* h1 = resp + ((long long)resp_index[2 * sp + 1] * N1 + k1) * N2;
+        const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
+        const cf* h0 = resp + ((long long)c0 * N1 + k1) * N2;
+        const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2;
         cf ha[BBT_GEN_EPT], hb[BBT_GEN_EPT];
-        BBT_GEN_FOR(e, i, N2) {
-            ha[e] = i < N2 ? h0[i] : make_float2(0.f, 0.f);
-            hb[e] = i < N2 ? h1[i] : make_float2(0.f, 0.f);
+        if (c0 == c1) {                                  // (both streams of the pair: one column)
+            BBT_GEN_FOR(e, i, N2) ha[e] = i < N2 ? h0[i] : make_float2(0.f, 0.f);
+            BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], ha[e]);
+        } else {
+            BBT_GEN_FOR(e, i, N2) {
+                ha[e] = i < N2 ? h0[i] : make_float2(0.f, 0.f);
+                hb[e] = i < N2 ? h1[i] : make_float2(0.f, 0.f);
+            }
+            BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], hb[e]);
         }
-        BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], hb[e]);
     }
     __syncthreads();
     gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
     {
         cf tw[BBT_GEN_EPT];
-        BBT_GEN_FOR(e, i, N2) tw[e] = i < N2 ? big_twiddle(tlo, thi, k1 * i) : make_float2(1.f, 0.f);
+        four_step(tw);
         BBT_GEN_FOR(e, i, N2) if (i < N2) row[i] = f4_twmul(gen_lds[i], make_float2(tw[e].x, -tw[e].y));
     }
 }
