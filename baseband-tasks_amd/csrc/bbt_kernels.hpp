@@ -31,6 +31,31 @@
 #define BBT_DBG 0
 #endif
 
+// Transform twiddles W^{tau c}, c < 16, of a stage: 0 = fifteen table loads per thread, 1 = one
+// load and its powers (products at most four roundings deep), 2 = four loads (c = 1, 2, 4, 8)
+// and eleven products at most three deep (fft_core.hpp).  The kernels that wait for loads rather
+// than for the VALU gain; measured on MI355X (round 3, same-box pairs):
+//   row pass      headline 49.63-49.96 -> 50.51-50.78 (1) / 50.58-50.89 (2) G; rel-L2 against the
+//                 oracle 3.81e-7 -> 5.77e-7 (1) / 4.23e-7 (2): 2
+//   one-kernel    inverse filter bank 51.0 -> 51.9 G, config 5 8.44 -> 8.62 G (1 and 2 alike): 2
+//   filter bank   config 3 136.5 -> 138.4-140.0 (1) / 139.0 (2) G: 2
+//   column passes 48.8 -> 48.6 G and Channelize (k_fft_rows) 193.8 -> 194.0 G: no gain, 0
+#ifndef BBT_SMALL_TW_POW
+#define BBT_SMALL_TW_POW 2
+#endif
+#ifndef BBT_ROWS_TW_POW
+#define BBT_ROWS_TW_POW 0
+#endif
+#ifndef BBT_COL_TW_POW
+#define BBT_COL_TW_POW 0
+#endif
+#ifndef BBT_ROWPASS_TW_POW
+#define BBT_ROWPASS_TW_POW 2
+#endif
+#ifndef BBT_PFB_TW_POW
+#define BBT_PFB_TW_POW 2
+#endif
+
 namespace bbt {
 
 // Blocks dispatched round-robin over the 8 XCDs: give each XCD one contiguous
@@ -100,7 +125,7 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
                 v[j] = c2{v2{a.x, b.x}, v2{a.y, b.y}};
             }
         }
-        wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+        wg_fft<N, SIGN, false, 0, BBT_ROWS_TW_POW>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
         if constexpr (SPLIT && SIGN < 0) {
             v2* area = lds + slot * G::LDS_ELEMS;                 // N elements fit (LDS_ELEMS >= N)
             // k = tau + T j for j < 8 covers 0 .. N/2 - 1; thread 0 also takes k = N/2
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(FPW* N / 16) void k_fft_rows(const float2* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = czero();
     }
-    wg_fft<N, SIGN, false>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    wg_fft<N, SIGN, false, 0, BBT_ROWS_TW_POW>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
     if constexpr (SPLIT && SIGN < 0) {
         // Stream pairs, each stream z = a + i b of two real streams (S complex = 2 S real streams):
         // the half spectra of all of them, (transform, k, 2 S reals), as in the one-stream case above.
@@ -620,6 +645,7 @@ __global__ __launch_bounds__(R * NCH / 16) void k_dechan_staged(const float2* __
 // of the chunk at [i][pair][N rows] complete two-stream samples in the work-buffer format
 // (k_dechan_staged wrote it): a workgroup's loads are PP contiguous runs of N * 16 bytes instead
 // of PP * 16 bytes out of every row of the (row, stream) matrix.
+// (its transform twiddles come as powers, BBT_SMALL_TW_POW below)
 template <int N, int PP, bool SINGLE = false, bool TRANS = false, int MINW = 1>
 __global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __restrict__ in,
                                                           float2* __restrict__ out, OsmChunk ch, int S,
@@ -640,10 +666,10 @@ __global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __
         const SinglePair pr = single_pair(ch, vb);
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_single(in, pr, tau + T * j);
-        wg_fft<N, -1, CM>(v, lds, tau, 0, tw0, tw1);
+        wg_fft<N, -1, CM, 0, BBT_SMALL_TW_POW>(v, lds, tau, 0, tw0, tw1);
         const cf* h = resp + (long long)resp_index[0] * N + tau;
         apply_resp<T>(v, h, h, true);
-        wg_fft<N, +1, CM>(v, lds, tau, 0, tw0, tw1);
+        wg_fft<N, +1, CM, 0, BBT_SMALL_TW_POW>(v, lds, tau, 0, tw0, tw1);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_single(out, pr, tau + T * j, v[j]);
         return;
@@ -661,12 +687,12 @@ __global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
     }
-    wg_fft<N, -1, CM>(v, lds, tau, pl, tw0, tw1);
+    wg_fft<N, -1, CM, 0, BBT_SMALL_TW_POW>(v, lds, tau, pl, tw0, tw1);
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (long long)c0 * N + tau;
     const cf* h1 = resp + (long long)c1 * N + tau;
     apply_resp<T>(v, h0, h1, c0 == c1);
-    wg_fft<N, +1, CM>(v, lds, tau, pl, tw0, tw1);
+    wg_fft<N, +1, CM, 0, BBT_SMALL_TW_POW>(v, lds, tau, pl, tw0, tw1);
     if (blk.flat) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -802,7 +828,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 v[j] = ld_single_shifted(in, pr, (long long)(tau + 16 * j) * N2 + n2, 256ll * N2);
-            wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
+            wg_fft<256, -1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
             if (so.twa) col_twiddles<-1>(v, so.twa, so.twg, tau, n2, N2);
 #pragma unroll
             for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
@@ -810,7 +836,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
             if (so.twa) col_twiddles<+1>(v, so.twa, so.twg, tau, n2, N2);
-            wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
+            wg_fft<256, +1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
             if constexpr (SPEC) {
                 const SpecCursor ca = spec_cursor(out, so, pr.a, tau, 16, N2, n2, 1, 0, 1);
                 const SpecCursor cb = spec_cursor(out, so, pr.b, tau, 16, N2, n2, 1, 0, 1);
@@ -847,7 +873,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
             for (int j = 0; j < 16; ++j)
                 v[j] = ld_ext(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
         }
-        wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);
+        wg_fft<256, -1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
         if (so.twa) col_twiddles<-1>(v, so.twa, so.twg, tau, n2, N2);
 #pragma unroll
         for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
@@ -855,7 +881,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
         if (so.twa) col_twiddles<+1>(v, so.twa, so.twg, tau, n2, N2);
-        wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
+        wg_fft<256, +1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
         SpecCursor cur;
         if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, so), S, sp, npair);
         if constexpr (SPEC && DET) {
@@ -1256,7 +1282,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
     const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
-    wg_fft<N2, -1, 0, IMOFF>(v, lds, tau, 0, tw0, tw1);
+    wg_fft<N2, -1, 0, IMOFF, BBT_ROWPASS_TW_POW>(v, lds, tau, 0, tw0, tw1);
     // keep the response and second-transform table loads from being hoisted above
     // the first transform (they were for NCH == 0: 199 VGPRs, 2 waves per SIMD)
     __builtin_amdgcn_sched_barrier(0);
@@ -1270,7 +1296,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         const cf* tw0b = tw0;
         const cf* tw1b = tw1;
         asm volatile("" : "+s"(tw0b), "+s"(tw1b));
-        wg_fft<N2, +1, 0, IMOFF>(v, lds, tau, 0, tw0b, tw1b);
+        wg_fft<N2, +1, 0, IMOFF, BBT_ROWPASS_TW_POW>(v, lds, tau, 0, tw0b, tw1b);
     }
     if (NCH > 0 && outer > 1) {
         // Three-level + fused channelizer: the outer four-step twiddle
@@ -1399,7 +1425,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
             for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
         }
         // the 16 sequences f = q P + c, one element b = tau each: T-point transforms over b
-        wg_fft_tail<N2, -1, 0, IMOFF>(v, lds, tau, 0, tw1);
+        wg_fft_tail<N2, -1, 0, IMOFF, BBT_ROWPASS_TW_POW>(v, lds, tau, 0, tw1);
         // thread tau2: register u + NU c2 holds k' = (g + R2 u) + 16 c2 of sequence f = tau2 & 15
         constexpr int R2 = G::R2, NU = 16 / R2;
         const int f = tau & 15, g = tau >> 4;
@@ -1533,7 +1559,7 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
             }
         }
     }
-    wg_fft<N, -1, 0>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
+    wg_fft<N, -1, 0, 0, BBT_PFB_TW_POW>(v, lds + slot * G::LDS_ELEMS, tau, 0, tw0, tw1);
     if (active) {
         float2* dst = out + ((i * N + tau) * S + 2 * sp);
 #pragma unroll
@@ -1664,7 +1690,7 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
 #pragma unroll
         for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
     }
-    wg_fft_tail<4096, -1, 0>(v, lds, tau, 0, tw1);
+    wg_fft_tail<4096, -1, 0, 0, BBT_PFB_TW_POW>(v, lds, tau, 0, tw1);
     const int f = tau & 15, g = tau >> 4;
     const int q = f / P, c = f - q * P;
     if constexpr (SINGLE && SPLIT) {

@@ -212,6 +212,53 @@ __device__ __forceinline__ void fft_load_tw1(cf (&w)[15], const cf* __restrict__
 #pragma unroll
     for (int c = 1; c < 16; ++c) w[c - 1] = (R2 > 1) ? tw1[c * R2 + tau % R2] : make_float2(1.f, 0.f);
 }
+// The same tables read ONCE per thread: index c - 1 holds the c-th power of the table's c = 1
+// entry (W^{tau c} = (W^tau)^c), formed by products at most four roundings deep.  Fourteen
+// loads fewer per stage for kernels that wait for their loads rather than for the VALU.
+__device__ __forceinline__ void fft_twiddle_powers(cf (&w)[15]) {
+#pragma unroll
+    for (int c = 2; c < 16; ++c) w[c - 1] = cmul(w[(c + 1) / 2 - 1], w[c / 2 - 1]);
+}
+template <int N>
+__device__ __forceinline__ void fft_load_tw0_pow(cf (&w)[15], const cf* __restrict__ tw0, int tau) {
+    w[0] = tw0[FftGeo<N>::T + tau];
+    fft_twiddle_powers(w);
+}
+template <int N>
+__device__ __forceinline__ void fft_load_tw1_pow(cf (&w)[15], const cf* __restrict__ tw1, int tau) {
+    constexpr int R2 = FftGeo<N>::R2;
+    w[0] = (R2 > 1) ? tw1[R2 + tau % R2] : make_float2(1.f, 0.f);
+    fft_twiddle_powers(w);
+}
+// Four loads (c = 1, 2, 4, 8) and eleven products at most three roundings deep: most of the
+// saving at about half the rounding of the one-load form (POW == 2).
+__device__ __forceinline__ void fft_twiddle_powers4(cf (&w)[15]) {
+    w[2] = cmul(w[1], w[0]);                       // 3 = 2 + 1
+    w[4] = cmul(w[3], w[0]);                       // 5 = 4 + 1
+    w[5] = cmul(w[3], w[1]);                       // 6 = 4 + 2
+    w[6] = cmul(w[3], w[2]);                       // 7 = 4 + 3
+#pragma unroll
+    for (int c = 9; c < 16; ++c) w[c - 1] = cmul(w[7], w[c - 9]);      // 8 + (1 .. 7)
+}
+template <int N>
+__device__ __forceinline__ void fft_load_tw0_pow4(cf (&w)[15], const cf* __restrict__ tw0, int tau) {
+    constexpr int T = FftGeo<N>::T;
+    w[0] = tw0[T + tau];
+    w[1] = tw0[2 * T + tau];
+    w[3] = tw0[4 * T + tau];
+    w[7] = tw0[8 * T + tau];
+    fft_twiddle_powers4(w);
+}
+template <int N>
+__device__ __forceinline__ void fft_load_tw1_pow4(cf (&w)[15], const cf* __restrict__ tw1, int tau) {
+    constexpr int R2 = FftGeo<N>::R2;
+    const int b1 = tau % R2;
+    w[0] = tw1[R2 + b1];
+    w[1] = tw1[2 * R2 + b1];
+    w[3] = tw1[4 * R2 + b1];
+    w[7] = tw1[8 * R2 + b1];
+    fft_twiddle_powers4(w);
+}
 template <int SIGN>
 __device__ __forceinline__ void fft_butterfly_twiddle(c2 (&v)[16], const cf (&w)[15]) {
     radix16<SIGN>(v);
@@ -308,13 +355,15 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
 // sequence c0 = tau2 & 15 -- for the full transform that is element
 // tau2 + T * register (k = c0 + 16 k').  The fused channelizer and the PFB
 // enter here with their own stage 0.
-template <int N, int SIGN, int COLMODE, int IMOFF = 0>
+template <int N, int SIGN, int COLMODE, int IMOFF = 0, int POW = 0>
 __device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                             const cf* __restrict__ tw1) {
     fft_exchange0<N, COLMODE, IMOFF>(v, lds, tau, f);
     if constexpr (FftGeo<N>::R2 > 1) {
         cf w1[15];
-        fft_load_tw1<N>(w1, tw1, tau);
+        if constexpr (POW == 1) fft_load_tw1_pow<N>(w1, tw1, tau);
+        else if constexpr (POW == 2) fft_load_tw1_pow4<N>(w1, tw1, tau);
+        else fft_load_tw1<N>(w1, tw1, tau);
         fft_butterfly_twiddle<SIGN>(v, w1);
     } else {
         radix16<SIGN>(v);
@@ -322,13 +371,15 @@ __device__ __forceinline__ void wg_fft_tail(c2 (&v)[16], v2* __restrict__ lds, i
     fft_exchange1_stage2<N, SIGN, COLMODE, IMOFF>(v, lds, tau, f);
 }
 
-template <int N, int SIGN, int COLMODE, int IMOFF = 0>
+template <int N, int SIGN, int COLMODE, int IMOFF = 0, int POW = 0>
 __device__ __forceinline__ void wg_fft(c2 (&v)[16], v2* __restrict__ lds, int tau, int f,
                                        const cf* __restrict__ tw0, const cf* __restrict__ tw1) {
     cf w0[15];
-    fft_load_tw0<N>(w0, tw0, tau);
+    if constexpr (POW == 1) fft_load_tw0_pow<N>(w0, tw0, tau);
+    else if constexpr (POW == 2) fft_load_tw0_pow4<N>(w0, tw0, tau);
+    else fft_load_tw0<N>(w0, tw0, tau);
     fft_butterfly_twiddle<SIGN>(v, w0);
-    wg_fft_tail<N, SIGN, COLMODE, IMOFF>(v, lds, tau, f, tw1);
+    wg_fft_tail<N, SIGN, COLMODE, IMOFF, POW>(v, lds, tau, f, tw1);
 }
 
 // ---------------------------------------------------------------------------
