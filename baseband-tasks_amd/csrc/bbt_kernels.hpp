@@ -40,6 +40,9 @@
 //   one-kernel    inverse filter bank 51.0 -> 51.9 G, config 5 8.44 -> 8.62 G (1 and 2 alike): 2
 //   filter bank   config 3 136.5 -> 138.4-140.0 (1) / 139.0 (2) G: 2
 //   column passes 48.8 -> 48.6 G and Channelize (k_fft_rows) 193.8 -> 194.0 G: no gain, 0
+#ifndef BBT_SHORT_TW_POW
+#define BBT_SHORT_TW_POW 1            // k_fft_short (Channelize with 32 .. 128 channels): the same
+#endif
 #ifndef BBT_SMALL_TW_POW
 #define BBT_SMALL_TW_POW 2
 #endif
@@ -297,8 +300,22 @@ __global__ __launch_bounds__(256) void k_fft_short(const float2* __restrict__ in
         }
     } else {
         constexpr int NU = 16 / R;
+#if BBT_SHORT_TW_POW
+        {   // W_N^{tau c}, c < 16, from four loads and products (fft_twiddle_powers4)
+            cf w[15];
+            const int step = tau * (4096 / N);
+            w[0] = wroot[step];
+            w[1] = wroot[2 * step];
+            w[3] = wroot[4 * step];
+            w[7] = wroot[8 * step];
+            fft_twiddle_powers4(w);
+#pragma unroll
+            for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], w[c - 1]);
+        }
+#else
 #pragma unroll
         for (int c = 1; c < 16; ++c) v[c] = twmul<SIGN>(v[c], wroot[(tau * c) * (4096 / N)]);
+#endif
         v2* my = lds + slot * 16 * PITCH;
         c2 t[NU][R];
 #pragma unroll
@@ -1385,11 +1402,25 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         if constexpr (L > 1) {
             // (unsigned index: scalar base + 32-bit lane offset, no 64-bit address per load;
             // four loads in flight at a time instead of fifteen)
+#if BBT_ROWPASS_TW_POW
+            {   // W_NCH^{c a}, a < 16, from four loads (a = 1, 2, 4, 8) and products (fft_twiddle_powers4)
+                cf w[15];
+                const unsigned step = (unsigned)c * (unsigned)(4096 / NCH);
+                w[0] = wroot[step];
+                w[1] = wroot[2 * step];
+                w[3] = wroot[4 * step];
+                w[7] = wroot[8 * step];
+                fft_twiddle_powers4(w);
+#pragma unroll
+                for (int a = 1; a < 16; ++a) v[a] = twmul<-1>(v[a], w[a - 1]);
+            }
+#else
 #pragma unroll
             for (int a = 1; a < 16; ++a) {
                 v[a] = twmul<-1>(v[a], wroot[(unsigned)(c * a) * (unsigned)(4096 / NCH)]);
                 if ((a & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             // DIF over the lane digit c: masks L/2, ..., 2, 1 -- within a quad by DPP
             // quad_perm moves, across quads (L = 8) by ds_swizzle; no address registers
             if constexpr (L >= 8) lane_radix2_stage<4, L>(v, c, wroot);
