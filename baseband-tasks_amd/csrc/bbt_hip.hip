@@ -629,6 +629,10 @@ struct bbt_osm_plan {
     // W_N^{k1 tau} [N1][N2 / 16]
     cf* tw4row = nullptr;
     cf* tw4base = nullptr;
+    // three-level plans with the fused channelizer: the outer four-step factors of the row pass,
+    // tw4o [outer][n2 / 16] = W_N^{tau k1o}, tw4u [outer][n1][16] = W_{16 n1}^{k1 j} W_65536^{k1o j}
+    cf* tw4o = nullptr;
+    cf* tw4u = nullptr;
     // the same twiddles applied by the 256-point column passes instead (col_twiddles):
     // twa [16][n2] = W_N^{tau n2}, twg [4][n2] = W_N^{16 n2 2^i}; BBT_OSM_TW_COL=0/1
     bool tw_col = false;
@@ -697,7 +701,7 @@ static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, 
                        dim3(N2 / 16), (size_t)lds_pad,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
                        p->wroot, p->wroot + 4096, ch, p->outer, y0, p->tw4row, p->tw4base,
-                       p->tw_col ? (NCH ? 1 : 3) : 0);
+                       p->tw_col ? (NCH ? 1 : 3) : 0, p->tw4o, p->tw4u);
 }
 
 // (row length, channels) -> instantiation; nch == 0 is the plain row pass.
@@ -1487,20 +1491,36 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if (p->n1 == 4096 && get_tables(4096, &p->tab1)) return bail(1);
         if (get_wroot(&p->wroot)) return bail(1);
         static const bool tw4_tables = [] { const char* e = getenv("BBT_OSM_TW4_TABLES"); return !(e && atoi(e) == 0); }();
-        if (tw4_tables && p->outer == 1 && (p->n1 == 16 || p->n1 == 256)) {
+        if (tw4_tables && (p->n1 == 16 || p->n1 == 256) && (p->outer == 1 || p->outer == 256)) {
+            // (three-level plans: these are the twiddles of the inner transform of n1 * n2 points)
             const int t = p->n2 / 16;
+            const long long inner = (long long)p->n1 * p->n2;
             std::vector<cf> row((size_t)p->n1 * 16), base((size_t)p->n1 * t);
             for (int k1 = 0; k1 < p->n1; ++k1) {
                 for (int j = 0; j < 16; ++j) row[(size_t)k1 * 16 + j] = unit_root((long long)k1 * j, 16ll * p->n1);
                 for (int tau = 0; tau < t; ++tau)
-                    base[(size_t)k1 * t + tau] = unit_root((long long)k1 * tau, n_fft);
+                    base[(size_t)k1 * t + tau] = unit_root((long long)k1 * tau, inner);
             }
             if (upload(&p->tw4row, row) || upload(&p->tw4base, base)) return bail(1);
+            if (p->outer > 1) {
+                std::vector<cf> o((size_t)p->outer * t), uu((size_t)p->outer * p->n1 * 16);
+                for (int k1o = 0; k1o < p->outer; ++k1o) {
+                    for (int tau = 0; tau < t; ++tau) o[(size_t)k1o * t + tau] = unit_root((long long)k1o * tau, n_fft);
+                    for (int k1 = 0; k1 < p->n1; ++k1)
+                        for (int j = 0; j < 16; ++j) {
+                            // W_{16 n1}^{k1 j} W_65536^{k1o j} as one angle over 65536 * 16 n1 / gcd ...: in double
+                            const double a = -2.0 * M_PI * ((double)((long long)k1 * j % (16ll * p->n1)) / (16.0 * p->n1) +
+                                                            (double)((long long)k1o * j % 65536) / 65536.0);
+                            uu[((size_t)k1o * p->n1 + k1) * 16 + j] = make_float2((float)cos(a), (float)sin(a));
+                        }
+                }
+                if (upload(&p->tw4o, o) || upload(&p->tw4u, uu)) return bail(1);
+            }
             // twiddles in the column passes: only with 256-point columns, and not with the
             // experiment kernel that fuses two column passes (BBT_OSM_CA)
             static const bool tw_col = [] { const char* e = getenv("BBT_OSM_TW_COL"); return e ? atoi(e) != 0 : true; }();
             static const bool ca = [] { const char* e = getenv("BBT_OSM_CA"); return e && atoi(e) == 1; }();
-            if (tw_col && !ca && p->n1 == 256) {
+            if (tw_col && !ca && p->n1 == 256 && p->outer == 1) {
                 std::vector<cf> a((size_t)16 * p->n2), g((size_t)4 * p->n2);
                 for (int n2 = 0; n2 < p->n2; ++n2) {
                     for (int i = 0; i < 4; ++i) g[(size_t)i * p->n2 + n2] = unit_root((16ll << i) * n2, n_fft);
@@ -1635,6 +1655,8 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     if (p->resp_index) hipFree(p->resp_index);
     if (p->tw4row) hipFree(p->tw4row);
     if (p->tw4base) hipFree(p->tw4base);
+    if (p->tw4o) hipFree(p->tw4o);
+    if (p->tw4u) hipFree(p->tw4u);
     if (p->twa) hipFree(p->twa);
     if (p->twg) hipFree(p->twg);
     if (p->tlo) hipFree(p->tlo);

@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
     const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
     OsmChunk ch, int outer, int y0, const cf* __restrict__ tw4row, const cf* __restrict__ tw4base,
-    int tw_in_col) {
+    int tw_in_col, const cf* __restrict__ tw4o, const cf* __restrict__ tw4u) {
     // Three-level transforms (N > 2^20) run this pass once per row k1o of the
     // outer 256-point level: blockIdx.y = (block * npair + pair) * outer + k1o;
     // the full frequency index is k = k1o + outer * (k1 + N1 * k2).  outer == 1
@@ -1320,15 +1320,26 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         // W_N^{(N2 a + n2) k1o} has a factor that depends on n2; it must act
         // before the channel FFT, so it is applied here (its a-dependent factor
         // stays in k_osm_mid16).  W_N^{(tau + T j) k1o} = W_N^{tau k1o} W_65536^{j k1o}.
-        float s, c;
-        sincospif(-2.0f * (float)(tau * k1o) / ((float)outer * (float)N1 * (float)N2), &s, &c);
-        const cf bb = cmul(base, make_float2(c, s));
+        if (tw4o) {
+            // from tables (three-level plans, bbt_osm_plan_create): tw4o [outer][T] = W_N^{tau k1o};
+            // tw4u [outer][N1][16] = W_{16 N1}^{k1 j} W_65536^{k1o j}, the same for the whole
+            // workgroup -- where a sincospif, forty-eight scalar-valued table loads and thirty-two
+            // complex products per thread were
+            const cf bb = cmul(base, tw4o[k1o * T + tau]);
+            const cf* uu = tw4u + ((long long)k1o * N1 + k1) * 16;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int x = k1o * j;                          // < 4096
-            const cf wo = cmul(wroot[(x >> 8) * 16], wfine[x & 255]);     // W_65536^x
-            const cf wi = wrow(j);
-            v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
+            for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(bb, uu[j]));
+        } else {
+            float s, c;
+            sincospif(-2.0f * (float)(tau * k1o) / ((float)outer * (float)N1 * (float)N2), &s, &c);
+            const cf bb = cmul(base, make_float2(c, s));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int x = k1o * j;                          // < 4096
+                const cf wo = cmul(wroot[(x >> 8) * 16], wfine[x & 255]);     // W_65536^x
+                const cf wi = wrow(j);
+                v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
+            }
         }
     } else if (tw_in_col & 2) {
     } else if (tw4 && !(BBT_DBG & 1)) {
