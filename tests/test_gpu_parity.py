@@ -2489,7 +2489,7 @@ assert len(maps) == 1, maps
 print("one runtime:", maps[0])
 ''' % root
     for order in ('lib-first', 'torch-first'):
-        done = subprocess.run([sys.executable, '-c', script, order], capture_output=True, text=True, timeout=300)
+        done = subprocess.run([sys.executable, '-c', script, order], capture_output=True, text=True, timeout=900)
         assert done.returncode == 0 and 'one runtime:' in done.stdout, (order, done.stdout[-500:], done.stderr[-1500:])
 
 
