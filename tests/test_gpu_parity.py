@@ -2576,7 +2576,7 @@ def test_bench_two_ranks_share_this_gpu():
     env.pop('WORLD_SIZE', None)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
                         '--warmup', '1', '--blocks', '24', '--no-cpu'], env=env, capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
@@ -2625,7 +2625,7 @@ def test_plain_c_program_on_the_abi():
     overlap-save delay filter over two blocks and a channelizer -- runs on the GPU."""
     import subprocess
     from test_cabi import build_c_example
-    r = subprocess.run([build_c_example()], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([build_c_example()], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'C ABI example OK' in r.stdout and 'expected error' in r.stdout
 
