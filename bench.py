@@ -129,12 +129,12 @@ def measure_traffic(args):
                                     env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                     start_new_session=True)
             try:
-                _, err = proc.communicate(timeout=100)
+                _, err = proc.communicate(timeout=180)
             except subprocess.TimeoutExpired:
                 import signal
                 os.killpg(proc.pid, signal.SIGKILL)
                 proc.wait()
-                return None, f'rocprofv3 --pmc {counter} did not finish within 100 s'
+                return None, f'rocprofv3 --pmc {counter} did not finish within 180 s'
             db = os.path.join(out, 'run_results.db')
             if proc.returncode or not os.path.exists(db):
                 return None, f'rocprofv3 --pmc {counter} failed (rc {proc.returncode}): ' + err.decode()[-200:]
