@@ -21,7 +21,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 136
+#define BBT_VERSION 140
 
 // ---------------------------------------------------------------------------
 // errors
@@ -125,15 +125,11 @@ static bool factor_7smooth(int64_t n, GenGeo* g) {
     // ones are small Cooley-Tukey transforms on registers, fft_generic.hpp), as few as possible --
     // every stage is a round trip of the whole tile through LDS with two barriers -- and among
     // the shortest lists the one with the smallest largest radix (registers).
-    // BBT_GEN_SMALL_RADICES=1: primes and 4, 8 only (round 2's rule).
     if (n < 1 || n > BBT_GEN_MAX_LEN) return false;
-    static const bool small_only = [] { const char* e = getenv("BBT_GEN_SMALL_RADICES"); return e && atoi(e) == 1; }();
     static const int all[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
-    static const int few[] = {8, 7, 5, 4, 3, 2};
-    static const int max_radix = [] { const char* e = getenv("BBT_GEN_MAX_RADIX"); return e ? atoi(e) : BBT_GEN_MAXR; }();
-    const int* radices = small_only ? few : all;
-    int nrad = small_only ? 6 : 13;
-    while (nrad > 1 && radices[0] > max_radix) {      // (lists are in descending order)
+    const int* radices = all;
+    int nrad = 13;
+    while (nrad > 1 && radices[0] > BBT_GEN_MAXR) {   // (the list is in descending order)
         ++radices;
         --nrad;
     }
@@ -175,11 +171,10 @@ static bool is_7smooth(int64_t n) {
         while (n % r == 0) n /= r;
     return n == 1;
 }
-// N = N1 * N2 with N1 <= N2 <= BBT_GEN_MAX_LEN: the largest N1 up to BBT_GEN_SPLIT_N1 (default
-// 512: the column passes then hold 16 columns of N1 points in their LDS tile, i.e. move 256-byte
-// runs), else as balanced as possible.
+// N = N1 * N2 with N1 <= N2 <= BBT_GEN_MAX_LEN: the largest N1 up to 512 (the column passes
+// then hold 8 columns of N1 points in their LDS tile: 128-byte runs), else as balanced as possible.
 static bool split_7smooth(int64_t n, int* n1, int* n2) {
-    static const int64_t prefer = [] { const char* e = getenv("BBT_GEN_SPLIT_N1"); return (int64_t)(e ? atoi(e) : 512); }();
+    const int64_t prefer = 512;
     int64_t best = 0, wide = 0;
     for (int64_t d = 1; d * d <= n; ++d)
         if (n % d == 0 && n / d <= BBT_GEN_MAX_LEN) {
@@ -548,6 +543,13 @@ int bbt_event_create(bbt_event* ev) {
     *ev = (bbt_event)e;
     return 0;
 }
+int bbt_event_create_ordering(bbt_event* ev) {
+    ARG_TRY(ev, "bbt_event_create_ordering: null argument");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
+    *ev = (bbt_event)e;
+    return 0;
+}
 int bbt_event_destroy(bbt_event ev) {
     if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev));
     return 0;
@@ -585,6 +587,12 @@ struct bbt_fir_plan {
 static constexpr int BBT_FIR_R = 8;
 
 #define BBT_MAX_LANES 8
+// Events that only order streams of this device among each other (fork / join of the lanes, end
+// of a call) and the per-pass timing events: no system-scope fence.  A default HIP event writes
+// the caches back and invalidates them when it is recorded -- at every call boundary that emptied
+// the Infinity Cache under the work buffers and cost both lanes 0.2-0.6 ms (round 4, measured:
+// the lanes stood still after the last kernel of a call even with no cross-stream wait queued).
+#define BBT_EV_ORDER (hipEventDisableTiming | hipEventDisableSystemFence)
 struct bbt_osm_plan {
     // One call at a time per plan: the lanes' work buffers, the seam buffer,
     // the fork/join events and the timing vectors belong to the running call.
@@ -612,17 +620,19 @@ struct bbt_osm_plan {
     hipEvent_t ev_fork = nullptr, ev_join[BBT_MAX_LANES] = {};
     hipEvent_t ev_done = nullptr;   // end of the previous execute call (on whatever stream it ran)
     bool ev_done_set = false;
-    // Stage schedule (two-level power-of-two plans): instead of whole chunks
-    // alternating between lanes, each of the three passes has its own stream and
-    // chunk c goes through them on work buffer c % lanes -- first column pass of
-    // chunk c + 1, row pass of chunk c and last column pass of chunk c - 1 are in
-    // flight together, whatever the phase the lanes would have drifted into, and
-    // a pass never waits at a kernel boundary of its own chunk.  Dependencies
-    // between the streams are events per work buffer: ev_pass[k][w] = pass k has
-    // finished with buffer w.
-    bool stages = false;
-    hipStream_t stage_stream[3] = {};
-    hipEvent_t ev_pass[3][BBT_MAX_LANES] = {};
+    // Deferred join (bbt_osm_plan_defer): a call that was given a completion event does not order
+    // the caller's stream after its lanes.  The lanes then run on into the next call -- no drain
+    // at the call boundary -- and what has to come after them (the seam pass of the fused
+    // channelizer, the completion event) is queued on `tail_stream`.  Chunks keep alternating
+    // between the lanes across calls (`lane_cursor`); the seam buffer has two turns so that the
+    // seam pass of call i may still read its slots while the lanes of call i + 1 fill the others.
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t defer_ev = nullptr;          // handed in for the NEXT execute call only
+    bool last_forked_deferred = false;      // the previous call left its lanes unjoined
+    int lane_cursor = 0;
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};   // seam pass of the last deferred call on turn i
+    bool ev_tail_set[2] = {false, false};
+    int seam_turn = 0;
     FftTables tab2;  // for N2
     FftTables tab1;  // for N1 == 256
     // four-step twiddles of two-level plans as tables (owned): W_{16 N1}^{k1 j} [N1][16] and
@@ -648,33 +658,19 @@ struct bbt_osm_plan {
     cf* tlo = nullptr;          // W_N^i, i < 4096        (owned)
     cf* thi = nullptr;          // W_N^{4096 j}           (owned)
     int gen_ct = 1;             // columns per tile of the column passes
-    // bbt_osm_execute_prefiltered: a direct FIR in front of every block, into
-    // per-lane staging buffers (chunk x N x S complex64), allocated on first use
-    const bbt_fir_plan* pre = nullptr;      // set for the duration of such a call
-    float2* lane_stage[BBT_MAX_LANES] = {};
-    size_t lane_stage_bytes = 0;
     // pair-planar hand-over (bbt_osm_plan_set_layout; OsmChunk::in_plane / out_plane)
     long long in_plane = 0, out_plane = 0;
-    // bbt_osm_execute_dechan_flat: the blocks of a chunk are first dechannelized (inverse
-    // transform over dechan_nch channels of dechan_s streams) into the lane's staging buffer,
-    // transposed (k_dechan_staged), and the one-kernel overlap-save step reads them from there
-    int dechan_nch = 0, dechan_s = 0;
-    FftTables dechan_tab;
-    int stage_lane = 0;                     // lane of the chunk being enqueued
     // fused channelizer
-    float2* seam = nullptr;     // [blocks][2][npair][n_chan] float4
-    size_t seam_bytes = 0;
+    float2* seam = nullptr;     // [blocks][2][npair][n_chan] float4 (the turn in use)
+    float2* seam_buf[2] = {nullptr, nullptr};
+    size_t seam_bytes[2] = {0, 0};
 
     // timing
     bool timing = false;
     bool timing_isolated = false;   // mode 2: single lane, passes do not overlap
     std::vector<hipEvent_t> ev;  // 4 per chunk launch: t0, tA, tB, tC
     std::vector<hipEvent_t> ev_free;   // recycled events
-    // stage schedule: (start, stop) around the launch of one pass on its stream, for
-    // every timing_stride-th chunk (a sample: events cost queue slots of their own)
-    struct PassSample { int pass; int nblk; hipEvent_t a, b; };
-    std::vector<PassSample> ev_pass_samples;
-    int timing_stride = 4;
+    int timing_stride = 4;          // events on every timing_stride-th chunk of a lane
     int64_t pass_launches[3] = {0, 0, 0};
     int64_t pass_blocks[3] = {0, 0, 0};      // blocks the timed launches of each pass covered
     std::vector<int> ev_nblk;                // lanes schedule: blocks of each timed chunk launch
@@ -685,22 +681,16 @@ struct bbt_osm_plan {
 template <int N2, int NCH>
 static void launch_rowpass_t(bbt_osm_plan* p, float2* work, const OsmChunk& ch, hipStream_t st,
                              int y0 = 0, int ny = -1) {
-    // BBT_ROWPASS_REMAP=0: the older (rows, blocks * pairs) grid
-    static const bool remap = [] { const char* e = getenv("BBT_ROWPASS_REMAP"); return !(e && atoi(e) == 0); }();
-    const bool flat = remap && p->outer == 1 && ch.nblk * p->npair > 1 &&
+    // two-level plans: a flat grid, the workgroups that share a response row on one XCD (k_osm_rowpass)
+    const bool flat = p->outer == 1 && ch.nblk * p->npair > 1 &&
                       (long long)p->n1 * ch.nblk * p->npair < (1ll << 31);
     // (three-level plans may launch a range [y0, y0 + ny) of the outer rows)
     const int rows = ny >= 0 ? ny : ch.nblk * p->npair * p->outer;
-    // BBT_ROWPASS_LDS_PAD: bytes of dynamic LDS asked for on top of the kernel's own (nothing uses
-    // them): fewer row-pass workgroups per CU, i.e. register room for the other lane's column
-    // passes on the same SIMDs (experiment switch)
-    static const int lds_pad = [] { const char* e = getenv("BBT_ROWPASS_LDS_PAD"); return e ? atoi(e) : 0; }();
-    if (lds_pad && ensure_dyn_lds((const void*)k_osm_rowpass<N2, NCH>, (size_t)lds_pad)) return;
     hipLaunchKernelGGL((k_osm_rowpass<N2, NCH>),
                        flat ? dim3(p->n1 * ch.nblk * p->npair, 1) : dim3(p->n1, rows),
-                       dim3(N2 / 16), (size_t)lds_pad,
+                       dim3(N2 / 16), 0,
                        st, work, p->n1, p->resp, p->resp_index, p->npair, p->tab2.tw0, p->tab2.tw1,
-                       p->wroot, p->wroot + 4096, ch, p->outer, y0, p->tw4row, p->tw4base,
+                       p->wroot, ch, p->outer, y0, p->tw4row, p->tw4base,
                        p->tw_col ? (NCH ? 1 : 3) : 0, p->tw4o, p->tw4u);
 }
 
@@ -729,7 +719,7 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
 
 template <int N>
 static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
-                        hipStream_t st, bool trans = false) {
+                        hipStream_t st) {
     // lanes over groups of pairs when there are many (see k_osm_small); the
     // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
     constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
@@ -738,26 +728,6 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
     if (p->single) {
         hipLaunchKernelGGL((k_osm_small<N, 1, true>), dim3((nblk + 1) / 2), dim3(N / 16), lds1, st, in,
                            out, ch, 1, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
-        return 0;
-    }
-    if (trans) {
-        if (p->npair % PP) return fail("osm: staged blocks need a multiple of %d stream pairs", PP);
-        static const int variant = [] { const char* e = getenv("BBT_IPFB_VARIANT"); return e ? atoi(e) : 0; }();
-        if (N == 4096 && variant == 0) {
-            constexpr int MINW = N == 4096 ? 4 : 1;
-            if (ensure_dyn_lds((const void*)k_osm_small<N, PP, false, true, MINW>, lds1 * PP)) return 1;
-            hipLaunchKernelGGL((k_osm_small<N, PP, false, true, MINW>), dim3(nblk * (p->npair / PP)),
-                               dim3(PP * N / 16), lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index,
-                               p->tab2.tw0, p->tab2.tw1);
-        } else if (variant == 2) {
-            hipLaunchKernelGGL((k_osm_small<N, 1, false, true>), dim3(nblk * p->npair), dim3(N / 16), lds1, st,
-                               in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
-        } else {
-            if (ensure_dyn_lds((const void*)k_osm_small<N, PP, false, true>, lds1 * PP)) return 1;
-            hipLaunchKernelGGL((k_osm_small<N, PP, false, true>), dim3(nblk * (p->npair / PP)),
-                               dim3(PP * N / 16), lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index,
-                               p->tab2.tw0, p->tab2.tw1);
-        }
     } else if (p->npair % PP == 0) {
         if (ensure_dyn_lds((const void*)k_osm_small<N, PP>, lds1 * PP)) return 1;
         hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(nblk * (p->npair / PP)), dim3(PP * N / 16),
@@ -771,17 +741,6 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
 }
 
 static int osm_flush_timing(bbt_osm_plan* p) {
-    for (auto& s : p->ev_pass_samples) {
-        HIP_TRY(hipEventSynchronize(s.b));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
-        p->acc_ms[s.pass] += ms;
-        p->pass_launches[s.pass] += 1;
-        p->pass_blocks[s.pass] += s.nblk;
-        p->ev_free.push_back(s.a);
-        p->ev_free.push_back(s.b);
-    }
-    p->ev_pass_samples.clear();
     for (size_t i = 0; i + 3 < p->ev.size(); i += 4) {
         HIP_TRY(hipEventSynchronize(p->ev[i + 3]));
         for (int k = 0; k < 3; ++k) {
@@ -797,19 +756,6 @@ static int osm_flush_timing(bbt_osm_plan* p) {
     p->ev.clear();
     p->ev_nblk.clear();
     return 0;
-}
-
-#ifndef BBT_COL_TILE
-#define BBT_COL_TILE 16
-#endif
-static int g_col_tile = -1;
-static int col_tile() {
-    if (g_col_tile < 0) {
-        const char* env = getenv("BBT_COL_TILE");
-        g_col_tile = env ? atoi(env) : BBT_COL_TILE;
-        if (g_col_tile != 32) g_col_tile = 16;
-    }
-    return g_col_tile;
 }
 
 template <bool FIRST, bool SPEC>
@@ -838,26 +784,6 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
             return 0;
         }
     }
-    // Many streams: the last pass puts the lanes of a row over 8 (4) pairs, so
-    // every store instruction writes whole 128-byte lines of the output
-    // (config 4's share +8 %; the same on the first pass, i.e. for its reads,
-    // measured 8 % slower); 4 pairs: 8-stream dedispersion +11 %.
-    // BBT_COL_PP: bit 0 first pass, bit 1 last pass, bit 2 also groups of 4,
-    // bit 3 first pass with 64-lane rows (4 pairs x 16 columns, 1024 threads:
-    // 1 KiB runs of input and 256-byte runs of work; 16 streams +3 %, 8 streams
-    // -5 %, hence only from 8 pairs on).
-    static const int col_pp = [] { const char* e = getenv("BBT_COL_PP"); return e ? atoi(e) : 14; }();
-    // BBT_COL_WIDE (8 pairs or a multiple): 64-lane rows of 8 pairs x 8 columns -- whole 128-byte
-    // lines of the stream (1 KiB per row of the tile) AND 128-byte runs of the work buffer -- for
-    // the first pass (bit 0) and the last pass (bit 1; 18-20 spilled dwords at 1024 threads);
-    // bits 2 / 3: 32-lane rows (8 pairs x 4 columns, 512 threads, 64-byte runs of work).
-    // Measured on MI355X (config 4's share, 2^24 blocks, 8 pairs; round 3): 0: 2.77 / 2.78,
-    // 1: 2.85 / 2.86, 3: 2.89, 9: 2.89, 4: 2.76, 12: 2.81 G complete samples/s; two-level plans
-    // (2^20 blocks, 16 / 32 streams; tools/bench_streams.py): 0: 4.33 / 2.15, 1: 4.53-4.62 / 2.25,
-    // 3: 4.64 / 2.24, 9: 4.61 / 2.26, 4: 4.42 / 2.01, 12: 4.50 / 2.16 -> 9 whenever the pairs come
-    // in eights.
-    static const int col_wide_env = [] { const char* e = getenv("BBT_COL_WIDE"); return e ? atoi(e) : -1; }();
-    const int col_wide = col_wide_env >= 0 ? col_wide_env : 9;
     if (FIRST && ch.in_plane) {
         // pair-planar input: every pair is a two-stream array, the plain 16-column tiles read
         // 256-byte runs of it (the arrangements below are for interleaved rows)
@@ -865,132 +791,46 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
                            dim3(256), 16 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
         return 0;
     }
-    if (p->npair % 8 == 0 && (col_wide & (FIRST ? 1 : 2))) {
-        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 64, false, 8>, 64 * lds1)) return 1;
-        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 64, false, 8>),
-                           dim3(row_len / 8 * (p->npair / 8), ch.nblk), dim3(1024), 64 * lds1, st, in, out,
-                           work, ch, p->S, row_len, p->tab1.tw0, so);
-        return 0;
-    }
-    if (p->npair % 8 == 0 && (col_wide & (FIRST ? 4 : 8))) {
-        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 32, false, 8>, 32 * lds1)) return 1;
-        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32, false, 8>),
-                           dim3(row_len / 4 * (p->npair / 8), ch.nblk), dim3(512), 32 * lds1, st, in, out,
-                           work, ch, p->S, row_len, p->tab1.tw0, so);
-        return 0;
-    }
-    // bits 4 / 5: 4 pairs (or a multiple) as 32-lane rows of 4 pairs x 8 columns (512 threads):
-    // 512 contiguous bytes of an 8-stream row and 128-byte runs of work, first / last pass.
-    // Measured (config 5, 8 streams): 8.07 without, first 7.99, last 7.72, both 7.89 G -- off.
-    if (p->npair % 4 == 0 && (col_wide & (FIRST ? 16 : 32))) {
-        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 32, false, 4>, 32 * lds1)) return 1;
-        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32, false, 4>),
-                           dim3(row_len / 8 * (p->npair / 4), ch.nblk), dim3(512), 32 * lds1, st, in, out,
-                           work, ch, p->S, row_len, p->tab1.tw0, so);
+    // Many streams: the lanes of a row go over groups of stream pairs so that the stream side
+    // moves whole lines.  Measured on MI355X (DESIGN, "column-pass tiles"):
+    //   pairs in eights   first pass 8 pairs x 8 columns (64 lanes, 1024 threads: 1 KiB of a row of
+    //                     the stream and 128-byte runs of work), last pass 8 pairs x 4 columns (512
+    //                     threads, no spills): config 4's share +4.2 %, 16 / 32 streams +5-7 %
+    //   pairs in fours    first pass from 8 pairs on 4 pairs x 16 columns (1024 threads; 16 streams
+    //                     +3 %, 8 streams -5 %), last pass 4 pairs x 4 columns (8 streams +11 %)
+    if (p->npair % 8 == 0) {
+        constexpr int F = FIRST ? 64 : 32;
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, F, false, 8>, F * lds1)) return 1;
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, F, false, 8>),
+                           dim3(row_len / (F / 8) * (p->npair / 8), ch.nblk), dim3(F * 16), F * lds1, st,
+                           in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
         return 0;
     }
     if constexpr (FIRST) {
-        if ((col_pp & 8) && p->npair % 4 == 0 && p->npair >= 8) {
+        if (p->npair % 4 == 0 && p->npair >= 8) {
             if (ensure_dyn_lds((const void*)k_osm_col256<true, SPEC, 64, false, 4>, 64 * lds1)) return 1;
             hipLaunchKernelGGL((k_osm_col256<true, SPEC, 64, false, 4>),
                                dim3(row_len / 16 * (p->npair / 4), ch.nblk), dim3(1024), 64 * lds1, st, in,
                                out, work, ch, p->S, row_len, p->tab1.tw0, so);
             return 0;
         }
+    } else if (p->npair % 4 == 0) {
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 4>),
+                           dim3(row_len / 4 * (p->npair / 4), ch.nblk), dim3(256), 16 * lds1, st, in,
+                           out, work, ch, p->S, row_len, p->tab1.tw0, so);
+        return 0;
     }
-    if ((FIRST && (col_pp & 1)) || (!FIRST && (col_pp & 2))) {
-        if (p->npair % 8 == 0) {
-            hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 8>),
-                               dim3(row_len / 2 * (p->npair / 8), ch.nblk), dim3(256), 16 * lds1, st, in,
-                               out, work, ch, p->S, row_len, p->tab1.tw0, so);
-            return 0;
-        }
-        if (p->npair % 4 == 0 && (col_pp & 4)) {
-            hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16, false, 4>),
-                               dim3(row_len / 4 * (p->npair / 4), ch.nblk), dim3(256), 16 * lds1, st, in,
-                               out, work, ch, p->S, row_len, p->tab1.tw0, so);
-            return 0;
-        }
-    }
-    if (col_tile() == 32 && row_len % 32 == 0) {
-        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 32>, 32 * lds1)) return 1;
-        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 32>), dim3(row_len / 32 * p->npair, ch.nblk),
-                           dim3(512), 32 * lds1, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
-    } else {
-        // BBT_COL_LDS_PAD_FIRST / _LAST: as BBT_ROWPASS_LDS_PAD, for the plain 16-column tiles.  The
-        // first pass (116 VGPRs, 34 KiB of LDS) fits four workgroups per CU, 464 registers per lane
-        // of a SIMD: no row-pass wave (162) can join them.  Asking for 9 KiB more leaves three
-        // (348 + 162 = 510 of 512): measured on MI355X (headline, same-box pairs) +1.8 / +1.3 /
-        // +1.9 % with it on both column passes, +0.9 / +2.3 % on the first alone; final form (first
-        // pass, two streams): headline 48.79 / 49.47 / 49.51 -> 49.62 / 49.36 / 49.65 (within the
-        // noise), config 2 48.58 / 48.72 -> 49.88 / 49.75 (+2.4 %), config 5 (four pairs) -0.5 %,
-        // hence only for one pair; fewer row-pass workgroups per CU (20 KiB more: two) cost 6 %.
-        // The last pass is at three already (148 VGPRs).
-        static const int col_pad_env = [] {
-            const char* e = getenv(FIRST ? "BBT_COL_LDS_PAD_FIRST" : "BBT_COL_LDS_PAD_LAST");
-            return e ? atoi(e) : -1;
-        }();
-        const int col_pad = col_pad_env >= 0 ? col_pad_env : ((FIRST && p->npair == 1) ? 9216 : 0);
-        if (col_pad && ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 16>, 16 * lds1 + col_pad)) return 1;
-        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
-                           dim3(256), 16 * lds1 + col_pad, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
-    }
+    // Plain 16-column tiles.  The first pass (116 VGPRs, 34 KiB of LDS) fits four workgroups per
+    // CU, 464 registers per lane of a SIMD: no row-pass wave (162) of the other lane can join
+    // them.  Asking for 9 KiB more of (unused) LDS leaves three (348 + 162 = 510 of 512): config 2
+    // +2.4 %, headline +0.3 %, four pairs -0.5 % -- hence for one pair only.
+    const int col_pad = (FIRST && p->npair == 1) ? 9216 : 0;
+    if (col_pad && ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, 16>, 16 * lds1 + col_pad)) return 1;
+    hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, 16>), dim3(row_len / 16 * p->npair, ch.nblk),
+                       dim3(256), 16 * lds1 + col_pad, st, in, out, work, ch, p->S, row_len, p->tab1.tw0, so);
     return 0;
 }
 
-// 4096-point column pass (blocks longer than 2^20): first pass with the lanes
-// of a row over 4 neighbouring columns of one pair (64-byte runs of the work
-// buffer), last pass over 4 pairs of one column when there are that many
-// (64-byte runs of the output); BBT_COL4096_PP: bit 0 / bit 1 switch the first /
-// last pass to the other arrangement.
-template <bool FIRST, bool SPEC>
-static int launch_col4096(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
-                          const OsmChunk& ch, const SpecOut& so, hipStream_t st) {
-    constexpr size_t lds = FftGeo<4096>::LDS_ELEMS * sizeof(v2) * 4;
-    static const int flip = [] { const char* e = getenv("BBT_COL4096_PP"); return e ? atoi(e) : 0; }();
-    bool pairs = FIRST ? false : true;
-    if (flip & (FIRST ? 1 : 2)) pairs = !pairs;
-    if (pairs && p->npair % 4 == 0) {
-        if (ensure_dyn_lds((const void*)k_osm_col4096<FIRST, SPEC, 4>, lds)) return 1;
-        hipLaunchKernelGGL((k_osm_col4096<FIRST, SPEC, 4>), dim3(p->n2 * (p->npair / 4), ch.nblk),
-                           dim3(1024), lds, st, in, out, work, ch, p->S, p->n2, p->tab1.tw0,
-                           p->tab1.tw1, so);
-    } else {
-        if (ensure_dyn_lds((const void*)k_osm_col4096<FIRST, SPEC, 1>, lds)) return 1;
-        hipLaunchKernelGGL((k_osm_col4096<FIRST, SPEC, 1>), dim3(p->n2 / 4 * p->npair, ch.nblk),
-                           dim3(1024), lds, st, in, out, work, ch, p->S, p->n2, p->tab1.tw0,
-                           p->tab1.tw1, so);
-    }
-    return 0;
-}
-
-// Can the last column pass of one chunk and the first of the next share a launch
-// (k_osm_col256_ca)?  Two-level plans with 256-point columns whose two column passes both use
-// the plain 16-column tiles of one stream pair (launch_col256 picks other tiles for many pairs).
-static bool osm_ca_ok(const bbt_osm_plan* p, const SpecOut& so) {
-    // Measured on MI355X (headline, round 3): 46.4-46.9 Gsamples/s with it, 46.6-46.9 without --
-    // the lanes were already busy 94 % of the time -- so it is opt-in (BBT_OSM_CA=1).
-    static const bool on = [] { const char* e = getenv("BBT_OSM_CA"); return e && atoi(e) == 1; }();
-    return on && !p->generic && !p->single && !p->pre && p->outer == 1 && p->n1 == 256 && !so.det &&
-           p->npair % 4 != 0 && col_tile() == 16 && p->lanes > 1 && !p->in_plane;
-}
-static int launch_col256_ca(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
-                            const OsmChunk& chc, const OsmChunk& cha, const SpecOut& so, hipStream_t st) {
-    constexpr size_t lds = FftGeo<256>::LDS_ELEMS * sizeof(v2) * 16;
-    const int rows = std::max(chc.nblk, cha.nblk);
-    const dim3 grid(p->n2 / 16 * p->npair, rows);
-    if (so.n_chan)
-        hipLaunchKernelGGL((k_osm_col256_ca<true>), grid, dim3(256), lds, st, in, out, work, chc, cha, p->S,
-                           p->n2, p->tab1.tw0, so);
-    else
-        hipLaunchKernelGGL((k_osm_col256_ca<false>), grid, dim3(256), lds, st, in, out, work, chc, cha, p->S,
-                           p->n2, p->tab1.tw0, so);
-    return 0;
-}
-
-// One pass of a two-level power-of-two plan (n1 == 16 or 256, outer == 1) over a chunk:
-// 0 = first column pass (stream -> work), 1 = row pass (in place), 2 = last column pass
-// (work -> kept samples or spectra).
 static int osm_launch_pass(bbt_osm_plan* p, int pass, const float2* in, float2* out, const OsmChunk& ch,
                            const SpecOut& so, float2* work, hipStream_t st) {
     const int nch = so.n_chan;
@@ -1033,78 +873,26 @@ static int osm_launch_pass(bbt_osm_plan* p, int pass, const float2* in, float2* 
     return 0;
 }
 
-// Dechannelize the blocks of a chunk into a staging buffer, transposed (k_dechan_staged).
-template <int NCH>
-static int launch_dechan_staged(bbt_osm_plan* p, const float2* in, float2* stage, const OsmChunk& ch,
-                                hipStream_t st) {
-    constexpr int R = 8;
-    const size_t lds = (size_t)FftGeo<NCH>::LDS_ELEMS * R * sizeof(v2);
-    if (ensure_dyn_lds((const void*)k_dechan_staged<NCH, R>, lds)) return 1;
-    const int rows = (int)p->n, npp = p->dechan_s / 2;
-    const dim3 grid((unsigned)((rows + R - 1) / R * npp), ch.nblk);
-    hipLaunchKernelGGL((k_dechan_staged<NCH, R>), grid, dim3(R * NCH / 16), lds, st, in, stage, ch, rows,
-                       p->dechan_s, 1.0f / (float)NCH, p->dechan_tab.tw0, p->dechan_tab.tw1);
-    return 0;
-}
-
 static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch_given,
-                         const SpecOut& so, float2* work, hipStream_t st) {
+                         const SpecOut& so, float2* work, hipStream_t st, bool sample = true) {
     const int nch = so.n_chan;   // 0: plain overlap-save output
     OsmChunk ch_arg = ch_given;
     ch_arg.in_plane = p->in_plane;
     ch_arg.out_plane = p->out_plane;
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (p->timing) {
+    const bool timed = p->timing && sample;       // (events on this chunk's kernels)
+    if (timed) {
         for (int i = 0; i < 4; ++i) {
             if (!p->ev_free.empty()) {
                 e[i] = p->ev_free.back();
                 p->ev_free.pop_back();
             } else {
-                HIP_TRY(hipEventCreate(&e[i]));
+                HIP_TRY(hipEventCreateWithFlags(&e[i], hipEventDisableSystemFence));
             }
         }
         HIP_TRY(hipEventRecord(e[0], st));
     }
-    OsmChunk staged;
-    const OsmChunk* chp = &ch_arg;
-    if (p->pre) {
-        // filter every block of the chunk into this lane's staging buffer; the
-        // first column pass then reads block i at staging[i * N]
-        const bbt_fir_plan* f = p->pre;
-        constexpr int R = BBT_FIR_R;
-        float2* stage = p->lane_stage[p->stage_lane];
-        const long long tiles = (p->n + 256 * R - 1) / (256 * R);
-        const size_t lds = (size_t)R * f->pitch * sizeof(float4);
-        const dim3 grid((unsigned)(tiles * p->npair), ch_arg.nblk);
-        if (f->cplx)
-            hipLaunchKernelGGL((k_fir_blocks<R, true>), grid, dim3(256), lds, st, in, stage, ch_arg,
-                               (long long)p->n, f->n_tap, p->S, f->tre, f->tim, f->tap_pitch,
-                               f->n_chunks, f->pitch);
-        else
-            hipLaunchKernelGGL((k_fir_blocks<R, false>), grid, dim3(256), lds, st, in, stage, ch_arg,
-                               (long long)p->n, f->n_tap, p->S, f->tre, f->tim, f->tap_pitch,
-                               f->n_chunks, f->pitch);
-        staged = ch_arg;
-        for (int i = 0; i < ch_arg.nblk; ++i) staged.b[i].in_off = (long long)i * p->n;
-        chp = &staged;
-        in = stage;
-    }
-    bool trans = false;
-    if (p->dechan_nch) {
-        float2* stage = p->lane_stage[p->stage_lane];
-        int rc = 0;
-        switch (p->dechan_nch) {
-            case 256: rc = launch_dechan_staged<256>(p, in, stage, ch_arg, st); break;
-            case 512: rc = launch_dechan_staged<512>(p, in, stage, ch_arg, st); break;
-            case 1024: rc = launch_dechan_staged<1024>(p, in, stage, ch_arg, st); break;
-            case 2048: rc = launch_dechan_staged<2048>(p, in, stage, ch_arg, st); break;
-            default: return fail("osm: no staged dechannelizer for %d channels", p->dechan_nch);
-        }
-        if (rc) return rc;
-        in = stage;
-        trans = true;
-    }
-    const OsmChunk& ch = *chp;         // (block i of a prefiltered chunk reads staging[i * N])
+    const OsmChunk& ch = ch_arg;
     OsmChunk pairs_view;               // one stream: the work buffers hold pairs of blocks
     if (p->single) {
         pairs_view = ch;
@@ -1118,7 +906,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             if (ensure_dyn_lds((const void*)k_gen_osm_small, lds)) return 1;
             hipLaunchKernelGGL(k_gen_osm_small, dim3(ch.nblk * p->npair), dim3(gen_threads(p->n2)), lds,
                                st, in, out, ch, p->S, p->resp, p->resp_index, p->g2, p->wn2);
-            if (p->timing) {
+            if (timed) {
                 HIP_TRY(hipEventRecord(e[1], st));
                 HIP_TRY(hipEventRecord(e[2], st));
             }
@@ -1132,37 +920,29 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             const dim3 gcol(tiles * p->npair, ch.nblk), bcol(gen_threads(p->n1 * ct));
             hipLaunchKernelGGL((k_gen_col<true>), gcol, bcol, lds_c, st, in, out, work, ch, p->S, p->n2,
                                ct, p->g1, p->wn1);
-            if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+            if (timed) HIP_TRY(hipEventRecord(e[1], st));
             hipLaunchKernelGGL(k_gen_row, dim3(p->n1, ch.nblk * p->npair), dim3(gen_threads(p->n2)),
                                lds_r, st, work, p->n1, p->resp, p->resp_index, p->npair, p->g2, p->wn2,
                                p->tlo, p->thi);
-            if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+            if (timed) HIP_TRY(hipEventRecord(e[2], st));
             hipLaunchKernelGGL((k_gen_col<false>), gcol, bcol, lds_c, st, in, out, work, ch, p->S, p->n2,
                                ct, p->g1, p->wn1);
         }
     } else if (p->n1 == 1) {
         int rc = 0;
         switch (p->n2) {
-            case 256: rc = launch_small<256>(p, in, out, ch, st, trans); break;
-            case 512: rc = launch_small<512>(p, in, out, ch, st, trans); break;
-            case 1024: rc = launch_small<1024>(p, in, out, ch, st, trans); break;
-            case 2048: rc = launch_small<2048>(p, in, out, ch, st, trans); break;
-            case 4096: rc = launch_small<4096>(p, in, out, ch, st, trans); break;
+            case 256: rc = launch_small<256>(p, in, out, ch, st); break;
+            case 512: rc = launch_small<512>(p, in, out, ch, st); break;
+            case 1024: rc = launch_small<1024>(p, in, out, ch, st); break;
+            case 2048: rc = launch_small<2048>(p, in, out, ch, st); break;
+            case 4096: rc = launch_small<4096>(p, in, out, ch, st); break;
             default: return fail("osm: unsupported n_fft %lld", (long long)p->n);
         }
         if (rc) return rc;
-        if (p->timing) {
+        if (timed) {
             HIP_TRY(hipEventRecord(e[1], st));
             HIP_TRY(hipEventRecord(e[2], st));
         }
-    } else if (p->n1 == 4096) {
-        if (launch_col4096<true, false>(p, in, out, work, ch, so, st)) return 1;
-        if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
-        if (launch_rowpass(p, work, ch, nch, st)) return 1;
-        if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
-        if (nch ? launch_col4096<false, true>(p, in, out, work, ch, so, st)
-                : launch_col4096<false, false>(p, in, out, work, ch, so, st))
-            return 1;
     } else if (p->outer > 1) {
         // three levels: outer 256-point column pass over rows of M = 16 * n2, then
         // the two-level machinery in place on every outer row
@@ -1186,9 +966,9 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             const dim3 gmid(p->n2 / 256, ny);
             hipLaunchKernelGGL((k_osm_mid16<true>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                                p->wroot, 0, y0);
-            if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+            if (timed) HIP_TRY(hipEventRecord(e[1], st));
             if (launch_rowpass(p, work, chw, nch, st, y0, ny)) return 1;
-            if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+            if (timed) HIP_TRY(hipEventRecord(e[2], st));
             hipLaunchKernelGGL((k_osm_mid16<false>), gmid, dim3(256), 0, st, work, p->n2, (int)p->n,
                                p->wroot, nch ? 1 : 0, y0);
         }
@@ -1197,13 +977,13 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             return 1;
     } else {
         if (osm_launch_pass(p, 0, in, out, ch, so, work, st)) return 1;
-        if (p->timing) HIP_TRY(hipEventRecord(e[1], st));
+        if (timed) HIP_TRY(hipEventRecord(e[1], st));
         if (osm_launch_pass(p, 1, in, out, ch, so, work, st)) return 1;
-        if (p->timing) HIP_TRY(hipEventRecord(e[2], st));
+        if (timed) HIP_TRY(hipEventRecord(e[2], st));
         if (osm_launch_pass(p, 2, in, out, ch, so, work, st)) return 1;
     }
     HIP_TRY(hipGetLastError());
-    if (p->timing) {
+    if (timed) {
         HIP_TRY(hipEventRecord(e[3], st));
         for (int i = 0; i < 4; ++i) p->ev.push_back(e[i]);
         p->ev_nblk.push_back(ch_arg.nblk);
@@ -1216,157 +996,95 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
 // device: the work, staging and seam buffers belong to the running call, so a
 // call queued on another stream than the previous one first waits for that
 // call's last kernel.
+//
+// Deferred calls (bbt_osm_plan_defer) are the exception: a forking call that was
+// given a completion event leaves the caller's stream unordered with respect to
+// its lanes, and the next forking deferred call does not wait for it either --
+// the lanes are in-order queues, a lane's work buffer is only ever touched from
+// that lane, and everything else (the seam buffer) has two turns.  `fin` is the
+// stream on which such a call ends: whatever must follow the lanes goes there.
+// The completion event handed in by bbt_osm_plan_defer belongs to the NEXT execute call on the
+// plan, whatever becomes of that call: every entry point takes it first thing, and if the call
+// returns before anything was queued (an argument error, nothing to do) the event is recorded on
+// the caller's stream as it stands.
+struct DeferTake {
+    hipEvent_t ev = nullptr;
+    hipStream_t st;
+    DeferTake(bbt_osm_plan* p, hipStream_t stream) : st(stream) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lock(p->mu);
+        ev = p->defer_ev;
+        p->defer_ev = nullptr;
+    }
+    hipEvent_t hand_over() {
+        hipEvent_t e = ev;
+        ev = nullptr;
+        return e;
+    }
+    void give_back(bbt_osm_plan* p) {        // (for an entry point that ends in another one)
+        std::lock_guard<std::mutex> lock(p->mu);
+        p->defer_ev = hand_over();
+    }
+    ~DeferTake() {
+        if (ev) (void)hipEventRecord(ev, st);
+    }
+};
+
 struct PlanCall {
     bbt_osm_plan* p;
     hipStream_t st;
     std::lock_guard<std::mutex> lock;
-    PlanCall(bbt_osm_plan* plan, hipStream_t stream) : p(plan), st(stream), lock(plan->mu) {
-        if (p->ev_done_set) (void)hipStreamWaitEvent(st, p->ev_done, 0);
+    hipEvent_t defer;           // the caller's completion event, or null
+    bool fork;                  // chunks go to the lane streams
+    bool deferred;              // ... and `st` is not joined after them
+    hipStream_t fin;
+    PlanCall(bbt_osm_plan* plan, DeferTake& take, int64_t n_blocks)
+        : p(plan), st(take.st), lock(plan->mu), defer(take.hand_over()) {
+        const int64_t n_chunks = (n_blocks + p->chunk - 1) / p->chunk;
+        const bool lanes_ok = p->lanes > 1 && !(p->timing && p->timing_isolated) && n_chunks > 0;
+        deferred = defer && lanes_ok && p->tail_stream;
+        fork = lanes_ok && (n_chunks > 1 || deferred);
+        fin = deferred ? p->tail_stream : st;
+        // (two deferred forking calls in a row: nothing of the earlier one is touched outside
+        // the lanes' own order, see above)
+        if (p->ev_done_set && !(deferred && p->last_forked_deferred))
+            (void)hipStreamWaitEvent(st, p->ev_done, 0);
     }
     ~PlanCall() {
-        if (hipEventRecord(p->ev_done, st) == hipSuccess) p->ev_done_set = true;
+        if (defer) (void)hipEventRecord(defer, fin);
+        if (hipEventRecord(p->ev_done, fin) == hipSuccess) p->ev_done_set = true;
+        p->last_forked_deferred = deferred;
     }
 };
 
-// Run all chunks, alternating lanes; returns with `st` ordered after every lane.
+// Run all chunks, alternating lanes.  Returns with `call.st` ordered after every lane, or -- a
+// deferred call -- with `call.fin` (the plan's tail stream) ordered after them instead.
 template <class FillChunk>
 static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n_blocks,
-                       const SpecOut& so, hipStream_t st, FillChunk fill) {
-    const int64_t n_chunks = (n_blocks + p->chunk - 1) / p->chunk;
-    const bool fork = p->lanes > 1 && !(p->timing && p->timing_isolated) && n_chunks > 1;
-    if (fork && p->stages && !p->pre) {
-        // Stage schedule: chunk c on work buffer w = c % lanes; pass k of it on stage stream k,
-        // after pass k - 1 of the same chunk (first pass: after the last pass of the chunk that
-        // had the buffer before).
-        HIP_TRY(hipEventRecord(p->ev_fork, st));
-        for (int k = 0; k < 3; ++k) HIP_TRY(hipStreamWaitEvent(p->stage_stream[k], p->ev_fork, 0));
-        auto timing_event = [&](hipEvent_t* e) -> int {
-            if (!p->ev_free.empty()) {
-                *e = p->ev_free.back();
-                p->ev_free.pop_back();
-                return 0;
-            }
-            HIP_TRY(hipEventCreate(e));
-            return 0;
-        };
-        int64_t c = 0;
-        for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
-            OsmChunk ch = {};
-            ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
-            for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
-            const int w = (int)(c % p->lanes);
-            const bool sample = p->timing && c % p->timing_stride == 0;
-            for (int k = 0; k < 3; ++k) {
-                hipStream_t sk = p->stage_stream[k];
-                if (k > 0) HIP_TRY(hipStreamWaitEvent(sk, p->ev_pass[k - 1][w], 0));
-                else if (c >= p->lanes) HIP_TRY(hipStreamWaitEvent(sk, p->ev_pass[2][w], 0));
-                bbt_osm_plan::PassSample s = {k, ch.nblk, nullptr, nullptr};
-                if (sample) {
-                    if (timing_event(&s.a) || timing_event(&s.b)) return 1;
-                    HIP_TRY(hipEventRecord(s.a, sk));
-                }
-                if (osm_launch_pass(p, k, in, out, ch, so, p->lane_work[w], sk)) return 1;
-                if (sample) {
-                    HIP_TRY(hipEventRecord(s.b, sk));
-                    p->ev_pass_samples.push_back(s);
-                }
-                HIP_TRY(hipEventRecord(p->ev_pass[k][w], sk));
-            }
-            HIP_TRY(hipGetLastError());
-            if (p->ev_pass_samples.size() >= 16384 && osm_flush_timing(p)) return 1;
-        }
-        for (int k = 0; k < 3; ++k) {
-            HIP_TRY(hipEventRecord(p->ev_join[k], p->stage_stream[k]));
-            HIP_TRY(hipStreamWaitEvent(st, p->ev_join[k], 0));
-        }
-        return 0;
-    }
-    if (fork && osm_ca_ok(p, so)) {
-        // Lanes whose launches alternate between the row pass of a chunk and ONE column kernel that
-        // finishes that chunk and starts the lane's next one (k_osm_col256_ca).  Lane l > 0 starts
-        // once lane l - 1 has done its first column pass, so that the lanes are out of phase: a row
-        // pass runs beside a column kernel, not beside another row pass.
-        static const bool stagger = [] { const char* e = getenv("BBT_OSM_STAGGER"); return !(e && atoi(e) == 0); }();
-        HIP_TRY(hipEventRecord(p->ev_fork, st));
-        for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
-        std::vector<OsmChunk> pend(p->lanes);
-        std::vector<char> has(p->lanes, 0);
-        auto timing_event = [&](hipEvent_t* e) -> int {
-            if (!p->ev_free.empty()) {
-                *e = p->ev_free.back();
-                p->ev_free.pop_back();
-                return 0;
-            }
-            HIP_TRY(hipEventCreate(e));
-            return 0;
-        };
-        bool sample = false;           // events on every timing_stride-th chunk of a lane
-        auto timed = [&](int pass, int nblk, hipStream_t sl, auto&& launch) -> int {
-            bbt_osm_plan::PassSample s = {pass, nblk, nullptr, nullptr};
-            if (sample) {
-                if (timing_event(&s.a) || timing_event(&s.b)) return 1;
-                HIP_TRY(hipEventRecord(s.a, sl));
-            }
-            if (launch()) return 1;
-            if (sample) {
-                HIP_TRY(hipEventRecord(s.b, sl));
-                p->ev_pass_samples.push_back(s);
-            }
-            return 0;
-        };
-        int64_t c = 0;
-        for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
-            OsmChunk ch = {};
-            ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
-            for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
-            const int l = (int)(c % p->lanes);
-            sample = p->timing && (c / p->lanes) % p->timing_stride == 0;
-            hipStream_t sl = p->lane_stream[l];
-            float2* work = p->lane_work[l];
-            if (has[l]) {
-                if (timed(0, ch.nblk, sl, [&] { return launch_col256_ca(p, in, out, work, pend[l], ch, so, sl); }))
-                    return 1;
-            } else {
-                if (stagger && l > 0) HIP_TRY(hipStreamWaitEvent(sl, p->ev_join[l - 1], 0));
-                if (timed(0, ch.nblk, sl, [&] { return osm_launch_pass(p, 0, in, out, ch, so, work, sl); })) return 1;
-                if (stagger && l + 1 < p->lanes) HIP_TRY(hipEventRecord(p->ev_join[l], sl));
-            }
-            if (timed(1, ch.nblk, sl, [&] { return osm_launch_pass(p, 1, in, out, ch, so, work, sl); })) return 1;
-            pend[l] = ch;
-            has[l] = 1;
-            HIP_TRY(hipGetLastError());
-            if (p->ev_pass_samples.size() >= 16384 && osm_flush_timing(p)) return 1;
-        }
-        sample = p->timing;
-        for (int l = 0; l < p->lanes; ++l) {
-            hipStream_t sl = p->lane_stream[l];
-            if (has[l] &&
-                timed(2, pend[l].nblk, sl, [&] { return osm_launch_pass(p, 2, in, out, pend[l], so, p->lane_work[l], sl); }))
-                return 1;
-            HIP_TRY(hipEventRecord(p->ev_join[l], sl));
-            HIP_TRY(hipStreamWaitEvent(st, p->ev_join[l], 0));
-        }
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
+                       const SpecOut& so, const PlanCall& call, FillChunk fill) {
+    hipStream_t st = call.st;
+    const bool fork = call.fork;
     if (fork) {
         HIP_TRY(hipEventRecord(p->ev_fork, st));
         for (int l = 0; l < p->lanes; ++l) HIP_TRY(hipStreamWaitEvent(p->lane_stream[l], p->ev_fork, 0));
     }
+    // (lanes keep alternating across deferred calls; a joined call starts on lane 0 as ever)
+    const int l0 = call.deferred ? p->lane_cursor : 0;
     int64_t c = 0;
     for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
         OsmChunk ch = {};                  // (fields a caller's fill does not set stay 0)
         ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
         for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
-        const int l = fork ? (int)(c % p->lanes) : 0;
-        p->stage_lane = l;
-        if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : st))
+        const int l = fork ? (int)((l0 + c) % p->lanes) : 0;
+        const bool sample = !fork || (c / p->lanes) % p->timing_stride == 0;
+        if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : st, sample))
             return 1;
     }
     if (fork) {
+        if (call.deferred) p->lane_cursor = (int)((l0 + c) % p->lanes);
         for (int l = 0; l < p->lanes; ++l) {
             HIP_TRY(hipEventRecord(p->ev_join[l], p->lane_stream[l]));
-            HIP_TRY(hipStreamWaitEvent(st, p->ev_join[l], 0));
+            HIP_TRY(hipStreamWaitEvent(call.fin, p->ev_join[l], 0));
         }
     }
     return 0;
@@ -1418,7 +1136,7 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             "bbt_osm_plan_create: n_fft=%lld must be a power of two in [256, 2^24] or a product of "
             "2, 3, 5, 7 that is <= 8192 or splits into two such factors",
             (long long)n_fft);
-    const bool single = n_stream == 1 && fast && !(getenv("BBT_OSM_TWO_LEVEL") && n_fft > (1 << 20));
+    const bool single = n_stream == 1 && fast;
     ARG_TRY(single || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
             "bbt_osm_plan_create: n_stream=%d must be even and >= 2 (or 1 with a power-of-two block "
             "length)", n_stream);
@@ -1455,15 +1173,6 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         p->n1 = 16;
     } else if (n_fft <= (1 << 20)) {
         p->n1 = 256;
-    } else if (const char* env = getenv("BBT_OSM_TWO_LEVEL"); env && atoi(env)) {
-        // 4096 x N2 (N2 = 512 .. 4096): three passes instead of five, but a
-        // 4096-point column transform fills the LDS of a CU with four columns, so
-        // its runs of the stream and of the work buffer are 64 bytes and one
-        // workgroup per CU hides no latency: measured on MI355X (config 4's share,
-        // 16 streams) 1.9 / 1.6 / 2.2 ms per block for the three passes against
-        // 1.85 / 1.1 / 2.0 ms for the five of the three-level scheme (256-byte
-        // and longer runs) -- no gain, so it is not the default.
-        p->n1 = 4096;
     } else {
         p->outer = 256;          // three levels, 256 x 16 x N2
         p->n1 = 16;
@@ -1481,17 +1190,15 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             // columns per tile: a power of two (gen_stage), as many as fit the LDS tile up to 8
             // (128-byte runs of the stream and of the work buffer; measured: 8 columns 18.9, 16
             // columns 18.1, 4 columns 17.3 Gsamples/s for the 1 666 980-sample block)
-            static const int ct_cap = [] { const char* e = getenv("BBT_GEN_CT"); return e ? atoi(e) : 8; }();
+            const int ct_cap = 8;
             p->gen_ct = 1;
             while (p->gen_ct < ct_cap && 2 * p->gen_ct * p->n1 <= BBT_GEN_MAX_LEN) p->gen_ct *= 2;
         }
     } else {
         if (get_tables(p->n2, &p->tab2)) return bail(1);
         if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
-        if (p->n1 == 4096 && get_tables(4096, &p->tab1)) return bail(1);
         if (get_wroot(&p->wroot)) return bail(1);
-        static const bool tw4_tables = [] { const char* e = getenv("BBT_OSM_TW4_TABLES"); return !(e && atoi(e) == 0); }();
-        if (tw4_tables && (p->n1 == 16 || p->n1 == 256) && (p->outer == 1 || p->outer == 256)) {
+        if ((p->n1 == 16 || p->n1 == 256) && (p->outer == 1 || p->outer == 256)) {
             // (three-level plans: these are the twiddles of the inner transform of n1 * n2 points)
             const int t = p->n2 / 16;
             const long long inner = (long long)p->n1 * p->n2;
@@ -1516,11 +1223,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
                 }
                 if (upload(&p->tw4o, o) || upload(&p->tw4u, uu)) return bail(1);
             }
-            // twiddles in the column passes: only with 256-point columns, and not with the
-            // experiment kernel that fuses two column passes (BBT_OSM_CA)
-            static const bool tw_col = [] { const char* e = getenv("BBT_OSM_TW_COL"); return e ? atoi(e) != 0 : true; }();
-            static const bool ca = [] { const char* e = getenv("BBT_OSM_CA"); return e && atoi(e) == 1; }();
-            if (tw_col && !ca && p->n1 == 256 && p->outer == 1) {
+            // twiddles in the column passes: only with 256-point columns
+            if (p->n1 == 256 && p->outer == 1) {
                 std::vector<cf> a((size_t)16 * p->n2), g((size_t)4 * p->n2);
                 for (int n2 = 0; n2 < p->n2; ++n2) {
                     for (int i = 0; i < 4; ++i) g[(size_t)i * p->n2 + n2] = unit_root((16ll << i) * n2, n_fft);
@@ -1566,21 +1270,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     // resident ones, while 2 x 12 (384 MiB) falls out of the 256 MiB Infinity
     // Cache and loses 6 % although every pass alone is faster.
     int lanes = 2;
-    // Stage schedule (see bbt_osm_plan::stages): two-level power-of-two plans; `lanes` is then
-    // the number of work buffers in rotation (three: one per pass in flight).
-    // BBT_OSM_SCHED=lanes|stages overrides the default.
-    // Measured on MI355X (headline, round 3): 37-40 Gsamples/s against 46 for the lanes -- a
-    // cross-stream event dependency costs 10-20 us of idle stream per hop -- so it is off
-    // unless BBT_OSM_SCHED=stages asks for it.
-    bool stages = fast && !p->generic && p->outer == 1 && (p->n1 == 16 || p->n1 == 256);
-    {
-        const char* env = getenv("BBT_OSM_SCHED");
-        stages = stages && env && strcmp(env, "stages") == 0;
-    }
-    if (stages) lanes = 3;
     if (const char* env = getenv("BBT_OSM_LANES")) lanes = atoi(env);
     lanes = lanes < 1 ? 1 : (lanes > BBT_MAX_LANES ? BBT_MAX_LANES : lanes);
-    if (lanes < 2) stages = false;
     if (const char* env = getenv("BBT_OSM_TIMING_STRIDE")) p->timing_stride = std::max(1, atoi(env));
     const size_t per_block = (size_t)p->npair * n_fft * 16;
     int chunk = (int)((192u << 20) / per_block / lanes);
@@ -1589,9 +1280,6 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (chunk > BBT_MAX_CHUNK) chunk = BBT_MAX_CHUNK;
     if (p->outer > 1) {                       // grid.y = blocks * pairs * 256 must fit
         while (chunk > 1 && (long long)chunk * p->npair * p->outer > 65535) --chunk;
-        // BBT_OSM_BIG_LANES=1: one lane for work buffers beyond 768 MiB (round 1's rule)
-        static const bool one = [] { const char* e = getenv("BBT_OSM_BIG_LANES"); return e && atoi(e) == 1; }();
-        if (one && chunk * per_block * lanes > (768u << 20)) lanes = 1;
     }
     while (chunk > 1 && (long long)chunk * p->npair > 65535) --chunk;      // grid.y of the row pass
     if ((double)chunk * per_block * lanes > 16.0 * (1u << 30)) lanes = 1;   // (config 4: 2 x 2 GiB)
@@ -1618,30 +1306,23 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
                                  p->work_bytes));
             if (p->lanes > 1 &&
                 (hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
-                 hipEventCreateWithFlags(&p->ev_join[l], hipEventDisableTiming) != hipSuccess))
+                 hipEventCreateWithFlags(&p->ev_join[l], BBT_EV_ORDER) != hipSuccess))
                 return bail(fail("bbt_osm_plan_create: creating the lane streams failed"));
         }
         p->work = p->lane_work[0];
         if (p->lanes > 1 &&
-            hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&p->ev_fork, BBT_EV_ORDER) != hipSuccess)
             return bail(fail("bbt_osm_plan_create: creating the fork event failed"));
-        p->stages = stages && p->lanes >= 2;
-        if (p->stages) {
-            for (int k = 0; k < 3; ++k) {
-                if (!p->ev_join[k] &&
-                    hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) != hipSuccess)
-                    return bail(fail("bbt_osm_plan_create: creating the join events failed"));
-                if (hipStreamCreateWithFlags(&p->stage_stream[k], hipStreamNonBlocking) != hipSuccess)
-                    return bail(fail("bbt_osm_plan_create: creating the stage streams failed"));
-                for (int w = 0; w < p->lanes; ++w)
-                    if (hipEventCreateWithFlags(&p->ev_pass[k][w], hipEventDisableTiming) != hipSuccess)
-                        return bail(fail("bbt_osm_plan_create: creating the stage events failed"));
-            }
+        if (p->lanes > 1) {
+            if (hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_tail[0], BBT_EV_ORDER) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev_tail[1], BBT_EV_ORDER) != hipSuccess)
+                return bail(fail("bbt_osm_plan_create: creating the tail stream failed"));
         }
     } else {
         p->lanes = 1;
     }
-    if (hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&p->ev_done, BBT_EV_ORDER) != hipSuccess)
         return bail(fail("bbt_osm_plan_create: creating the completion event failed"));
     *plan = p;
     return 0;
@@ -1668,23 +1349,17 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
         }
         if (p->ev_join[l]) hipEventDestroy(p->ev_join[l]);
         if (p->lane_work[l]) hipFree(p->lane_work[l]);
-        if (p->lane_stage[l]) hipFree(p->lane_stage[l]);
     }
-    for (int k = 0; k < 3; ++k) {
-        if (p->stage_stream[k]) {
-            hipStreamSynchronize(p->stage_stream[k]);
-            hipStreamDestroy(p->stage_stream[k]);
-        }
-        for (int w = 0; w < BBT_MAX_LANES; ++w)
-            if (p->ev_pass[k][w]) hipEventDestroy(p->ev_pass[k][w]);
+    if (p->tail_stream) {
+        hipStreamSynchronize(p->tail_stream);
+        hipStreamDestroy(p->tail_stream);
     }
-    for (auto& s : p->ev_pass_samples) {
-        hipEventDestroy(s.a);
-        hipEventDestroy(s.b);
+    for (int i = 0; i < 2; ++i) {
+        if (p->ev_tail[i]) hipEventDestroy(p->ev_tail[i]);
+        if (p->seam_buf[i]) hipFree(p->seam_buf[i]);
     }
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->ev_done) hipEventDestroy(p->ev_done);
-    if (p->seam) hipFree(p->seam);
     delete p;
     return 0;
 }
@@ -1699,26 +1374,34 @@ int bbt_osm_plan_info(const bbt_osm_plan* p, int64_t* workspace_bytes, int* chun
     return 0;
 }
 
+int bbt_osm_plan_defer(bbt_osm_plan* p, bbt_event done) {
+    ARG_TRY(p, "bbt_osm_plan_defer: null plan");
+    std::lock_guard<std::mutex> lock(p->mu);
+    p->defer_ev = (hipEvent_t)done;
+    return 0;
+}
+
 int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     // can bbt_osm_execute_channelized take Channelize(n_chan) into the row pass?
     if (!p || p->generic || (p->n1 == 1 && p->outer == 1)) return 0;
     if (p->single)              // one stream: blocks side by side; 256 channels and up, no detection
-        return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0 && p->n1 != 4096;
+        return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
     if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
-        return p->n1 == 256 || p->n1 == 4096 || p->outer == 256;            // exchange in the row pass
+        return p->n1 == 256 || p->outer == 256;                             // exchange in the row pass
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
 }
 
 int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,
                     const int64_t* in_off, const int64_t* out_off, const int32_t* valid_start,
                     const int32_t* valid_count, bbt_stream stream) {
+    DeferTake take(p, (hipStream_t)stream);
     ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute: null argument");
     if (osm_check_blocks(p, "bbt_osm_execute", n_blocks, in_off, out_off, valid_start, valid_count))
         return 1;
     hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
-    PlanCall call(p, st);
-    return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+    PlanCall call(p, take, n_blocks);
+    return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, call,
                        [&](OsmBlock& blk, int64_t b) {
                            blk.in_off = in_off[b];
                            blk.out_off = out_off[b];
@@ -1733,6 +1416,7 @@ int bbt_osm_execute_flat(bbt_osm_plan* p, const void* in_dev, void* out_dev, int
                          const int64_t* in_off, const int64_t* out_elem_off, const int32_t* valid_start,
                          int32_t first_elem, const int32_t* valid_elems, bbt_stream stream) {
     const char* who = "bbt_osm_execute_flat";
+    DeferTake take(p, (hipStream_t)stream);
     ARG_TRY(p && in_dev && out_dev, "%s: null argument", who);
     ARG_TRY(!p->generic && !p->single && p->n1 == 1 && p->outer == 1,
             "%s: only for power-of-two blocks of at most 4096 samples with an even stream count", who);
@@ -1747,8 +1431,8 @@ int bbt_osm_execute_flat(bbt_osm_plan* p, const void* in_dev, void* out_dev, int
                 "%s: block %lld keeps elements outside the block", who, (long long)b);
     hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
-    PlanCall call(p, st);
-    return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+    PlanCall call(p, take, n_blocks);
+    return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, call,
                        [&](OsmBlock& blk, int64_t b) {
                            blk.in_off = in_off[b];
                            blk.out_off = out_elem_off[b];
@@ -1763,7 +1447,7 @@ int bbt_osm_plan_set_layout(bbt_osm_plan* p, int64_t in_plane, int64_t out_plane
     ARG_TRY(p, "bbt_osm_plan_set_layout: null plan");
     ARG_TRY(in_plane >= 0 && out_plane >= 0, "bbt_osm_plan_set_layout: negative plane length");
     const bool pairs = !p->generic && !p->single && p->outer == 1 && p->S % 2 == 0;
-    ARG_TRY(in_plane == 0 || (pairs && p->n1 == 256 && !p->stages),
+    ARG_TRY(in_plane == 0 || (pairs && p->n1 == 256),
             "bbt_osm_plan_set_layout: pair-planar input needs a two-level plan with 256-point columns "
             "(blocks of 2^17 to 2^20 samples) of an even number of streams");
     ARG_TRY(out_plane == 0 || (pairs && p->n1 == 1),
@@ -1775,110 +1459,6 @@ int bbt_osm_plan_set_layout(bbt_osm_plan* p, int64_t in_plane, int64_t out_plane
     return 0;
 }
 
-int bbt_osm_execute_dechan_flat(bbt_osm_plan* p, const void* spectra_dev, void* out_dev, int n_chan,
-                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_elem_off,
-                                const int32_t* valid_start, int32_t first_elem,
-                                const int32_t* valid_elems, bbt_stream stream) {
-    const char* who = "bbt_osm_execute_dechan_flat";
-    ARG_TRY(p && spectra_dev && out_dev, "%s: null argument", who);
-    ARG_TRY(!p->generic && !p->single && p->n1 == 1 && p->outer == 1 && p->n >= 256,
-            "%s: only for power-of-two blocks of 256 to 4096 rows with an even stream count", who);
-    ARG_TRY(n_chan == 256 || n_chan == 512 || n_chan == 1024 || n_chan == 2048,
-            "%s: n_chan=%d must be 256, 512, 1024 or 2048", who, n_chan);
-    ARG_TRY(p->S % n_chan == 0 && (p->S / n_chan) % 2 == 0,
-            "%s: the plan's %d streams are not n_chan=%d phases of an even number of streams", who, p->S, n_chan);
-    constexpr int PPN = 8;                    // (the largest lanes-over-pairs group of k_osm_small)
-    ARG_TRY(p->npair % PPN == 0, "%s: %d stream pairs", who, p->npair);
-    ARG_TRY(n_blocks >= 0 && (n_blocks == 0 || (in_off && out_elem_off && valid_start && valid_elems)),
-            "%s: bad descriptors", who);
-    ARG_TRY(first_elem >= 0 && first_elem < p->S && first_elem % 2 == 0,
-            "%s: first_elem=%d must be an even element of a row of %d", who, first_elem, p->S);
-    for (int64_t b = 0; b < n_blocks; ++b)
-        ARG_TRY(in_off[b] >= 0 && out_elem_off[b] >= 0 && out_elem_off[b] % 2 == 0 && valid_start[b] >= 0 &&
-                    valid_elems[b] >= 0 && valid_elems[b] % 2 == 0 &&
-                    (int64_t)valid_start[b] * p->S + first_elem + valid_elems[b] <= p->n * p->S,
-                "%s: block %lld keeps elements outside the block", who, (long long)b);
-    hipStream_t st = (hipStream_t)stream;
-    SpecOut so = {};
-    PlanCall call(p, st);
-    // two lanes, each with a staging buffer of `chunk` dechannelized blocks: 128 MiB together, so
-    // that what the first kernel wrote is still in the Infinity Cache when the second reads it
-    const size_t per_block = (size_t)p->n * p->S * sizeof(float2);
-    int chunk = (int)std::max<size_t>(1, (64u << 20) / per_block);
-    if (const char* env = getenv("BBT_IPFB_CHUNK")) chunk = std::max(1, atoi(env));
-    chunk = std::min(chunk, BBT_MAX_CHUNK);
-    int lanes = 2;
-    if (const char* env = getenv("BBT_IPFB_LANES")) lanes = std::min(std::max(1, atoi(env)), BBT_MAX_LANES);
-    const size_t bytes = per_block * chunk;
-    if (p->lane_stage_bytes < bytes) {
-        HIP_TRY(hipDeviceSynchronize());
-        for (int l = 0; l < BBT_MAX_LANES; ++l)
-            if (p->lane_stage[l]) {
-                HIP_TRY(hipFree(p->lane_stage[l]));
-                p->lane_stage[l] = nullptr;
-            }
-        p->lane_stage_bytes = bytes;
-    }
-    for (int l = 0; l < lanes; ++l) {
-        if (!p->lane_stage[l]) HIP_TRY(hipMalloc((void**)&p->lane_stage[l], p->lane_stage_bytes));
-        if (lanes > 1 && !p->lane_stream[l])
-            HIP_TRY(hipStreamCreateWithFlags(&p->lane_stream[l], hipStreamNonBlocking));
-        if (lanes > 1 && !p->ev_join[l])
-            HIP_TRY(hipEventCreateWithFlags(&p->ev_join[l], hipEventDisableTiming));
-    }
-    if (lanes > 1 && !p->ev_fork) HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    if (p->dechan_tab.tw0 == nullptr || p->dechan_nch != n_chan)
-        if (get_tables(n_chan, &p->dechan_tab)) return 1;
-    const int chunk_was = p->chunk, lanes_was = p->lanes;
-    p->chunk = chunk;
-    p->lanes = lanes;
-    p->dechan_nch = n_chan;
-    p->dechan_s = p->S / n_chan;
-    const int rc = osm_run_all(p, (const float2*)spectra_dev, (float2*)out_dev, n_blocks, so, st,
-                               [&](OsmBlock& blk, int64_t b) {
-                                   blk.in_off = in_off[b];
-                                   blk.out_off = out_elem_off[b];
-                                   blk.valid_start = valid_start[b];
-                                   blk.valid_count = valid_elems[b];
-                                   blk.flat = 1;
-                                   blk.flat_sub = first_elem;
-                               });
-    p->chunk = chunk_was;
-    p->lanes = lanes_was;
-    p->dechan_nch = 0;
-    return rc;
-}
-
-int bbt_osm_execute_prefiltered(bbt_osm_plan* p, const bbt_fir_plan* fir, const void* in_dev,
-                                void* out_dev, int64_t n_blocks, const int64_t* in_off,
-                                const int64_t* out_off, const int32_t* valid_start,
-                                const int32_t* valid_count, bbt_stream stream) {
-    const char* who = "bbt_osm_execute_prefiltered";
-    ARG_TRY(p && fir && in_dev && out_dev, "%s: null argument", who);
-    ARG_TRY(!p->single && fir->S != 1, "%s: not for one-stream plans", who);
-    ARG_TRY(fir->S == p->S, "%s: the filter has %d streams, the plan %d", who, fir->S, p->S);
-    ARG_TRY(p->n >= 256 * BBT_FIR_R, "%s: blocks of %lld samples are too short", who, (long long)p->n);
-    if (osm_check_blocks(p, who, n_blocks, in_off, out_off, valid_start, valid_count)) return 1;
-    hipStream_t st = (hipStream_t)stream;
-    PlanCall call(p, st);
-    const size_t bytes = (size_t)p->chunk * p->n * p->S * sizeof(float2);
-    for (int l = 0; l < p->lanes; ++l)
-        if (!p->lane_stage[l]) HIP_TRY(hipMalloc((void**)&p->lane_stage[l], bytes));
-    SpecOut so = {};
-    p->pre = fir;
-    const int rc = osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
-                               [&](OsmBlock& blk, int64_t b) {
-                                   blk.in_off = in_off[b];
-                                   blk.out_off = out_off[b];
-                                   blk.valid_start = valid_start[b];
-                                   blk.valid_count = valid_count[b];
-                                   blk.shift = 0;
-                                   blk.index = (int)b;
-                               });
-    p->pre = nullptr;
-    return rc;
-}
-
 // Channelize(overlap-save task) as one call; with det_step > 0 the spectra are
 // detected and integrated instead of stored (out_dev = float32 bins).
 static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev, void* out_dev,
@@ -1886,14 +1466,15 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
                            const int32_t* valid_start, const int32_t* valid_count, int n_chan,
                            int64_t first_spectrum, int64_t n_spectra, int det_step, int det_mode,
                            float det_scale, hipStream_t st) {
+    DeferTake take(p, st);
     ARG_TRY(p && in_dev && out_dev, "%s: null argument", who);
     ARG_TRY(!p->generic, "%s: the fused channelizer needs a power-of-two block length (got %lld)",
             who, (long long)p->n);
     ARG_TRY(p->n1 > 1 || p->outer > 1, "%s: block length %lld is too short to fuse", who,
             (long long)p->n);
     ARG_TRY(bbt_osm_plan_fusable(p, n_chan),
-            "%s: n_chan=%d must be a power of two in [256, %d] (or 16..128 for blocks with 256 or "
-            "4096 columns or of three levels)", who, n_chan, p->n2);
+            "%s: n_chan=%d must be a power of two in [256, %d] (or 16..128 for blocks with 256 "
+            "columns or of three levels)", who, n_chan, p->n2);
     const bool small = n_chan < 256;
     ARG_TRY(!(small && det_step > 0), "%s: fused detection needs n_chan >= 256", who);
     ARG_TRY(!(p->single && det_step > 0), "%s: one-stream plans have no fused detection", who);
@@ -1903,22 +1484,30 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
         ARG_TRY(valid_count[b] >= n_chan, "%s: block %lld keeps %d samples < n_chan", who,
                 (long long)b, valid_count[b]);
     if (n_blocks == 0 || n_spectra == 0) return 0;
-    PlanCall call(p, st);
+    PlanCall call(p, take, n_blocks);
     FftTables tabc;
     GenGeo gsmall = {};
     cf* wsmall = nullptr;
     if (small ? (!factor_7smooth(n_chan, &gsmall) || get_gen_table(&gsmall, &wsmall))
               : get_tables(n_chan, &tabc))
         return 1;
-    // seam slots and jobs
-    const size_t need = (size_t)n_blocks * 2 * p->npair * n_chan * 16;
-    if (need > p->seam_bytes) {
-        if (p->seam) HIP_TRY(hipFree(p->seam));
-        p->seam = nullptr;
-        p->seam_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&p->seam, need));
-        p->seam_bytes = need;
+    // seam slots and jobs.  The slots are filled by the lanes and read by the seam pass at the
+    // end of the call; a deferred call takes the turn the call before it did not use, after the
+    // seam pass of the last call on that turn (two calls back, long done: no stall).
+    const int turn = call.deferred ? (p->seam_turn ^= 1) : p->seam_turn;
+    if (p->ev_tail_set[turn]) {
+        HIP_TRY(hipStreamWaitEvent(st, p->ev_tail[turn], 0));
+        if (!call.deferred) p->ev_tail_set[turn] = false;
     }
+    const size_t need = (size_t)n_blocks * 2 * p->npair * n_chan * 16;
+    if (need > p->seam_bytes[turn]) {
+        if (p->seam_buf[turn]) HIP_TRY(hipFree(p->seam_buf[turn]));      // (waits for the device)
+        p->seam_buf[turn] = nullptr;
+        p->seam_bytes[turn] = 0;
+        HIP_TRY(hipMalloc((void**)&p->seam_buf[turn], need));
+        p->seam_bytes[turn] = need;
+    }
+    p->seam = p->seam_buf[turn];
     std::vector<SeamJob> jobs;
     for (int64_t b = 0; b + 1 < n_blocks; ++b) {
         const int64_t seam_pos = out_off[b] + valid_count[b];
@@ -1947,7 +1536,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
         so.det_mode = det_mode;
         so.det_scale = det_scale;
     }
-    if (osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, st,
+    if (osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, call,
                     [&](OsmBlock& blk, int64_t b) {
                         blk.in_off = in_off[b];
                         blk.out_off = out_off[b];
@@ -1960,6 +1549,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
                         blk.index = (int)b;
                     }))
         return 1;
+    hipStream_t fin = call.fin;        // (a deferred call: the plan's tail stream, after the lanes)
     if (!jobs.empty() && small) {
         const size_t lds = (size_t)2 * n_chan * sizeof(f4);
         for (size_t j0 = 0; j0 < jobs.size(); j0 += BBT_SEAM_JOBS_PER_LAUNCH) {
@@ -1967,18 +1557,22 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
             const size_t n = std::min(jobs.size() - j0, (size_t)BBT_SEAM_JOBS_PER_LAUNCH);
             for (size_t i = 0; i < n; ++i) batch.j[i] = jobs[j0 + i];
             hipLaunchKernelGGL(k_seam_fix_gen, dim3((unsigned)n, p->npair), dim3(gen_threads(2 * n_chan)),
-                               lds, st, p->seam, (float2*)out_dev, batch, p->S, p->npair, gsmall, wsmall, so);
+                               lds, fin, p->seam, (float2*)out_dev, batch, p->S, p->npair, gsmall, wsmall, so);
         }
         HIP_TRY(hipGetLastError());
     } else if (!jobs.empty()) {
         switch (n_chan) {
-            case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, so, st); break;
-            case 512: launch_seam_fix<512>(p, (float2*)out_dev, jobs, tabc, so, st); break;
-            case 1024: launch_seam_fix<1024>(p, (float2*)out_dev, jobs, tabc, so, st); break;
-            case 2048: launch_seam_fix<2048>(p, (float2*)out_dev, jobs, tabc, so, st); break;
-            case 4096: launch_seam_fix<4096>(p, (float2*)out_dev, jobs, tabc, so, st); break;
+            case 256: launch_seam_fix<256>(p, (float2*)out_dev, jobs, tabc, so, fin); break;
+            case 512: launch_seam_fix<512>(p, (float2*)out_dev, jobs, tabc, so, fin); break;
+            case 1024: launch_seam_fix<1024>(p, (float2*)out_dev, jobs, tabc, so, fin); break;
+            case 2048: launch_seam_fix<2048>(p, (float2*)out_dev, jobs, tabc, so, fin); break;
+            case 4096: launch_seam_fix<4096>(p, (float2*)out_dev, jobs, tabc, so, fin); break;
         }
         HIP_TRY(hipGetLastError());
+    }
+    if (call.deferred) {
+        HIP_TRY(hipEventRecord(p->ev_tail[turn], fin));
+        p->ev_tail_set[turn] = true;
     }
     return 0;
 }
@@ -2007,6 +1601,7 @@ int bbt_osm_execute_channelized_detect(bbt_osm_plan* p, const void* in_dev, void
                                        int64_t first_spectrum, int64_t n_bins, int step, int mode,
                                        int average, bbt_stream stream) {
     const char* who = "bbt_osm_execute_channelized_detect";
+    DeferTake take(p, (hipStream_t)stream);
     ARG_TRY(p && out_dev, "%s: null argument", who);
     ARG_TRY(p->n1 == 256 && p->outer == 1,
             "%s: fused detection needs a two-level transform with 256 columns (block length 2^16..2^20)",
@@ -2018,6 +1613,7 @@ int bbt_osm_execute_channelized_detect(bbt_osm_plan* p, const void* in_dev, void
             "than %d bins)", who, step, n_chan, p->n2, BBT_DET_MAX_BINS);
     const size_t out_bytes = (size_t)n_bins * n_chan * p->npair * (mode ? 4 : 2) * sizeof(float);
     if (out_bytes) HIP_TRY(hipMemsetAsync(out_dev, 0, out_bytes, (hipStream_t)stream));
+    take.give_back(p);
     return osm_channelized(p, who, in_dev, out_dev, n_blocks, in_off, out_off, valid_start,
                            valid_count, n_chan, first_spectrum, n_bins * step, step, mode,
                            average ? 1.0f / (float)step : 1.0f, (hipStream_t)stream);
@@ -2026,6 +1622,7 @@ int bbt_osm_execute_channelized_detect(bbt_osm_plan* p, const void* in_dev, void
 int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t n_blocks,
                             int64_t in_off0, int64_t out_off0, int64_t hop, int32_t valid_start,
                             bbt_stream stream) {
+    DeferTake take(p, (hipStream_t)stream);
     ARG_TRY(p, "bbt_osm_execute_regular: null plan");
     ARG_TRY(n_blocks >= 0 && hop > 0 && hop <= p->n, "bbt_osm_execute_regular: bad hop %lld",
             (long long)hop);
@@ -2037,7 +1634,7 @@ int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, 
                 (long long)(valid_start + hop), (long long)p->n);
         hipStream_t st = (hipStream_t)stream;
         SpecOut so = {};
-        PlanCall call(p, st);
+        PlanCall call(p, take, 0);         // (one-kernel plans have no lanes)
         const int64_t per_launch = std::min<int64_t>(1 << 20, ((1ll << 31) - 1) / p->npair);
         for (int64_t b0 = 0; b0 < n_blocks; b0 += per_launch) {
             OsmChunk ch = {};
@@ -2058,6 +1655,7 @@ int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, 
         io[b] = in_off0 + b * hop;
         oo[b] = out_off0 + b * hop;
     }
+    take.give_back(p);
     return bbt_osm_execute(p, in_dev, out_dev, n_blocks, io.data(), oo.data(), vs.data(),
                            vc.data(), stream);
 }
@@ -2354,8 +1952,7 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     p->npair = n_stream / 2;
     p->n_tap = n_tap;
     const size_t tb = (size_t)n_tap * n_chan * sizeof(float);
-    const char* env = getenv("BBT_PFB_WINDOW");
-    p->window = (!env || atoi(env) != 0) && pfb_window_dispatch(p, nullptr, nullptr, 0, nullptr, true);
+    p->window = pfb_window_dispatch(p, nullptr, nullptr, 0, nullptr, true);
     if ((n_stream == 1 || split_real) && !p->window) {   // only the sliding-window kernels take one stream / split
         delete p;
         return fail("bbt_pfb_plan_create: one stream needs n_chan in 256..2048 and 4, 8, 12 or 16 taps "

@@ -23,14 +23,6 @@
 #include <hip/hip_runtime.h>
 #include "fft_core.hpp"
 
-// Timing-only experiment switches (never set in the product build; results are wrong with any
-// of them): 1 the row pass skips the four-step twiddles, 2 the last column pass stores nothing,
-// 4 the first column pass reads block 0's samples for every block, 8 the row pass only loads
-// and stores, 16 the row pass skips the fused channelizer transform.
-#ifndef BBT_DBG
-#define BBT_DBG 0
-#endif
-
 // Transform twiddles W^{tau c}, c < 16, of a stage: 0 = fifteen table loads per thread, 1 = one
 // load and its powers (products at most four roundings deep), 2 = four loads (c = 1, 2, 4, 8)
 // and eleven products at most three deep (fft_core.hpp).  The kernels that wait for loads rather
@@ -609,62 +601,14 @@ __device__ __forceinline__ void apply_resp(c2 (&v)[16], const cf* __restrict__ h
     }
 }
 
-// Dechannelize for the inverse filter bank (pfb.py:255-269 runs its transform along the block
-// axis of the DEchannelized frame): the inverse transform over the NCH channels of R consecutive
-// spectra per workgroup, written TRANSPOSED into a staging buffer -- sample (row r, phase k,
-// stream pair sp) of block b of the chunk goes to stage[b][k * (s / 2) + sp][r], 16 bytes in the
-// work-buffer format -- so that the overlap-save kernel that follows (k_osm_small<.., TRANS>)
-// reads each of its transforms as one contiguous run instead of 16 or 32 bytes out of every
-// 16 KiB row.  Lanes run over the R spectra first: a wave's loads are R runs of 128 bytes (8
-// channels of one spectrum), its stores runs of R * 16 bytes (R rows of one phase).
-//   in    : (spectra, NCH, s) complex64, s even; block b starts at spectrum ch.b[b].in_off
-//   stage : [ch.nblk][NCH * s / 2][rows] complete samples
-template <int NCH, int R>
-__global__ __launch_bounds__(R * NCH / 16) void k_dechan_staged(const float2* __restrict__ in,
-                                                               float2* __restrict__ stage, OsmChunk ch,
-                                                               int rows, int s, float scale,
-                                                               const cf* __restrict__ tw0,
-                                                               const cf* __restrict__ tw1) {
-    typedef FftGeo<NCH> G;
-    constexpr int T = G::T;
-    extern __shared__ v2 dechan_lds[];             // G::LDS_ELEMS * R elements
-    const int f = threadIdx.x % R, tau = threadIdx.x / R;
-    const int npp = s >> 1;
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int sp = vb % npp, r = (vb / npp) * R + f;
-    const int b = blockIdx.y;
-    const OsmBlock blk = osm_block(ch, b);
-    const bool active = r < rows;
-    c2 v[16];
-    if (active) {
-        const float2* src = in + (((blk.in_off + r) * NCH + tau) * s + 2 * sp);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * s);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = czero();
-    }
-    wg_fft<NCH, +1, R>(v, dechan_lds, tau, f, tw0, tw1);
-    if (active) {
-        float2* dst = stage + ((((long long)b * NCH + tau) * npp + sp) * rows + r) * 2;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            st_int(dst + (long long)T * j * npp * rows * 2, c2{v[j].re * scale, v[j].im * scale});
-    }
-}
-
 // Single-kernel path, N <= 4096: one workgroup per (block, group of PP pairs).
 // With many streams (InversePolyphaseFilterBank runs this along the block axis
 // with n_chan * S streams) the lanes run over PP pairs first, so a wave touches
 // PP * 16 contiguous bytes of each complete sample instead of 16; the PP
 // transforms are interleaved in LDS (COLMODE = PP).
-// TRANS: the blocks of the chunk come from a staging buffer that holds them transposed, block i
-// of the chunk at [i][pair][N rows] complete two-stream samples in the work-buffer format
-// (k_dechan_staged wrote it): a workgroup's loads are PP contiguous runs of N * 16 bytes instead
-// of PP * 16 bytes out of every row of the (row, stream) matrix.
 // (its transform twiddles come as powers, BBT_SMALL_TW_POW below)
-template <int N, int PP, bool SINGLE = false, bool TRANS = false, int MINW = 1>
-__global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __restrict__ in,
+template <int N, int PP, bool SINGLE = false>
+__global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restrict__ in,
                                                           float2* __restrict__ out, OsmChunk ch, int S,
                                                           const cf* __restrict__ resp,
                                                           const int* __restrict__ resp_index,
@@ -695,15 +639,9 @@ __global__ __launch_bounds__(PP* N / 16, MINW) void k_osm_small(const float2* __
     const int pl = threadIdx.x % PP, tau = threadIdx.x / PP;
     const int sp = (vb % npg) * PP + pl;
     const OsmBlock blk = osm_block(ch, vb / npg);
-    if constexpr (TRANS) {
-        const float2* src = in + (((long long)(vb / npg) * (S >> 1) + sp) * N + tau) * 2;
+    const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_int(src + T * j * 2);
-    } else {
-        const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
-    }
+    for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);
     wg_fft<N, -1, CM, 0, BBT_SMALL_TW_POW>(v, lds, tau, pl, tw0, tw1);
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (long long)c0 * N + tau;
@@ -942,15 +880,6 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                 p[j] = (full && sj >= 0 && sj < cur.n_out) ? detect_pair(v[j], mode)
                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-#if BBT_DBG & 64
-            {   // timing only: the powers are formed, nothing is reduced or stored
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc += p[j].x + p[j].y + p[j].z + p[j].w;
-                if (acc == 12345.678f) unsafeAtomicAdd(so.det, acc);
-                return;
-            }
-#endif
             const int npass = mode ? 2 : 1;
             for (int pass = 0; pass < npass; ++pass) {
                 __syncthreads();                                     // exchange buffer / previous pass done
@@ -971,11 +900,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                     if (hi > 256) hi = 256;
                     float sum = 0.f;
                     for (int n1 = lo; n1 < hi; ++n1) sum += pf[n1 * (FCOL * 2) + fc];
-#if BBT_DBG & 128
-                    if (sum == 12345.678f)          // timing only: the sums are formed, not added
-#else
                     if (sum != 0.f)
-#endif
                         unsafeAtomicAdd(so.det + detect_index(bin, ch0 + (fc >> 1), sp, so.lg_chan, npair, mode)
                                             + 2 * pass + (fc & 1),
                                         sum * so.det_scale);
@@ -991,126 +916,6 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                 const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
                     st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
-            }
-        }
-    }
-}
-
-// Last column pass of one chunk and first column pass of the next chunk of the same lane in
-// ONE launch.  Both passes of a workgroup touch the same 16-column x 256-row tile of the work
-// buffer -- the last pass reads it, the first pass writes it -- and every thread stores exactly
-// where it loaded, so the workgroup can empty its tile (inverse transform over k1, kept samples
-// or spectra out) and refill it at once (next block in, forward transform over n1): the lane
-// has two kernel boundaries per chunk instead of three, its launches alternate between a
-// stream-bound kernel (this one) and the row pass, and the second lane, started half a period
-// later, always has the other kind in flight.  chc: blocks whose last pass this is (block b of
-// the chunk in work slot b); cha: the blocks that take the slots over.  Either may hold fewer
-// blocks than the grid has rows.  Two-stream tiles (PP == 1) of 16 columns.
-template <bool SPEC>
-__global__ __launch_bounds__(256) void k_osm_col256_ca(const float2* __restrict__ in,
-                                                       float2* __restrict__ out,
-                                                       float2* __restrict__ work, OsmChunk chc,
-                                                       OsmChunk cha, int S, int N2,
-                                                       const cf* __restrict__ tw0, SpecOut so) {
-    constexpr int FCOL = 16;
-    extern __shared__ v2 col256_lds[];                   // FftGeo<256>::LDS_ELEMS * FCOL elements
-    v2* lds = col256_lds;
-    const int f = threadIdx.x % FCOL, tau = threadIdx.x / FCOL;
-    const int npair = S >> 1;
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int n2 = (vb / npair) * FCOL + f;
-    const int b = blockIdx.y, sp = vb % npair;
-    float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
-    c2 v[16];
-    if (b < chc.nblk) {
-        const OsmBlock blk = chc.b[b];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
-        wg_fft<256, +1, FCOL>(v, lds, tau, f, tw0, nullptr);
-#if BBT_DBG & 2
-        if (v[0].re.x == 1.2345e-30f)
-#endif
-        if constexpr (SPEC) {
-            const SpecCursor cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, so), S, sp, npair);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) emit_spectrum(v[j], cur, j);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
-                if (r >= 0 && r < blk.valid_count)
-                    st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
-            }
-        }
-    }
-    if (b < cha.nblk) {
-        OsmBlock blk = cha.b[b];
-#if BBT_DBG & 4
-        blk.in_off = 0;
-#endif
-        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);
-        const long long wrap = (tau == 15 && n2 + blk.shift >= N2) ? (long long)256 * N2 * S : 0;
-        if (S == 2) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = ld_ext(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
-        }
-        wg_fft<256, -1, FCOL>(v, lds, tau, f, tw0, nullptr);     // (its exchanges open with a barrier)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
-    }
-}
-
-// Column pass, N1 == 4096 (blocks longer than 2^20 as 4096 x N2, N2 = 512 ..
-// 4096): one 4096-point transform is 256 threads x 16 points; a 1024-thread
-// workgroup runs four of them interleaved in LDS (136 KiB), the four lanes of a
-// row being PP stream pairs x 4 / PP neighbouring columns:
-//   PP == 1: 64-byte runs of the work buffer (16-byte pieces of the stream,
-//            merged in L2 with the other pairs' workgroups, which run beside it)
-//   PP == 4: 64-byte runs of the stream (one complete sample of 4 pairs), 16-byte
-//            pieces of four work buffers
-template <bool FIRST, bool SPEC, int PP>
-__global__ __launch_bounds__(1024) void k_osm_col4096(const float2* __restrict__ in,
-                                                      float2* __restrict__ out,
-                                                      float2* __restrict__ work, OsmChunk ch, int S,
-                                                      int N2, const cf* __restrict__ tw0,
-                                                      const cf* __restrict__ tw1, SpecOut so) {
-    constexpr int F = 4, T = 256, CPT = F / PP;
-    extern __shared__ v2 col4096_lds[];                  // G::LDS_ELEMS * F elements
-    const int f = threadIdx.x % F, tau = threadIdx.x / F;
-    const int npair = S >> 1, npg = npair / PP;
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int n2 = (vb / npg) * CPT + f / PP;
-    const int b = blockIdx.y, sp = (vb % npg) * PP + f % PP;
-    const OsmBlock blk = ch.b[b];
-    float2* w = work + (((long long)(b * npair + sp) * 4096 + tau) * N2 + n2) * 2;
-    c2 v[16];
-    if (FIRST) {
-        // read circularly shifted by blk.shift (see k_osm_col16): row 4095 can wrap
-        const float2* src = in + ((blk.in_off + (long long)tau * N2 + n2 + blk.shift) * S + 2 * sp);
-        const long long wrap = (tau == T - 1 && n2 + blk.shift >= N2) ? (long long)4096 * N2 * S : 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * N2 * S - (j == 15 ? wrap : 0));
-        wg_fft<4096, -1, F>(v, col4096_lds, tau, f, tw0, tw1);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) st_int(w + (long long)T * j * N2 * 2, v[j]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)T * j * N2 * 2);
-        wg_fft<4096, +1, F>(v, col4096_lds, tau, f, tw0, tw1);
-        SpecCursor cur;
-        if (SPEC) cur = spec_cursor(out, so, blk, tau, T, N2, small_channel_slot(n2, so), S, sp, npair);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (SPEC) {
-                emit_spectrum(v[j], cur, j);
-            } else {
-                const long long r = (long long)(tau + T * j) * N2 + n2 - blk.valid_start;
-                if (r >= 0 && r < blk.valid_count) st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j]);
             }
         }
     }
@@ -1216,7 +1021,7 @@ template <int N2, int NCH>
 __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MINWAVES : ((NCH == 0 && N2 >= 1024) ? BBT_ROWPASS_PLAIN_MINWAVES : ((NCH > 16 && NCH < 256) ? BBT_ROWPASS_SMALL_MINWAVES : 1)))) void k_osm_rowpass(
     float2* __restrict__ work, int N1, const cf* __restrict__ resp,
     const int* __restrict__ resp_index, int npair, const cf* __restrict__ tw0,
-    const cf* __restrict__ tw1, const cf* __restrict__ wroot, const cf* __restrict__ wfine,
+    const cf* __restrict__ tw1, const cf* __restrict__ wroot,
     OsmChunk ch, int outer, int y0, const cf* __restrict__ tw4row, const cf* __restrict__ tw4base,
     int tw_in_col, const cf* __restrict__ tw4o, const cf* __restrict__ tw4u) {
     // Three-level transforms (N > 2^20) run this pass once per row k1o of the
@@ -1258,44 +1063,13 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     // tw_in_col (two-level plans with tables): bit 0, the first column pass has applied the
     // forward twiddles; bit 1, the last column pass will apply the inverse ones (col_twiddles;
     // not with the fused channelizer, whose transform over n2 comes after them)
-    const bool tw4 = tw4row != nullptr;
     cf base = make_float2(1.f, 0.f);
-    if (tw_in_col & 1) {
-    } else if (tw4) {
+    if (!(tw_in_col & 1)) {
         base = tw4base[k1 * T + tau];
-    } else {
-        float s, c;
-        const float ang = -2.0f * (float)(k1 * tau) / ((float)N1 * (float)N2);
-        sincospif(ang, &s, &c);
-        base = make_float2(c, s);
-    }
-    // W_{16 N1}^{k1 j}: from the W_4096 table for N1 <= 256, else (N1 = 4096: blocks longer
-    // than 2^20 as 4096 x N2) as W_65536^x = W_256^{x >> 8} W_65536^{x & 255}
-    const int M = 16 * N1;
-    const int rstride = M <= 4096 ? 4096 / M : 0;
-    auto wrow = [&](int j) -> cf {
-        const int x = (k1 * j) & (M - 1);
-        if (M <= 4096) return wroot[x * rstride];
-        return cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
-    };
-#if !(BBT_DBG & 1)
-    if (tw_in_col & 1) {
-    } else if (tw4) {
         const cf* tr = tw4row + k1 * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, tr[j]));
-    } else if (N1 > 1) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = twmul<-1>(v[j], cmul(base, wrow(j)));
     }
-#endif
-#if BBT_DBG & 8
-    {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) st_int(row + (long long)(tau + T * j) * 2, v[j]);
-        return;
-    }
-#endif
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     const cf* h0 = resp + (((long long)c0 * outer + k1o) * N1 + k1) * N2 + tau;
     const cf* h1 = resp + (((long long)c1 * outer + k1o) * N1 + k1) * N2 + tau;
@@ -1320,29 +1094,16 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         // W_N^{(N2 a + n2) k1o} has a factor that depends on n2; it must act
         // before the channel FFT, so it is applied here (its a-dependent factor
         // stays in k_osm_mid16).  W_N^{(tau + T j) k1o} = W_N^{tau k1o} W_65536^{j k1o}.
-        if (tw4o) {
-            // from tables (three-level plans, bbt_osm_plan_create): tw4o [outer][T] = W_N^{tau k1o};
-            // tw4u [outer][N1][16] = W_{16 N1}^{k1 j} W_65536^{k1o j}, the same for the whole
-            // workgroup -- where a sincospif, forty-eight scalar-valued table loads and thirty-two
-            // complex products per thread were
-            const cf bb = cmul(base, tw4o[k1o * T + tau]);
-            const cf* uu = tw4u + ((long long)k1o * N1 + k1) * 16;
+        // from tables (three-level plans, bbt_osm_plan_create): tw4o [outer][T] = W_N^{tau k1o};
+        // tw4u [outer][N1][16] = W_{16 N1}^{k1 j} W_65536^{k1o j}, the same for the whole
+        // workgroup -- where a sincospif, forty-eight scalar-valued table loads and thirty-two
+        // complex products per thread were
+        const cf bb = cmul(base, tw4o[k1o * T + tau]);
+        const cf* uu = tw4u + ((long long)k1o * N1 + k1) * 16;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(bb, uu[j]));
-        } else {
-            float s, c;
-            sincospif(-2.0f * (float)(tau * k1o) / ((float)outer * (float)N1 * (float)N2), &s, &c);
-            const cf bb = cmul(base, make_float2(c, s));
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int x = k1o * j;                          // < 4096
-                const cf wo = cmul(wroot[(x >> 8) * 16], wfine[x & 255]);     // W_65536^x
-                const cf wi = wrow(j);
-                v[j] = twmul<+1>(v[j], cmul(bb, cmul(wi, wo)));
-            }
-        }
+        for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(bb, uu[j]));
     } else if (tw_in_col & 2) {
-    } else if (tw4 && !(BBT_DBG & 1)) {
+    } else {
         // (the tables again, through opaque moves: see below)
         const cf* tr = tw4row + k1 * 16;
         const cf* tb = tw4base;
@@ -1350,29 +1111,13 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
         const cf base2 = tb[k1 * T + tau];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = twmul<+1>(v[j], cmul(base2, tr[j]));
-    } else if (N1 > 1 && !(BBT_DBG & 1)) {
-        // Evaluate the twiddles again instead of keeping the 16 products of the
-        // forward step alive through both transforms (the compiler did: 199
-        // VGPRs / 2 waves per SIMD for the plain row pass): the row index goes
-        // through an opaque move so the two evaluations are not merged.
-        int k1b = k1;
-        asm volatile("" : "+s"(k1b));
-        float s2, c2v;
-        sincospif(-2.0f * (float)(k1b * tau) / ((float)N1 * (float)N2), &s2, &c2v);
-        const cf base2 = make_float2(c2v, s2);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int x = (k1b * j) & (M - 1);
-            const cf wj = M <= 4096 ? wroot[x * rstride] : cmul(wroot[(x >> 8) * 16], wfine[x & 255]);
-            v[j] = twmul<+1>(v[j], cmul(base2, wj));
-        }
     }
     // (Stores that go back to the addresses the row was loaded from take the row
     // pointer through an opaque move: otherwise the 16 load addresses, 32 VGPRs,
     // stay alive from the first instruction to the last -- that, with the tables
     // above, is what made the plain row pass 199 VGPRs / 2 waves per SIMD and
     // plain Dedisperse slower than the fused pipeline; now 148 / 3.)
-    if constexpr (NCH == 0 || (BBT_DBG & 16)) {
+    if constexpr (NCH == 0) {
         float2* row2 = row;
         asm volatile("" : "+s"(row2));
 #pragma unroll
@@ -2171,29 +1916,6 @@ __global__ __launch_bounds__(256) void k_fir(const float2* __restrict__ in, floa
     const int npair = S >> 1;
     fir_tile<R, CPLX>(in, out, n_in, n_out, S, vb % npair, (long long)(vb / npair) * (256 * R), tre, tim,
                       tap_pitch, n_chunks, pitch, fir_tile_mem);
-}
-
-// The same filter as the first stage of an overlap-save chunk
-// (bbt_osm_execute_prefiltered): block b of the chunk reads its N + n_tap - 1
-// input samples at ch.b[b].in_off and leaves N filtered samples in
-// staging[b * N ...], which the first column pass then reads -- on the plan's
-// lane stream, so the filter (VALU bound) of one chunk runs beside the memory
-// bound passes of the other lane, and the filtered blocks never leave the
-// Infinity Cache.  grid (tiles * npair, blocks).
-template <int R, bool CPLX>
-__global__ __launch_bounds__(256) void k_fir_blocks(const float2* __restrict__ in,
-                                                    float2* __restrict__ staging, OsmChunk ch,
-                                                    long long n_fft, int n_tap, int S,
-                                                    const float2* __restrict__ tre,
-                                                    const float2* __restrict__ tim, int tap_pitch,
-                                                    int n_chunks, int pitch) {
-    extern __shared__ float4 fir_tile_mem[];
-    const int npair = S >> 1;
-    const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = blockIdx.y;
-    fir_tile<R, CPLX>(in + ch.b[b].in_off * S, staging + (long long)b * n_fft * S, n_fft + n_tap - 1, n_fft,
-                      S, vb % npair, (long long)(vb / npair) * (256 * R), tre, tim, tap_pitch, n_chunks,
-                      pitch, fir_tile_mem);
 }
 
 // ---------------------------------------------------------------------------

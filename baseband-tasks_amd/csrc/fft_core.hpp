@@ -267,13 +267,6 @@ __device__ __forceinline__ void fft_butterfly_twiddle(c2 (&v)[16], const cf (&w)
 }
 
 // exchange 0: (c0, b) -> thread (c0, b1), b = R2 a1 + b1
-// (timing-only experiment, BBT_DBG & 32: the exchanges of the transform without their
-// workgroup barriers -- wrong results, an upper bound on what the barriers cost)
-#if defined(BBT_DBG) && (BBT_DBG & 32)
-#define BBT_FFT_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
-#define BBT_FFT_SYNC() __syncthreads()
-#endif
 
 template <int N, int COLMODE, int IMOFF>
 __device__ __forceinline__ void fft_exchange0(c2 (&v)[16], v2* __restrict__ lds, int tau, int f) {
@@ -281,21 +274,21 @@ __device__ __forceinline__ void fft_exchange0(c2 (&v)[16], v2* __restrict__ lds,
     constexpr int R2 = G::R2;
     const int c0s = tau / R2, b1 = tau % R2;
     v2* __restrict__ lds_im = lds + IMOFF;
-    BBT_FFT_SYNC();
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].re;
     if (IMOFF) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds_im[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
     }
-    BBT_FFT_SYNC();
+    __syncthreads();
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a].re = lds[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
     if (!IMOFF) {
-        BBT_FFT_SYNC();
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PAD0 + tau, f)] = v[c].im;
-        BBT_FFT_SYNC();
+        __syncthreads();
     }
 #pragma unroll
     for (int a = 0; a < 16; ++a) v[a].im = lds_im[lds_idx<COLMODE>(c0s * G::PAD0 + R2 * a + b1, f)];
@@ -313,7 +306,7 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
         const int c0r = tau & 15, g = tau >> 4;
         v2* __restrict__ lds_im = lds + IMOFF;
         c2 t[NU][R2];
-        BBT_FFT_SYNC();
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].re;
         if (IMOFF) {
@@ -321,18 +314,18 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
             for (int c = 0; c < 16; ++c)
                 lds_im[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
         }
-        BBT_FFT_SYNC();
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int bb = 0; bb < R2; ++bb)
                 t[u][bb].re = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
         if (!IMOFF) {
-            BBT_FFT_SYNC();
+            __syncthreads();
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
-            BBT_FFT_SYNC();
+            __syncthreads();
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u)

@@ -105,6 +105,13 @@ class DeviceTaskMixin:
             row *= d
         need = n_samples * row
         buf = self._cache_buffer
+        if buf is not None and buf.pending:
+            # A deferred plan call (hip.DEFER_JOIN) may still be writing the buffer of the previous
+            # run -- or its reader may not have come for it yet.  Taking it again would order this
+            # run after that one (the drain the deferral avoids), so runs alternate between two
+            # buffers: the other one was written two calls back, its event has long fired.
+            self._cache_buffer, self._cache_buffer_b = self._cache_buffer_b, buf
+            buf = self._cache_buffer
         if buf is None or buf.size < need:
             # drop the old one first so peak memory is one buffer
             self._cache = self._cache_buffer = None
@@ -220,9 +227,10 @@ class DeviceTaskMixin:
             buffers[b] = self._cache_buffer
             piece = cache[pos - c0:pos - c0 + n]
             target = out[done:done + n]
+            src = piece.ptr                  # (orders the current stream after a deferred producer)
             computed.record()
             down.wait(computed)
-            hip.check(hip.lib().bbt_memcpy_d2h(target.ctypes.data, piece.ptr, piece.nbytes, down.handle))
+            hip.check(hip.lib().bbt_memcpy_d2h(target.ctypes.data, src, piece.nbytes, down.handle))
             gone[b] = host_pipeline.StreamEvent().record(down)
             self.offset = pos + n
         self._cache_buffer_b = buffers[(len(runs)) % 2]      # (the other one stays the cache's)
@@ -234,7 +242,12 @@ class DeviceTaskMixin:
 
     def read(self, count=None, out=None):
         count = self._prepare_read(count, out)
-        pipelined = host_pipeline.ENABLED and count > 0
+        # (page-locked results and the three-stream pipeline from 1 MiB on: below that the
+        # pinned block -- 2 MiB at least -- and the extra streams cost more than they hide)
+        row = np.dtype(self._device_dtype).itemsize
+        for d in self.sample_shape:
+            row *= d
+        pipelined = host_pipeline.ENABLED and count * row >= (1 << 20)
         if out is None:
             empty = host_pipeline.pinned_empty if pipelined else np.empty
             out = empty((count,) + tuple(self.sample_shape), dtype=self._device_dtype)

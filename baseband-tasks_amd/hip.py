@@ -58,6 +58,7 @@ SIGNATURES = {
     'bbt_stream_sync': [_vp],
     'bbt_device_sync': [],
     'bbt_event_create': [_pvp],
+    'bbt_event_create_ordering': [_pvp],
     'bbt_event_destroy': [_vp],
     'bbt_event_record': [_vp, _vp],
     'bbt_event_sync': [_vp],
@@ -69,11 +70,10 @@ SIGNATURES = {
     'bbt_osm_plan_destroy': [_vp],
     'bbt_osm_plan_info': [_vp, _pi64, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)],
     'bbt_osm_plan_fusable': [_vp, _int],
+    'bbt_osm_plan_defer': [_vp, _vp],
     'bbt_osm_execute': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
-    'bbt_osm_execute_prefiltered': [_vp, _vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _vp],
     'bbt_osm_execute_flat': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
     'bbt_osm_plan_set_layout': [_vp, _i64, _i64],
-    'bbt_osm_execute_dechan_flat': [_vp, _vp, _vp, _int, _i64, _pi64, _pi64, _pi32, _i32, _pi32, _vp],
     'bbt_osm_execute_channelized': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int, _i64,
                                     _i64, _vp],
     'bbt_osm_execute_channelized_detect': [_vp, _vp, _vp, _i64, _pi64, _pi64, _pi32, _pi32, _int,
@@ -108,7 +108,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 136
+MIN_LIB_VERSION = 140
 
 _lib = None
 _lock = threading.Lock()
@@ -211,6 +211,7 @@ def device_name():
 # The stream all work of this package is queued on (a hipStream_t as int;
 # None / 0 = the default stream).  bench.py points it at torch's stream.
 _stream = None
+_NO_STREAM = object()
 
 
 def set_stream(stream):
@@ -267,17 +268,74 @@ def pool_info():
     return cached.value, live.value
 
 
+#: Plan calls whose output this package owns are issued with a deferred join
+#: (include/bbt_hip.h: bbt_osm_plan_defer): the stream is not ordered after the plan's lanes, so
+#: consecutive calls -- a reader taking run after run of frames -- flow into each other without
+#: a drain at the call boundary; the completion event travels with the output's allocation and
+#: is waited for by whatever touches that memory next (`DeviceArray.ptr`).  ``BBT_DEFER=0``:
+#: every call joins its stream (round 3's behaviour).
+DEFER_JOIN = os.environ.get('BBT_DEFER', '1') != '0'
+
+
+class _EventPool:
+    """Completion events of deferred plan calls: ordering events (no timing, no system-scope fence
+    -- streams wait for them, the host never does).  An event goes back to the pool as soon as the
+    wait for it has been queued: a stream's wait refers to the record that preceded it."""
+
+    def __init__(self):
+        self._idle = []
+        self._lock = threading.Lock()
+
+    def take(self):
+        with self._lock:
+            if self._idle:
+                return self._idle.pop()
+        h = C.c_void_p()
+        check(lib().bbt_event_create_ordering(C.byref(h)))
+        return h
+
+    def give(self, h):
+        with self._lock:
+            self._idle.append(h)
+
+
+_events = _EventPool()
+
+
+class _Pending:
+    """What a deferred plan call still owes an allocation: the event that marks its end and the
+    objects (its input, the plan) that must outlive it."""
+    __slots__ = ('event', 'keep')
+
+    def __init__(self, event, keep):
+        self.event = event
+        self.keep = keep
+
+
 class _Allocation:
-    """Owns one hipMalloc'ed block."""
+    """Owns one block of the device memory pool."""
+    pending = None              # _Pending of the deferred call that last wrote here, if any
 
     def __init__(self, nbytes):
         self.ptr = C.c_void_p()
         self.nbytes = int(nbytes)
         check(lib().bbt_malloc(C.byref(self.ptr), max(self.nbytes, 1)))
 
+    def settle(self, stream=_NO_STREAM):
+        """Order ``stream`` (default: the package's current stream) after the deferred call that
+        last wrote this block; from then on the block is an ordinary one of that stream."""
+        p = self.pending
+        if p is not None:
+            self.pending = None
+            check(lib().bbt_stream_wait_event(_stream if stream is _NO_STREAM else stream, p.event))
+            _events.give(p.event)
+
     def __del__(self):
         try:
             if self.ptr:
+                # (reuse of a freed block is ordered by the pool stream: it must come after the
+                # deferred writer too; the writer's inputs are released after this block)
+                self.settle()
                 lib().bbt_free(self.ptr)
                 self.ptr = None
         except Exception:
@@ -295,8 +353,25 @@ class DeviceArray:
         if ptr is None:
             owner = _Allocation(self.nbytes)
             ptr = owner.ptr.value
-        self.ptr = int(ptr) if ptr else 0
-        self.owner = owner
+        self._ptr = int(ptr) if ptr else 0
+        # (a view of a view is kept alive by -- and shares the pending state of -- the root)
+        self.owner = owner.owner if isinstance(owner, DeviceArray) else owner
+
+    @property
+    def ptr(self):
+        """Device address.  Asking for it is the announcement of a use: if a deferred plan call
+        still owes this memory (`_Allocation.pending`), the current stream is first ordered after
+        that call -- every binding, copy and interop path goes through here."""
+        o = self.owner
+        if o.__class__ is _Allocation and o.pending is not None:
+            o.settle()
+        return self._ptr
+
+    @property
+    def pending(self):
+        """Is a deferred plan call still writing this array's allocation (not yet waited for)?"""
+        o = self.owner
+        return o.__class__ is _Allocation and o.pending is not None
 
     @property
     def size(self):
@@ -327,7 +402,7 @@ class DeviceArray:
             raise ValueError("DeviceArray slices must be contiguous")
         stop = max(stop, start)
         return DeviceArray((stop - start,) + self.shape[1:], self.dtype,
-                           self.ptr + start * self.row_bytes, self.owner)
+                           self._ptr + start * self.row_bytes, self.owner)
 
     def reshape(self, *shape):
         if len(shape) == 1 and not isinstance(shape[0], int):
@@ -339,7 +414,7 @@ class DeviceArray:
                 if d != -1:
                     known *= d
             shape[shape.index(-1)] = self.size // known if known else 0
-        out = DeviceArray(shape, self.dtype, self.ptr, self.owner)
+        out = DeviceArray(shape, self.dtype, self._ptr, self.owner)
         if out.size != self.size:
             raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
         return out
@@ -392,7 +467,7 @@ class DeviceArray:
                     version=3, strides=None)
 
     def __repr__(self):
-        return f"<DeviceArray shape={self.shape} dtype={self.dtype} ptr=0x{self.ptr:x}>"
+        return f"<DeviceArray shape={self.shape} dtype={self.dtype} ptr=0x{self._ptr:x}>"
 
 
 def as_device_array(obj):
@@ -545,6 +620,8 @@ class OsmPlan(_Plan):
             idx = idx_arr.ctypes.data_as(_pi32)
         check(lib().bbt_osm_plan_create(C.byref(self._h), self.n_fft, self.n_stream, n_resp,
                                         resp_ptr, on_dev, idx))
+        # (plans of more than one kernel run chunks of blocks on internal streams, the lanes)
+        self._has_lanes = self.info()['n1'] > 1
 
     def info(self):
         ws, chunk, n1, n2 = _i64(), _int(), _int(), _int()
@@ -560,68 +637,55 @@ class OsmPlan(_Plan):
         """Can `execute_channelized` take Channelize(n_chan) into the row pass?"""
         return bool(lib().bbt_osm_plan_fusable(self._h, int(n_chan)))
 
-    def execute(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
+    def _call(self, fn, in_dev, out_dev, *args):
+        """One execute entry point of the C ABI on (in_dev, out_dev).  When this package owns the
+        output's allocation and the plan has lanes, the call is issued with a deferred join
+        (`DEFER_JOIN`): its completion event is left with the output's allocation."""
+        src, dst = in_dev.ptr, out_dev.ptr          # (orders the stream after earlier deferred writers)
+        owner = out_dev.owner
+        if not (DEFER_JOIN and self._has_lanes and owner.__class__ is _Allocation):
+            check(fn(self._h, src, dst, *args, _stream))
+            return
+        ev = _events.take()
+        check(lib().bbt_osm_plan_defer(self._h, ev))
+        try:
+            check(fn(self._h, src, dst, *args, _stream))
+        except Exception:
+            lib().bbt_osm_plan_defer(self._h, None)         # (if the call never took it)
+            check(lib().bbt_event_record(ev, _stream))
+            _events.give(ev)
+            raise
+        owner.pending = _Pending(ev, (in_dev, self))
+
+    @staticmethod
+    def _descriptors(in_off, out_off, valid_start, valid_count):
         in_off = np.ascontiguousarray(in_off, dtype=np.int64)
         out_off = np.ascontiguousarray(out_off, dtype=np.int64)
         valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
         valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
         n = in_off.shape[0]
         assert out_off.shape == valid_start.shape == valid_count.shape == (n,)
-        check(lib().bbt_osm_execute(self._h, in_dev.ptr, out_dev.ptr, n,
-                                    in_off.ctypes.data_as(_pi64), out_off.ctypes.data_as(_pi64),
-                                    valid_start.ctypes.data_as(_pi32),
-                                    valid_count.ctypes.data_as(_pi32), _stream))
+        return (n, in_off.ctypes.data_as(_pi64), out_off.ctypes.data_as(_pi64),
+                valid_start.ctypes.data_as(_pi32), valid_count.ctypes.data_as(_pi32)), \
+            (in_off, out_off, valid_start, valid_count)
+
+    def execute(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
+        desc, _alive = self._descriptors(in_off, out_off, valid_start, valid_count)
+        self._call(lib().bbt_osm_execute, in_dev, out_dev, *desc)
 
     def execute_flat(self, in_dev, out_dev, in_off, out_elem_off, valid_start, first_elem, valid_elems):
         """`execute` with the kept range in elements of the (row, stream) matrix (plans of one
         kernel: power-of-two n_fft <= 4096): see bbt_osm_execute_flat."""
-        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
-        out_elem_off = np.ascontiguousarray(out_elem_off, dtype=np.int64)
-        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
-        valid_elems = np.ascontiguousarray(valid_elems, dtype=np.int32)
-        check(lib().bbt_osm_execute_flat(self._h, in_dev.ptr, out_dev.ptr, in_off.shape[0],
-                                         in_off.ctypes.data_as(_pi64), out_elem_off.ctypes.data_as(_pi64),
-                                         valid_start.ctypes.data_as(_pi32), int(first_elem),
-                                         valid_elems.ctypes.data_as(_pi32), _stream))
-
-    def execute_dechan_flat(self, spectra_dev, out_dev, n_chan, in_off, out_elem_off, valid_start, first_elem,
-                            valid_elems):
-        """`execute_flat` on blocks of spectra that are dechannelized on the way in: see
-        bbt_osm_execute_dechan_flat."""
-        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
-        out_elem_off = np.ascontiguousarray(out_elem_off, dtype=np.int64)
-        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
-        valid_elems = np.ascontiguousarray(valid_elems, dtype=np.int32)
-        check(lib().bbt_osm_execute_dechan_flat(self._h, spectra_dev.ptr, out_dev.ptr, int(n_chan), in_off.shape[0],
-                                                in_off.ctypes.data_as(_pi64), out_elem_off.ctypes.data_as(_pi64),
-                                                valid_start.ctypes.data_as(_pi32), int(first_elem),
-                                                valid_elems.ctypes.data_as(_pi32), _stream))
-
-    def execute_prefiltered(self, fir, in_dev, out_dev, in_off, out_off, valid_start, valid_count):
-        """`execute` on blocks that first pass through the direct filter
-        ``fir`` (a `FirPlan`): block b reads ``N + n_tap - 1`` input samples."""
-        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
-        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
-        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
-        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
-        check(lib().bbt_osm_execute_prefiltered(
-            self._h, fir._h, in_dev.ptr, out_dev.ptr, in_off.shape[0], in_off.ctypes.data_as(_pi64),
-            out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
-            valid_count.ctypes.data_as(_pi32), _stream))
+        (n, io, oo, vs, ve), _alive = self._descriptors(in_off, out_elem_off, valid_start, valid_elems)
+        self._call(lib().bbt_osm_execute_flat, in_dev, out_dev, n, io, oo, vs, int(first_elem), ve)
 
     def execute_channelized(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count,
                             n_chan, first_spectrum, n_spectra):
         """Fused Channelize: spectra [first_spectrum, +n_spectra) of the stream
         the blocks would produce (``out_off`` absolute in that stream)."""
-        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
-        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
-        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
-        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
-        check(lib().bbt_osm_execute_channelized(
-            self._h, in_dev.ptr, out_dev.ptr, in_off.shape[0], in_off.ctypes.data_as(_pi64),
-            out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
-            valid_count.ctypes.data_as(_pi32), int(n_chan), int(first_spectrum), int(n_spectra),
-            _stream))
+        desc, _alive = self._descriptors(in_off, out_off, valid_start, valid_count)
+        self._call(lib().bbt_osm_execute_channelized, in_dev, out_dev, *desc, int(n_chan),
+                   int(first_spectrum), int(n_spectra))
 
     def detect_bins_max(self, n_chan, step):
         """Integration bins one workgroup of the last pass would touch (<= 64
@@ -631,20 +695,13 @@ class OsmPlan(_Plan):
     def execute_channelized_detect(self, in_dev, out_dev, in_off, out_off, valid_start, valid_count,
                                    n_chan, first_spectrum, n_bins, step, mode, average=True):
         """Fused Channelize + Square/Power + Integrate(step): float32 bins."""
-        in_off = np.ascontiguousarray(in_off, dtype=np.int64)
-        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
-        valid_start = np.ascontiguousarray(valid_start, dtype=np.int32)
-        valid_count = np.ascontiguousarray(valid_count, dtype=np.int32)
-        check(lib().bbt_osm_execute_channelized_detect(
-            self._h, in_dev.ptr, out_dev.ptr, in_off.shape[0], in_off.ctypes.data_as(_pi64),
-            out_off.ctypes.data_as(_pi64), valid_start.ctypes.data_as(_pi32),
-            valid_count.ctypes.data_as(_pi32), int(n_chan), int(first_spectrum), int(n_bins),
-            int(step), int(mode), int(bool(average)), _stream))
+        desc, _alive = self._descriptors(in_off, out_off, valid_start, valid_count)
+        self._call(lib().bbt_osm_execute_channelized_detect, in_dev, out_dev, *desc, int(n_chan),
+                   int(first_spectrum), int(n_bins), int(step), int(mode), int(bool(average)))
 
     def execute_regular(self, in_dev, out_dev, n_blocks, in_off0, out_off0, hop, valid_start):
-        check(lib().bbt_osm_execute_regular(self._h, in_dev.ptr, out_dev.ptr, int(n_blocks),
-                                            int(in_off0), int(out_off0), int(hop),
-                                            int(valid_start), _stream))
+        self._call(lib().bbt_osm_execute_regular, in_dev, out_dev, int(n_blocks), int(in_off0),
+                   int(out_off0), int(hop), int(valid_start))
 
     def timing_enable(self, enable=True):
         """False/0 off, True/1 time the normal (two-lane) schedule, 2 isolated

@@ -47,7 +47,18 @@ class _PinnedPool:
         self.free = {}                      # nbytes -> [ptr, ...]
         self.cached = 0
         self.ranges = {}                    # ptr -> nbytes of every live or cached block
-        self.limit = int(float(os.environ.get('BBT_PINNED_POOL_GB', '48')) * 2**30)
+        # idle page-locked bytes kept at most: BBT_PINNED_POOL_GB, default 48 GB shared between the
+        # ranks of a node (one process per GPU: LOCAL_WORLD_SIZE), and never more than a quarter
+        # of the host's memory
+        limit = os.environ.get('BBT_PINNED_POOL_GB')
+        if limit is None:
+            limit = 48. / max(int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1), 1)
+            try:
+                ram = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
+                limit = min(limit, ram / 4 / 2**30)
+            except (ValueError, OSError):
+                pass
+        self.limit = int(float(limit) * 2**30)
 
     def take(self, nbytes):
         with self.lock:
@@ -117,7 +128,12 @@ def pinned_empty(shape, dtype=np.complex64):
     n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if n == 0:
         return np.empty(shape, dtype)
-    block = _PinnedBlock(-(-n // (2 << 20)) * (2 << 20))
+    try:
+        block = _PinnedBlock(-(-n // (2 << 20)) * (2 << 20))
+    except hip.HipError:
+        # (a memlock limit, or more than the host can lock: an ordinary array -- `read` then
+        # takes the synchronous path, as `is_pinned` says no)
+        return np.empty(shape, dtype)
     buf = (C.c_ubyte * n).from_address(block.ptr)
     buf._bbt_block = block                       # the array's base keeps the block alive
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
@@ -191,7 +207,7 @@ class StreamEvent:
 
     def __init__(self):
         self._h = C.c_void_p()
-        hip.check(hip.lib().bbt_event_create(C.byref(self._h)))
+        hip.check(hip.lib().bbt_event_create_ordering(C.byref(self._h)))
 
     def record(self, stream=None):
         handle = hip.get_stream() if stream is None else stream.handle
@@ -224,10 +240,10 @@ class HostUploader:
 
     ``fetch(start, count)`` returns the samples as a `hip.DeviceArray`, ordered
     before later work on the package's current stream; ``prefetch(start,
-    count)`` starts reading and uploading a range in the background (one at a
-    time), for the ``fetch`` of the same range that follows.  The host stream
-    is only ever touched by one thread at a time: ``fetch`` waits for a running
-    prefetch before anything else.
+    count)`` announces the range of the fetch after the next one, which is then
+    read and uploaded in the background while the caller computes.  The host
+    stream is only ever touched by one thread at a time: ``fetch`` waits for a
+    running load before anything else.  Every range is loaded once.
     """
 
     def __init__(self, ih):
@@ -237,17 +253,20 @@ class HostUploader:
         self._stream = Stream()
         self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='bbt-upload')
         self._device = hip.get_device() if hasattr(hip, 'get_device') else 0
-        self._pending = None            # (start, count, future)
+        self._pending = None            # (start, count, future): the one load in flight
+        self._announced = None          # (start, count) to load once the next fetch is served
+        self.loads = 0                  # `_load` calls so far (tests count them)
         self._staging = [None, None]    # page-locked staging arrays (streams that are not pinned themselves)
         self._staging_event = [None, None]
         self._turn = 0
 
     # -- the one place the host stream is read
-    def _load(self, start, count, after):
+    def _load(self, start, count, dev, after):
         ih = self._ih()
         up = _Upload()
         up.start, up.count, up.staging = start, count, None
         hip.set_device(self._device)
+        self.loads += 1
         shape = (count,) + self._row
         view = None
         if hasattr(ih, 'host_view'):
@@ -269,36 +288,50 @@ class HostUploader:
             if got is not view:
                 view[...] = got
             up.staging = slot
-        up.dev = hip.DeviceArray(shape, self._dtype)
-        if after is not None:
-            self._stream.wait(after)                      # the block's previous users (pool reuse)
-        hip.check(hip.lib().bbt_memcpy_h2d(up.dev.ptr, view.ctypes.data, view.nbytes, self._stream.handle))
+        up.dev = dev
+        self._stream.wait(after)                          # the block's previous users (pool reuse)
+        hip.check(hip.lib().bbt_memcpy_h2d(dev.ptr, view.ctypes.data, view.nbytes, self._stream.handle))
         up.event = StreamEvent().record(self._stream)
         if up.staging is not None:
             self._staging_event[up.staging] = up.event
         return up
 
     def _submit(self, start, count):
-        # device blocks come from the pool, whose reuse is ordered by the current stream: the upload
-        # must not start before what is queued there now (a freed block's last readers) has run
+        # Device blocks come from the pool, whose reuse is ordered by the current stream (the pool
+        # stream): a block freed a moment ago may still have readers queued there.  So the block
+        # is TAKEN HERE, on the calling thread, and the event the upload stream waits for is
+        # recorded after that: every reader of the block's previous life was queued before its
+        # free, hence before this event.  (Taking it later, in the worker, would let a block
+        # through that the main thread freed after the event -- the input of the run whose
+        # kernels it has just queued.)
+        dev = hip.DeviceArray((int(count),) + self._row, self._dtype)
         after = StreamEvent().record()
-        return self._worker.submit(self._load, int(start), int(count), after)
+        return self._worker.submit(self._load, int(start), int(count), dev, after)
 
     def prefetch(self, start, count):
+        """Announce the range the fetch AFTER the next one will ask for: its load is started as
+        soon as the next `fetch` has its own samples -- before the caller queues that run's
+        kernels, so the upload waits for the kernels of the run before only and overlaps this
+        run's.  (Started right away it would be in the way: the host stream is read by one
+        thread at a time, and the next fetch wants its own range first.)"""
         ih = self._ih()
-        if ih is None or self._pending is not None or count <= 0 or start < 0 or start + count > ih.shape[0]:
+        if ih is None or count <= 0 or start < 0 or start + count > ih.shape[0]:
             return
-        self._pending = (int(start), int(count), self._submit(start, count))
+        self._announced = (int(start), int(count))
 
     def fetch(self, start, count):
-        pending, self._pending = self._pending, None
+        key = (int(start), int(count))
         up = None
-        if pending is not None:
-            got = pending[2].result()                     # (also: the stream is free again)
-            if (pending[0], pending[1]) == (int(start), int(count)):
-                up = got
+        if self._pending is not None:
+            pending, self._pending = self._pending, None
+            got = pending[2].result()                     # (also: the host stream is free again)
+            if pending[:2] == key:
+                up = got                                  # (else: a read-ahead nobody came for)
         if up is None:
-            up = self._submit(start, count).result()
+            up = self._submit(*key).result()
+        announced, self._announced = self._announced, None
+        if announced is not None and announced != key:
+            self._pending = announced + (self._submit(*announced),)
         current_stream_wait(up.event)
         return up.dev
 
@@ -309,6 +342,7 @@ class HostUploader:
                 pending[2].result()
             except Exception:
                 pass
+        self._announced = None
         self._worker.shutdown(wait=True)
 
 

@@ -147,37 +147,15 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         (start, length) and per-block arrays (input start, absolute output
         sample, first kept block sample, kept count)."""
         spf, n = self.samples_per_frame, self._ih_samples_per_frame
-        frames = np.arange(first, last)
-        blocks = [self._block_start(m) for m in frames]
-        starts = np.array([b[0] for b in blocks], dtype=np.int64)
-        skips = np.array([b[1] for b in blocks], dtype=np.int64)
+        frames = np.arange(first, last, dtype=np.int64)
+        # `PaddedTaskBase._block_start` for all frames at once: the last frame is re-aligned to
+        # end with the input and skips what the frame before it has produced
+        wanted = frames * spf
+        starts = np.minimum(wanted, self.ih.shape[0] - n)
+        skips = wanted - starts
         counts = np.minimum(spf - skips, self.shape[0] - frames * spf)
         in0 = int(starts[0])
         return in0, int(starts[-1]) + n - in0, starts, frames * spf, self._keep_from + skips, counts
-
-    #: When the input is a `Convolve` (`Resample`, `ShiftAndResample`) that
-    #: filters directly in the time domain, that filter can run inside this
-    #: task's plan, block by block (libbbt_hip: bbt_osm_execute_prefiltered): the
-    #: filtered stream is then never stored (the result is the same, the direct
-    #: filter being block independent).  Off by default: measured on MI355X for
-    #: config 5 (8 streams, 129 taps) it is 9 % SLOWER than the two tasks in
-    #: turn, 5.06 against 5.59 G complete samples/s -- the overlap of the blocks
-    #: is filtered twice (+25 % filter work) and the VALU-bound filter does not
-    #: overlap the other lane's passes (no room for its waves beside a row
-    #: pass's 150-200 VGPRs); set BBT_FUSE_PREFILTER=1 to save the memory.
-    FUSE_PREFILTER = os.environ.get('BBT_FUSE_PREFILTER', '0') == '1'
-
-    def _prefilter_input(self):
-        """The upstream direct-FIR task whose filter this task can absorb, else None."""
-        from .convolution import Convolve
-        up = self.ih
-        if not (self.FUSE_PREFILTER and isinstance(up, Convolve)) or up.closed:
-            return None
-        if self._real or up._real or self._n_stream % 2 or up._n_stream != self._n_stream:
-            return None
-        if self._ih_samples_per_frame < 2048 or not up._use_fir():
-            return None
-        return up
 
     #: When the input is a `Convolve` (`Resample`) on its short-block route and both plans work on
     #: the same S >= 4 complex streams, the filtered stream -- which only the two plans see -- is
@@ -197,7 +175,7 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
         if self._real or up._real or s % 2 or s < 4 or up._n_stream != s:
             return None
         n = self._ih_samples_per_frame
-        if n & (n - 1) or not (1 << 17) <= n <= (1 << 20) or self._prefilter_input() is not None:
+        if n & (n - 1) or not (1 << 17) <= n <= (1 << 20):
             return None
         if up._short_blocks() is None or self._get_plan().info()['n1'] != 256:
             return None
@@ -205,9 +183,6 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
 
     def _input_span(self, first, last):
         in0, in_len = self._block_descriptors(first, last)[:2]
-        up = self._prefilter_input()
-        if up is not None:
-            return up.ih, in0, in_len + up._pad_start + up._pad_end
         up = self._planar_input()
         if up is not None:
             return (up.ih,) + up._short_blocks()._span_blocks(in0, in_len)[:2]
@@ -216,13 +191,6 @@ class SpectralMultiplyTask(DeviceTaskMixin, PaddedTaskBase):
     def _compute_frames(self, first, last, out):
         in0, in_len, starts, out_abs, keep, counts = self._block_descriptors(first, last)
         out_off = out_abs - first * self.samples_per_frame
-        up = self._prefilter_input()
-        if up is not None:
-            # sample i of the filtered stream is made of input samples [i, i + taps - 1]
-            taps_less_one = up._pad_start + up._pad_end
-            x = fetch_device(up.ih, in0, in_len + taps_less_one)
-            self._get_plan().execute_prefiltered(up._fir, x, out, starts - in0, out_off, keep, counts)
-            return
         up = self._planar_input()
         if up is not None:
             x = up.read_planar(in0, in_len)                   # (S / 2, in_len, 2)

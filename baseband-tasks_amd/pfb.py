@@ -1,6 +1,4 @@
 """Polyphase filter bank on the GPU (reference baseband_tasks/pfb.py:14-154)."""
-import os
-
 import numpy as np
 
 from . import hip
@@ -19,16 +17,6 @@ def sinc_hamming(n_tap, n_sample, sinc_scale=1.):
     n = n_tap * n_sample
     x = n_tap * sinc_scale * np.linspace(-0.5, 0.5, n, endpoint=False)
     return (np.sinc(x) * np.hamming(n)).reshape(n_tap, n_sample)
-
-
-#: InversePolyphaseFilterBank: dechannelize block by block inside the deconvolution call, into
-#: a staging buffer laid out for the transform along the block axis (bbt_osm_execute_dechan_flat)
-#: instead of reading the dechannelized stream of `Dechannelize`.  Built and measured in round 3
-#: (MI355X, 1024 channels x 2 streams, blocks of 4096 spectra): 47.7-49.7 against 51.4 G complete
-#: samples/s -- the deconvolution kernel gets faster (61 -> 51 us per block) but the transposing
-#: dechannelizer loses as much (21 -> 34 us) -- so it is off unless ``BBT_FUSE_DECHANNELIZE=1``
-#: (it does save the memory of the dechannelized stream).
-FUSE_DECHANNELIZE = os.environ.get('BBT_FUSE_DECHANNELIZE', '0') == '1'
 
 
 class _PaddedSource(PaddedTaskBase):
@@ -95,8 +83,7 @@ class PolyphaseFilterBank(_RowFFTTask):
     def _even(self, count):
         """One stream runs unpadded on the sliding-window kernels (n 256..2048 with
         4, 8, 12 or 16 taps); every other odd count is padded to even."""
-        if (count == 1 and self._n in (256, 512, 1024, 2048) and self._response.shape[0] in (4, 8, 12, 16)
-                and os.environ.get('BBT_PFB_WINDOW', '1') != '0'):
+        if count == 1 and self._n in (256, 512, 1024, 2048) and self._response.shape[0] in (4, 8, 12, 16):
             return 1
         return count + count % 2
 
@@ -349,17 +336,6 @@ class InversePolyphaseFilterBank(DeviceTaskMixin, PaddedTaskBase):
         flat_ok = (not self._real and geo['n1'] == 1 and 256 <= n_rows <= 4096 and not n_rows & (n_rows - 1)
                    and int(counts.max()) * s < 2**31 and (off * s) % 2 == 0
                    and (spf * s) % 2 == 0 and np.all((counts * s) % 2 == 0))
-        if (flat_ok and FUSE_DECHANNELIZE and n in (256, 512, 1024, 2048) and s % 2 == 0
-                and not self.dechannelized._mismatch):
-            # the spectra themselves go in: each block is dechannelized into a staging buffer of the
-            # plan, laid out for the transform along the block axis (the dechannelized stream, which
-            # that transform would read 16 or 32 bytes at a time out of rows of n * s * 8, is never
-            # stored)
-            spectra = fetch_device(self.dechannelized.ih, in0 // n, (int(starts[-1]) + n_in - in0) // n)
-            flat = out.reshape(out.shape[0], s)
-            plan.execute_dechan_flat(spectra, flat, n, (starts - in0) // n, (frames * spf - first * spf) * s,
-                                     keep // n, off * s, counts * s)
-            return
         x = fetch_device(self.dechannelized, in0, int(starts[-1]) + n_in - in0)
         if self._real:
             x = hip.real_to_complex(x)

@@ -101,6 +101,11 @@ int bbt_stream_destroy(bbt_stream stream);
 int bbt_stream_sync(bbt_stream stream);
 int bbt_device_sync(void);
 int bbt_event_create(bbt_event* ev);
+/* An event that only orders streams of this device among each other (bbt_stream_wait_event):
+ * no timing, and no system-scope fence when it is recorded -- a default event writes the caches
+ * back and invalidates them, which empties the Infinity Cache under whatever runs next.  Not for
+ * bbt_event_sync / bbt_event_elapsed_ms by a host that then reads device results. */
+int bbt_event_create_ordering(bbt_event* ev);
 int bbt_event_destroy(bbt_event ev);
 int bbt_event_record(bbt_event ev, bbt_stream stream);
 int bbt_event_sync(bbt_event ev);
@@ -122,7 +127,7 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  *               unpadded, two consecutive blocks side by side where a pair of
  *               streams would be (bbt_osm_execute, and
  *               bbt_osm_execute_channelized for 256 channels and up; no fused
- *               detection, no prefilter)
+ *               detection)
  *   n_resp      number of distinct response columns C
  *   resp        C x N complex64, FFT-natural order, UNSCALED
  *               (= Disperse.phase_factor, dispersion.py:115-129, or
@@ -133,7 +138,8 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  * A plan runs one execute call at a time: its work buffers, seam buffer and
  * events belong to the running call, so calls on one plan are serialised by a
  * mutex inside it on the host and, on the device, a call first makes its stream
- * wait for the end of the previous call (which may have run on another stream).
+ * wait for the end of the previous call (which may have run on another stream;
+ * consecutive deferred calls, bbt_osm_plan_defer, are the one exception).
  * Calls on different plans are independent.
  * bbt_osm_plan_create itself synchronises the device when
  * `resp` is a device pointer, so a response still being written on another
@@ -146,6 +152,23 @@ int bbt_osm_plan_destroy(bbt_osm_plan* plan);
  * processes per kernel launch. */
 int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* chunk_blocks,
                       int* n1, int* n2);
+/* Deferred join for the NEXT bbt_osm_execute* call on `plan` (that one call only, whatever
+ * becomes of it).  By default an execute call returns with `stream` ordered after all of its
+ * work: anything queued on `stream` afterwards sees the results.  A plan with lanes (block
+ * lengths above 4096) runs its kernels on internal streams, so that default costs a drain at
+ * every call boundary -- the lanes run empty, `stream` takes over, the next call's lanes start
+ * again: 2-4 % of a 768-block call on MI355X.  A reader that takes consecutive frames
+ * (base.py:427-436) does not need `stream` ordered after call i to issue call i + 1.  With a
+ * completion event handed in, the call leaves `stream` as it found it and records `done` where
+ * its work really ends (an internal stream, after the lanes and the seam pass of the fused
+ * channelizer): whoever consumes `out_dev` -- or frees or overwrites `in_dev` or `out_dev` --
+ * must first wait for `done` (bbt_stream_wait_event, bbt_event_sync).  Consecutive deferred
+ * calls on one plan flow into each other: lane order protects the work buffers, the seam
+ * buffer has two turns.  Calls that have no lanes to leave behind (one-kernel plans, the
+ * isolated timing mode) simply record `done` on `stream` at their end.  done == NULL cancels.
+ * The Python host layer uses this for every plan call whose output it owns (hip.py: the event
+ * travels with the DeviceArray and is waited for by the next thing that touches it). */
+int bbt_osm_plan_defer(bbt_osm_plan* plan, bbt_event done);
 /* 1 if bbt_osm_execute_channelized can take Channelize(n_chan) into this
  * plan's row pass (power-of-two block of two or three levels, n_chan a power
  * of two in [256, 4096] dividing the row length), else 0. */
@@ -181,31 +204,6 @@ int bbt_osm_execute_flat(bbt_osm_plan* plan, const void* in_dev, void* out_dev, 
  * (two-level plans with 256-point columns, n_fft 2^17 ... 2^20): the executes read their input
  * that way.  0, 0 restores the interleaved (n, S) layout.  The setting holds until changed. */
 int bbt_osm_plan_set_layout(bbt_osm_plan* plan, int64_t in_plane, int64_t out_plane);
-/* bbt_osm_execute_flat on blocks that are dechannelized on the way in: `spectra_dev` holds
- * (spectra, n_chan, S / n_chan) complex64 -- the channelized stream InversePolyphaseFilterBank
- * is given (pfb.py:157-232) -- and block b covers the n_fft spectra from in_off[b] on.  Per
- * chunk of blocks one kernel does Dechannelize (inverse transform over the channels, 1 / n_chan:
- * channelize.py:169-178) into a staging buffer of the plan, transposed so that the transform
- * along the block axis reads contiguous memory; the dechannelized stream is never stored.
- * n_chan in {256, 512, 1024, 2048}, S / n_chan even; the arithmetic is that of
- * bbt_chan_execute (direction +1) followed by bbt_osm_execute_flat. */
-int bbt_osm_execute_dechan_flat(bbt_osm_plan* plan, const void* spectra_dev, void* out_dev, int n_chan,
-                                int64_t n_blocks, const int64_t* in_off, const int64_t* out_elem_off,
-                                const int32_t* valid_start, int32_t first_elem,
-                                const int32_t* valid_elems, bbt_stream stream);
-/* The same with a short FIR in front of every block (Resample / Convolve with a
- * short response feeding Dedisperse): block b reads input
- * samples [in_off[b], in_off[b] + N + n_tap - 1) of `in_dev`, the filter
- * (bbt_fir_plan, same stream count) turns them into the N samples
- * sum_k response[k] in[i + n_tap - 1 - k] in a staging buffer of the plan, and
- * the block transform runs on those.  Equal to filtering the whole stream first
- * (convolution.py:116-120 is block independent) but the filtered stream never
- * reaches HBM and the filter (VALU bound) of one chunk overlaps the memory
- * bound passes of another. */
-int bbt_osm_execute_prefiltered(bbt_osm_plan* plan, const bbt_fir_plan* fir, const void* in_dev,
-                                void* out_dev, int64_t n_blocks, const int64_t* in_off,
-                                const int64_t* out_off, const int32_t* valid_start,
-                                const int32_t* valid_count, bbt_stream stream);
 /* Fused Channelize(Dedisperse(...), n_chan): as bbt_osm_execute, but instead
  * of the dedispersed samples it writes their channelization
  * (Channelize.task, channelize.py:73-74): spectrum s is the unnormalised FFT
@@ -215,7 +213,7 @@ int bbt_osm_execute_prefiltered(bbt_osm_plan* plan, const bbt_fir_plan* fir, con
  * in the output stream (out_off[b+1] == out_off[b] + valid_count[b]) wherever a
  * wanted spectrum straddles them.  n_chan: whatever bbt_osm_plan_fusable
  * accepts (a power of two, 256 <= n_chan <= row length n2 of
- * bbt_osm_plan_info, or 16..128 for blocks with 256 or 4096 columns or of three
+ * bbt_osm_plan_info, or 16..128 for blocks with 256 columns or of three
  * levels; power-of-two n_fft > 4096), valid_count >= n_chan; valid_start may be
  * anything, 0 included.  The dedispersed stream itself never exists in memory. */
 int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
@@ -254,10 +252,9 @@ int bbt_osm_execute_regular(bbt_osm_plan* plan, const void* in_dev, void* out_de
 int bbt_osm_timing_enable(bbt_osm_plan* plan, int enable);
 int bbt_osm_timing_read(bbt_osm_plan* plan, double ms[3], int64_t* launches);
 /* The same per pass, with the number of timed launches and the overlap-save
- * blocks they covered: in the stage schedule (each pass on a stream of its
- * own) only every BBT_OSM_TIMING_STRIDE-th launch carries events, so the
- * per-launch mean is ms[k] / launches[k] and the time per block
- * ms[k] / blocks[k]. */
+ * blocks they covered: only every BBT_OSM_TIMING_STRIDE-th (4) chunk of a lane
+ * carries events (they cost queue slots of their own), so the per-launch mean
+ * is ms[k] / launches[k] and the time per block ms[k] / blocks[k]. */
 int bbt_osm_timing_read_passes(bbt_osm_plan* plan, double ms[3], int64_t launches[3], int64_t blocks[3]);
 
 /* ---- channelizer: Channelize / Dechannelize -----------------------------

@@ -64,7 +64,7 @@ def test_argument_validation_reports_errors():
     assert lib.bbt_osm_detect_bins_max(None, 1024, 64) == -1
     assert lib.bbt_free(C.c_void_p(12345)) != 0 and b'not allocated' in lib.bbt_last_error()
     # entry points added in round 2
-    assert lib.bbt_osm_execute_prefiltered(None, None, None, None, 0, None, None, None, None, None) != 0
+    assert lib.bbt_osm_plan_defer(None, None) != 0 and b'null plan' in lib.bbt_last_error()
     assert lib.bbt_osm_plan_fusable(None, 1024) == 0
     raw = np.zeros(64, np.uint8)
     assert lib.bbt_unpack(raw.ctypes.data, raw.ctypes.data, 3, 64, 32, 2, 128, 2, 1, 0, None) != 0
@@ -94,7 +94,7 @@ def test_python_wrappers_raise():
         hip.ChanPlan(22, 2)
     assert hip.OsmPlan.fusable.__doc__
     d = hip.DeviceArray.__new__(hip.DeviceArray)      # views without touching the device
-    d.shape, d.dtype, d.ptr, d.owner = (10, 4), np.dtype(np.complex64), 1 << 20, None
+    d.shape, d.dtype, d._ptr, d.owner = (10, 4), np.dtype(np.complex64), 1 << 20, None
     v = d[2:5]
     assert v.shape == (3, 4) and v.ptr == (1 << 20) + 2 * 32 and v.nbytes == 96
     assert d.reshape(5, -1).shape == (5, 8)
