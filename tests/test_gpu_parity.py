@@ -213,8 +213,10 @@ def test_host_path_upload_never_lands_in_a_block_still_being_read():
     plain = ch2.read(out=np.empty(got.shape, got.dtype))          # (pageable result: synchronous copies)
     assert np.array_equal(got, plain)
     want, _ = orc.dedisperse(x[:2 * n_fft], 16e6, 1000., 1, 100., samples_per_frame=spf, ih_samples_per_frame=n_fft)
-    z = orc.channelize(want[:(want.shape[0] // 1024) * 1024], 1024)
-    assert_parity(got[:z.shape[0]], z, 'slow reader, runs of one frame')
+    # (the oracle on the first two blocks only: its second block is then the stream's re-aligned
+    # last one, so just the first frame is comparable)
+    nz = spf // 1024
+    assert_parity(got[:nz], orc.channelize(want[:nz * 1024], 1024), 'slow reader, runs of one frame')
 
 
 def test_pipeline_output_into_the_hdf5_sink(tmp_path):

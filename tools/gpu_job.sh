@@ -90,7 +90,7 @@ one)
             env $e timeout -k 10 300 python3 tools/bench_one.py $c $ARGS 2>> $OUT/one.err | tee -a $OUT/one.jsonl | python3 -c "
 import json,sys
 for l in sys.stdin:
-    d=json.loads(l); print('$c [$e]', d.get('value'), d.get('unit'), d.get('frac'))" || { say "$c failed"; tail -5 $OUT/one.err; exit 1; }
+    d=json.loads(l); print('$c [$e]', d.get('msamples_per_s'), 'Msamples/s', d.get('roofline_frac'))" || { say "$c failed"; tail -5 $OUT/one.err; exit 1; }
         done
       done
     done ;;
