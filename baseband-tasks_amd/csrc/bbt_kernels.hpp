@@ -749,20 +749,24 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     }
 }
 
-// Column pass, N1 == 256: FCOL two-stream columns (f, fastest lane index ->
-// FCOL * 16-byte runs per row: 256 B for 16, 512 B for 32) x 16 threads per
-// 256-point transform; FCOL * 16 threads per workgroup.
+// Column pass, N1 == 256 or 512: FCOL two-stream columns (f, fastest lane index ->
+// FCOL * 16-byte runs per row: 256 B for 16) x T1 = N1 / 16 threads per N1-point
+// transform; FCOL * T1 threads per workgroup.  (512 points: blocks of 2^21 samples as
+// 512 x 4096 -- three passes where the three-level scheme takes five; 8 columns per
+// workgroup, 48 KiB of exchange area, so that three workgroups share a CU.)
 // With many streams the FCOL lanes of a row can instead cover PP pairs x
 // FCOL / PP columns (PP > 1): the stream side then moves PP * 16 contiguous
 // bytes per complete sample (a whole 128-byte line for 8 pairs) at the price
 // of FCOL / PP * 16-byte runs on the work-buffer side.
-template <bool FIRST, bool SPEC, int FCOL, bool DET = false, int PP = 1, bool SINGLE = false>
-__global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restrict__ in,
+template <bool FIRST, bool SPEC, int FCOL, bool DET = false, int PP = 1, bool SINGLE = false, int N1 = 256>
+__global__ __launch_bounds__(FCOL * (N1 / 16)) void k_osm_col256(const float2* __restrict__ in,
                                                           float2* __restrict__ out,
                                                           float2* __restrict__ work, OsmChunk ch,
                                                           int S, int N2, const cf* __restrict__ tw0,
-                                                          SpecOut so) {
-    typedef FftGeo<256> G;
+                                                          SpecOut so, const cf* __restrict__ tw1 = nullptr) {
+    typedef FftGeo<N1> G;
+    constexpr int T1 = N1 / 16;                          // threads per column: row k1 = tau + T1 j
+    static_assert(!DET || N1 == 256, "fused detection: 256-point columns");
     extern __shared__ v2 col256_lds[];                   // G::LDS_ELEMS * FCOL elements
     v2* lds = col256_lds;
     static_assert(!DET || PP == 1, "fused detection needs the lanes of a row in one stream pair");
@@ -773,8 +777,8 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
     const int npg = npair / PP;                          // pair groups
     const int n2 = (vb / npg) * CPT + f / PP;
     const int b = blockIdx.y, sp = (vb % npg) * PP + f % PP;
-    // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*256 + k1)*N2 + n2
-    float2* w = work + (((long long)(b * npair + sp) * 256 + tau) * N2 + n2) * 2;
+    // work element (k1, n2) of this (block, pair): 16 bytes at ((b*npair+sp)*N1 + k1)*N2 + n2
+    float2* w = work + (((long long)(b * npair + sp) * N1 + tau) * N2 + n2) * 2;
     c2 v[16];
     if constexpr (SINGLE) {                              // b = pair of blocks of the one stream
         static_assert(!DET && PP == 1, "one-stream plans: no fused detection");
@@ -782,19 +786,19 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
         if (FIRST) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = ld_single_shifted(in, pr, (long long)(tau + 16 * j) * N2 + n2, 256ll * N2);
-            wg_fft<256, -1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
+                v[j] = ld_single_shifted(in, pr, (long long)(tau + T1 * j) * N2 + n2, (long long)N1 * N2);
+            wg_fft<N1, -1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, tw1);
             if (so.twa) col_twiddles<-1>(v, so.twa, so.twg, tau, n2, N2);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
+            for (int j = 0; j < 16; ++j) st_int(w + (long long)T1 * j * N2 * 2, v[j]);
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+            for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)T1 * j * N2 * 2);
             if (so.twa) col_twiddles<+1>(v, so.twa, so.twg, tau, n2, N2);
-            wg_fft<256, +1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
+            wg_fft<N1, +1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, tw1);
             if constexpr (SPEC) {
-                const SpecCursor ca = spec_cursor(out, so, pr.a, tau, 16, N2, n2, 1, 0, 1);
-                const SpecCursor cb = spec_cursor(out, so, pr.b, tau, 16, N2, n2, 1, 0, 1);
+                const SpecCursor ca = spec_cursor(out, so, pr.a, tau, T1, N2, n2, 1, 0, 1);
+                const SpecCursor cb = spec_cursor(out, so, pr.b, tau, T1, N2, n2, 1, 0, 1);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     emit_spectrum_single(make_float2(v[j].re.x, v[j].im.x), ca, j);
@@ -802,43 +806,43 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)(tau + 16 * j) * N2 + n2, v[j]);
+                for (int j = 0; j < 16; ++j) st_single(out, pr, (long long)(tau + T1 * j) * N2 + n2, v[j]);
             }
         }
         return;
     }
     const OsmBlock blk = ch.b[b];
     if (FIRST) {
-        // read circularly shifted by blk.shift (see k_osm_col16): row 255 can wrap
+        // read circularly shifted by blk.shift (see k_osm_col16): the last row can wrap
         // (pair-planar input: this pair's samples are an array of their own, see OsmChunk)
         const int Si = ch.in_plane ? 2 : S;
         const float2* src = in + (ch.in_plane ? (long long)sp * ch.in_plane * 2 : 2 * sp) +
                             (blk.in_off + (long long)tau * N2 + n2 + blk.shift) * Si;
-        const long long wrap = (tau == 15 && n2 + blk.shift >= N2) ? (long long)256 * N2 * Si : 0;
+        const long long wrap = (tau == T1 - 1 && n2 + blk.shift >= N2) ? (long long)N1 * N2 * Si : 0;
         if (Si == 2) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = ld_ext_nt(src + (long long)16 * j * N2 * 2 - (j == 15 ? wrap : 0));
+                v[j] = ld_ext_nt(src + (long long)T1 * j * N2 * 2 - (j == 15 ? wrap : 0));
         } else if (S == 2) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = ld_ext_nt(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
+                v[j] = ld_ext_nt(src + (long long)T1 * j * N2 * S - (j == 15 ? wrap : 0));
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = ld_ext(src + (long long)16 * j * N2 * S - (j == 15 ? wrap : 0));
+                v[j] = ld_ext(src + (long long)T1 * j * N2 * S - (j == 15 ? wrap : 0));
         }
-        wg_fft<256, -1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
+        wg_fft<N1, -1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, tw1);
         if (so.twa) col_twiddles<-1>(v, so.twa, so.twg, tau, n2, N2);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) st_int(w + (long long)16 * j * N2 * 2, v[j]);
+        for (int j = 0; j < 16; ++j) st_int(w + (long long)T1 * j * N2 * 2, v[j]);
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)16 * j * N2 * 2);
+        for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)T1 * j * N2 * 2);
         if (so.twa) col_twiddles<+1>(v, so.twa, so.twg, tau, n2, N2);
-        wg_fft<256, +1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, nullptr);
+        wg_fft<N1, +1, FCOL, 0, BBT_COL_TW_POW>(v, lds, tau, f, tw0, tw1);
         SpecCursor cur;
-        if (SPEC) cur = spec_cursor(out, so, blk, tau, 16, N2, small_channel_slot(n2, so), S, sp, npair);
+        if (SPEC) cur = spec_cursor(out, so, blk, tau, T1, N2, small_channel_slot(n2, so), S, sp, npair);
         if constexpr (SPEC && DET) {
             // Detection + integration instead of storing spectra.  The workgroup
             // holds, for each of its FCOL channels, every (N2 / n_chan)-th of
@@ -913,7 +917,7 @@ __global__ __launch_bounds__(FCOL * 16) void k_osm_col256(const float2* __restri
             if (SPEC) {
                 emit_spectrum(v[j], cur, j);
             } else {
-                const long long r = (long long)(tau + 16 * j) * N2 + n2 - blk.valid_start;
+                const long long r = (long long)(tau + T1 * j) * N2 + n2 - blk.valid_start;
                 if (r >= 0 && r < blk.valid_count)
                     st_ext(out + ((blk.out_off + r) * S + 2 * sp), v[j], S == 2);
             }

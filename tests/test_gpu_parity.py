@@ -1480,8 +1480,8 @@ def test_convolve_on_short_blocks_matches_numpy_and_direct_filter(shape):
 
 
 def test_blocks_longer_than_2_20_with_sixteen_streams():
-    """2^21-sample blocks x 16 streams: plain and fused-channelizer outputs (256
-    and 64 channels), pair-grouped column passes; three levels, 256 x 16 x 512."""
+    """2^21-sample blocks x 16 streams: plain and fused-channelizer outputs (256,
+    64 and 16 channels); two levels, 512 x 4096 (the 512-point column pass)."""
     n_fft = 2**21
     freq = (400. + 6.25 * np.arange(8)).reshape(8, 1) * u.MHz
     nh = noise(n_fft + 300000, (8, 2), 2**19, seed=63, fs=6.25 * u.MHz, frequency=freq, sideband=1)
@@ -1494,7 +1494,7 @@ def test_blocks_longer_than_2_20_with_sixteen_streams():
     with bt.fft_maker.set(pow2):
         dd = bt.Dedisperse(nh, dm, reference_frequency=freq)
         assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
-        assert dd._get_plan().info()['n1'] == 16
+        assert dd._get_plan().info()['n1'] == 512
         assert_parity(dd.read(), want, 'dedisperse, 16 streams')
         ds = bt.DeviceStream(x, T0, 6.25 * u.MHz, frequency=freq, sideband=1)     # (re-reading the noise
         for n in (256, 64, 16):                                                      # generator per call is slow)
@@ -1801,7 +1801,8 @@ def test_random_fused_channelizer_geometries():
     (2**18, 1024, False),      # 256 x 1024
     (2**18, 1024, True),       # ... with the powers summed in the last pass
     (2**20, 4096, False),      # 256 x 4096
-    (2**21, 512, False),       # three levels, 256 x 16 x 512
+    (2**21, 512, False),       # 512 x 4096 (512-point column pass)
+    (2**22, 512, False),       # three levels, 256 x 16 x 1024
 ])
 def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
     """When n_chan exceeds the block's padding, the last n_chan-aligned group of a
@@ -2454,29 +2455,42 @@ def test_this_library_and_torch_share_one_hip_runtime_in_either_import_order():
     """PyTorch bundles its own ROCm runtime; two runtimes in one process leave the
     second without a GPU ("No HIP GPUs are available" when this library came
     first).  hip.lib() therefore loads torch's copy first when torch is installed:
-    both orders work, and only one libamdhip64 is mapped."""
+    both orders work, and only one libamdhip64 is mapped.
+
+    Timing (round 4, `tools/import_order.py` on the MI355X box): ``import torch`` takes 0.7 s
+    before the HIP runtime is initialised and 3-11 s after it -- a runtime that is already up
+    digests the fat binaries of libtorch_hip.so (gigabytes of device code) as they register
+    instead of on first use, i.e. it reads them all.  On a box whose page cache is cold that read
+    is what took more than 300 s once in round 3 (the child was killed inside ``import torch``;
+    no lock is involved).  Hence: torch-first runs first (it pages torch in the cheap way), the
+    child dumps its stacks after 240 s should it ever sit anywhere that long, and the limit is
+    back at 300 s per order."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = '''
-import sys
+import faulthandler, sys, time
+faulthandler.dump_traceback_later(240, exit=False)
 sys.path.insert(0, %r)
 order = sys.argv[1]
+t0 = time.time()
 if order == "torch-first":
     import torch
     t = torch.ones(4, device="cuda")
 import baseband_tasks_amd as bt
 a = bt.hip.DeviceArray.from_host(__import__("numpy").arange(4, dtype="float32"))
+t1 = time.time()
 if order == "lib-first":
     import torch
+    print("import torch after the runtime was up: %%.1f s" %% (time.time() - t1), file=sys.stderr)
     t = torch.ones(4, device="cuda")
 assert float(t.sum()) == 4. and a.to_host().sum() == 6.
 maps = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
 assert len(maps) == 1, maps
 print("one runtime:", maps[0])
 ''' % root
-    for order in ('lib-first', 'torch-first'):
-        done = subprocess.run([sys.executable, '-c', script, order], capture_output=True, text=True, timeout=900)
+    for order in ('torch-first', 'lib-first'):
+        done = subprocess.run([sys.executable, '-c', script, order], capture_output=True, text=True, timeout=300)
         assert done.returncode == 0 and 'one runtime:' in done.stdout, (order, done.stdout[-500:], done.stderr[-1500:])
 
 
