@@ -758,6 +758,25 @@ static int osm_flush_timing(bbt_osm_plan* p) {
     return 0;
 }
 
+template <bool FIRST, bool SPEC, int N1>
+static int launch_col_long(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
+                           const OsmChunk& ch, int row_len, const SpecOut& so, hipStream_t st) {
+    constexpr int F = 8;
+    constexpr size_t lds = FftGeo<N1>::LDS_ELEMS * sizeof(v2) * F;
+    if (p->single) {
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, F, false, 1, true, N1>, lds)) return 1;
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, F, false, 1, true, N1>),
+                           dim3(row_len / F, (ch.nblk + 1) / 2), dim3(F * (N1 / 16)), lds, st, in, out, work,
+                           ch, 1, row_len, p->tab1.tw0, so, p->tab1.tw1);
+    } else {
+        if (ensure_dyn_lds((const void*)k_osm_col256<FIRST, SPEC, F, false, 1, false, N1>, lds)) return 1;
+        hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, F, false, 1, false, N1>),
+                           dim3(row_len / F * p->npair, ch.nblk), dim3(F * (N1 / 16)), lds, st, in, out, work,
+                           ch, p->S, row_len, p->tab1.tw0, so, p->tab1.tw1);
+    }
+    return 0;
+}
+
 template <bool FIRST, bool SPEC>
 static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2* work,
                           const OsmChunk& ch, int row_len, const SpecOut& so_arg, hipStream_t st) {
@@ -769,21 +788,11 @@ static int launch_col256(bbt_osm_plan* p, const float2* in, float2* out, float2*
         so.twa = p->twa;
         so.twg = p->twg;
     }
-    if (p->n1 == 512) {
-        // 512-point columns (2^21-sample blocks): 8 columns per workgroup, 128-byte runs
+    if (p->n1 == 512 || p->n1 == 1024) {
+        // 512- / 1024-point columns (2^21- / 2^22-sample blocks): 8 columns per workgroup, 128-byte runs
         if (so.det) return fail("osm: fused detection needs 256-point columns");
-        constexpr int F = 8;
-        constexpr size_t lds512 = FftGeo<512>::LDS_ELEMS * sizeof(v2) * F;
-        if (p->single) {
-            hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, F, false, 1, true, 512>),
-                               dim3(row_len / F, (ch.nblk + 1) / 2), dim3(F * 32), lds512, st, in, out, work,
-                               ch, 1, row_len, p->tab1.tw0, so, p->tab1.tw1);
-        } else {
-            hipLaunchKernelGGL((k_osm_col256<FIRST, SPEC, F, false, 1, false, 512>),
-                               dim3(row_len / F * p->npair, ch.nblk), dim3(F * 32), lds512, st, in, out, work,
-                               ch, p->S, row_len, p->tab1.tw0, so, p->tab1.tw1);
-        }
-        return 0;
+        return p->n1 == 512 ? launch_col_long<FIRST, SPEC, 512>(p, in, out, work, ch, row_len, so, st)
+                            : launch_col_long<FIRST, SPEC, 1024>(p, in, out, work, ch, row_len, so, st);
     }
     if (p->single) {
         if (so.det) return fail("osm: one-stream plans have no fused detection");
@@ -1194,6 +1203,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         // (A 512-point column pass holds 8 columns in 48 KiB of exchange area, three workgroups
         // per CU; the row pass is the 4096-point one of the 2^20 blocks.)
         p->n1 = 512;
+    } else if (n_fft == (1 << 22)) {
+        p->n1 = 1024;            // 1024 x 4096, likewise (8 columns: 80 KiB, two workgroups per CU)
     } else {
         p->outer = 256;          // three levels, 256 x 16 x N2
         p->n1 = 16;
@@ -1218,9 +1229,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     } else {
         if (get_tables(p->n2, &p->tab2)) return bail(1);
         if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
-        if (p->n1 == 512 && get_tables(512, &p->tab1)) return bail(1);
+        if ((p->n1 == 512 || p->n1 == 1024) && get_tables(p->n1, &p->tab1)) return bail(1);
         if (get_wroot(&p->wroot)) return bail(1);
-        if ((p->n1 == 16 || p->n1 == 256 || p->n1 == 512) && (p->outer == 1 || p->outer == 256)) {
+        if ((p->n1 == 16 || p->n1 == 256 || p->n1 == 512 || p->n1 == 1024) && (p->outer == 1 || p->outer == 256)) {
             // (three-level plans: these are the twiddles of the inner transform of n1 * n2 points)
             const int t = p->n2 / 16;
             const long long inner = (long long)p->n1 * p->n2;
@@ -1247,7 +1258,7 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             }
             // twiddles in the column passes: only with 256- / 512-point columns (T1 = n1 / 16 threads
             // per column, thread tau holds rows tau + T1 j: factors a g^j, a = W_N^{tau n2}, g = W_N^{T1 n2})
-            if ((p->n1 == 256 || p->n1 == 512) && p->outer == 1) {
+            if (p->n1 >= 256 && p->outer == 1) {
                 const int t1 = p->n1 / 16;
                 std::vector<cf> a((size_t)t1 * p->n2), g((size_t)4 * p->n2);
                 for (int n2 = 0; n2 < p->n2; ++n2) {
@@ -1411,7 +1422,7 @@ int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     if (p->single)              // one stream: blocks side by side; 256 channels and up, no detection
         return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
     if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
-        return p->n1 == 256 || p->n1 == 512 || p->outer == 256;             // exchange in the row pass
+        return p->n1 >= 256 || p->outer == 256;                             // exchange in the row pass
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
 }
 

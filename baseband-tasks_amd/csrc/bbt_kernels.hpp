@@ -749,11 +749,11 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
     }
 }
 
-// Column pass, N1 == 256 or 512: FCOL two-stream columns (f, fastest lane index ->
+// Column pass, N1 == 256, 512 or 1024: FCOL two-stream columns (f, fastest lane index ->
 // FCOL * 16-byte runs per row: 256 B for 16) x T1 = N1 / 16 threads per N1-point
-// transform; FCOL * T1 threads per workgroup.  (512 points: blocks of 2^21 samples as
-// 512 x 4096 -- three passes where the three-level scheme takes five; 8 columns per
-// workgroup, 48 KiB of exchange area, so that three workgroups share a CU.)
+// transform; FCOL * T1 threads per workgroup.  (512 / 1024 points: blocks of 2^21 / 2^22
+// samples as N1 x 4096 -- three passes where the three-level scheme takes five; 8 columns per
+// workgroup, 48 / 80 KiB of exchange area, so that three / two workgroups share a CU.)
 // With many streams the FCOL lanes of a row can instead cover PP pairs x
 // FCOL / PP columns (PP > 1): the stream side then moves PP * 16 contiguous
 // bytes per complete sample (a whole 128-byte line for 8 pairs) at the price

@@ -1802,7 +1802,8 @@ def test_random_fused_channelizer_geometries():
     (2**18, 1024, True),       # ... with the powers summed in the last pass
     (2**20, 4096, False),      # 256 x 4096
     (2**21, 512, False),       # 512 x 4096 (512-point column pass)
-    (2**22, 512, False),       # three levels, 256 x 16 x 1024
+    (2**22, 2048, False),      # 1024 x 4096 (1024-point column pass)
+    (2**23, 512, False),       # three levels, 256 x 16 x 2048
 ])
 def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
     """When n_chan exceeds the block's padding, the last n_chan-aligned group of a
