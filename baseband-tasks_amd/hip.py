@@ -302,19 +302,35 @@ class _EventPool:
 _events = _EventPool()
 
 
-class _Pending:
-    """What a deferred plan call still owes an allocation: the event that marks its end and the
-    objects (its input, the plan) that must outlive it."""
-    __slots__ = ('event', 'keep')
+class _Done:
+    """The completion event of one deferred plan call, shared by the allocations the call reads
+    and writes; back to the pool once each of them has queued its wait."""
+    __slots__ = ('event', 'refs')
 
-    def __init__(self, event, keep):
+    def __init__(self, event, refs):
         self.event = event
+        self.refs = refs
+
+    def release(self):
+        self.refs -= 1
+        if self.refs == 0:
+            _events.give(self.event)
+
+
+class _Pending:
+    """What a deferred plan call still owes an allocation -- it is writing it, or reading it --:
+    the event that marks the call's end and the objects (the input, the plan) that must outlive
+    the call."""
+    __slots__ = ('done', 'keep')
+
+    def __init__(self, done, keep):
+        self.done = done
         self.keep = keep
 
 
 class _Allocation:
     """Owns one block of the device memory pool."""
-    pending = None              # _Pending of the deferred call that last wrote here, if any
+    pending = None              # _Pending of the deferred call that last wrote or read here, if any
 
     def __init__(self, nbytes):
         self.ptr = C.c_void_p()
@@ -323,12 +339,12 @@ class _Allocation:
 
     def settle(self, stream=_NO_STREAM):
         """Order ``stream`` (default: the package's current stream) after the deferred call that
-        last wrote this block; from then on the block is an ordinary one of that stream."""
+        last wrote or read this block; from then on the block is an ordinary one of that stream."""
         p = self.pending
         if p is not None:
             self.pending = None
-            check(lib().bbt_stream_wait_event(_stream if stream is _NO_STREAM else stream, p.event))
-            _events.give(p.event)
+            check(lib().bbt_stream_wait_event(_stream if stream is _NO_STREAM else stream, p.done.event))
+            p.done.release()
 
     def __del__(self):
         try:
@@ -369,7 +385,8 @@ class DeviceArray:
 
     @property
     def pending(self):
-        """Is a deferred plan call still writing this array's allocation (not yet waited for)?"""
+        """Is a deferred plan call still writing or reading this array's allocation (nobody has
+        waited for it yet)?"""
         o = self.owner
         return o.__class__ is _Allocation and o.pending is not None
 
@@ -655,7 +672,16 @@ class OsmPlan(_Plan):
             check(lib().bbt_event_record(ev, _stream))
             _events.give(ev)
             raise
-        owner.pending = _Pending(ev, (in_dev, self))
+        # The call's end is owed to the output (it is being written) and to the input (it is being
+        # read: whoever overwrites it next -- the upstream task filling its cache again -- or frees
+        # it must come after the lanes).  The input of a foreign owner (a torch tensor) is the
+        # caller's to keep untouched, as include/bbt_hip.h says.
+        src_owner = in_dev.owner
+        shared = src_owner.__class__ is _Allocation and src_owner is not owner
+        done = _Done(ev, 2 if shared else 1)
+        owner.pending = _Pending(done, (src_owner, self))
+        if shared:
+            src_owner.pending = _Pending(done, (self,))
 
     @staticmethod
     def _descriptors(in_off, out_off, valid_start, valid_count):

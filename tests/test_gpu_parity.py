@@ -219,6 +219,45 @@ def test_host_path_upload_never_lands_in_a_block_still_being_read():
     assert_parity(got[:nz], orc.channelize(want[:nz * 1024], 1024), 'slow reader, runs of one frame')
 
 
+def test_deferred_calls_do_not_let_the_upstream_task_overwrite_what_the_lanes_still_read(monkeypatch):
+    """Plan calls are issued with a deferred join (hip.DEFER_JOIN): the stream is not ordered after
+    the lanes.  The input of such a call is the upstream task's cache, which that task fills again
+    for the next run -- on the stream, i.e. possibly while the lanes of the previous run still read
+    it.  The call's completion event therefore stays with the INPUT's allocation too, and the
+    upstream task waits for it (or switches to its second buffer) before it writes.  A direct filter (a single kernel on the stream)
+    in front of a dedispersion on 2^20-sample blocks, read run after run: same bits as with every
+    call joined."""
+    n_fft = 2**20
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal((14 * n_fft, 4), dtype=np.float32).view(np.complex64)
+    taps = rng.standard_normal(9).astype(np.float32)
+    ds = bt.DeviceStream(x, T0, 16 * u.MHz, samples_per_frame=n_fft, frequency=1000 * u.MHz, sideband=1)
+
+    def chain():
+        cv = bt.Convolve(ds, taps, samples_per_frame=n_fft)
+        assert cv._use_fir()
+        dd = bt.Dedisperse(cv, 100.)
+        cv.max_frames_per_call = 6
+        dd.max_frames_per_call = 4
+        return cv, dd
+    assert bt.hip.DEFER_JOIN
+    cv, dd = chain()
+    pieces, buffers, starts = [], set(), []
+    dd.seek(0)
+    while dd.tell() < dd.shape[0]:
+        starts.append(dd.tell())
+        # (nothing touches a piece before the next run is queued: the window stays open)
+        pieces.append(dd.read_device(min(4 * dd.samples_per_frame, dd.shape[0] - dd.tell())))
+        buffers.add(dd._cache_buffer._ptr)
+    assert len(pieces) >= 4 and len(buffers) == 2          # (the cache alternates while a call is owed)
+    last_two = [p.to_host() for p in pieces[-2:]]           # (earlier ones have been overwritten since)
+    monkeypatch.setattr(bt.hip, 'DEFER_JOIN', False)
+    cv, dd = chain()
+    whole = dd.read()
+    for piece, start in zip(last_two, starts[-2:]):
+        assert np.array_equal(piece, whole[start:start + piece.shape[0]])
+
+
 def test_pipeline_output_into_the_hdf5_sink(tmp_path):
     """SURVEY 8f rank 3, downstream side: a task's output goes into the reference's intermediate HDF5
     format the way the reference writes it -- ``task.read(out=writer)``, the writer taking slices in order
