@@ -487,6 +487,72 @@ def verify_config4(x, z, freq_mhz, n_blocks, n_spec, spf):
 
 
 # ---------------------------------------------------------------------------
+def _inject(what):
+    """BBT_BENCH_INJECT=bcast,gather: make that collective fail on every rank (tests of the
+    fall-backs below: the sharded `value` must stand without either)."""
+    if what in os.environ.get('BBT_BENCH_INJECT', '').split(','):
+        raise RuntimeError(f'injected {what} failure (BBT_BENCH_INJECT)')
+
+
+def chirp_shared_or_local(share, local, rank):
+    """The chirp hand-out with its fall-back: ``share()`` (rank 0 evaluates, one broadcast) or, if
+    that raises, ``local()`` (every rank evaluates its own: same values, no collective).  Returns
+    True when the broadcast was used."""
+    try:
+        _inject('bcast')
+        share()
+        return True
+    except Exception as exc:          # the measurement stands without it
+        print(f'bench.py: rank {rank}: chirp broadcast failed ({type(exc).__name__}: {exc}); '
+              'computing it locally', file=sys.stderr)
+        local()
+        return False
+
+
+def gathered_or_error(timed_gather, after_failure=None):
+    """The `with_gather` object: the timed steps that end with the all-gather, or -- the sharded
+    `value` stands either way -- a record of why they are missing."""
+    try:
+        _inject('gather')
+        return timed_gather()
+    except Exception as exc:
+        if after_failure is not None:
+            after_failure()
+        return dict(error=f'{type(exc).__name__}: {exc}'[:300])
+
+
+def headline_collectives(world, blocks, backend='nccl'):
+    """What a headline run of `world` ranks sends, and which bound applies (DESIGN, multi-GPU):
+    per rank one chirp broadcast at plan time, nothing on the data path; the optional gather of the
+    channelized outputs is timed separately."""
+    spf = N_FFT - PAD_START - PAD_END
+    n_spec = ((blocks * spf) // N_CHAN // 512) * 512
+    out_bytes = n_spec * N_CHAN * 2 * 8                   # complex64 spectra of 2 pol per rank and step
+    link = 153e9                                          # one xGMI link, bytes/s
+    per_gpu = 50e9                                        # complete samples/s one GPU computes (measured order)
+    return dict(
+        layout=f'time: every rank takes its own {blocks} consecutive overlap-save blocks (weak scaling)',
+        calls=[dict(op='broadcast', what='chirp (C x N complex64) + column index', root=0,
+                    bytes=int(N_FFT * 8 + 2 * 4), when='plan creation, once',
+                    through='bbt_bcast_chirp' if os.environ.get('BBT_BENCH_COMM') == 'cabi' and backend == 'nccl'
+                    else f'torch.distributed.broadcast ({"RCCL" if backend == "nccl" else backend})'),
+               dict(op='all_gather', what='channelized spectra', bytes_sent_per_rank_per_step=int(out_bytes),
+                    bytes_received_per_rank_per_step=int(out_bytes * (world - 1)),
+                    when='with_gather only: after every step, outside `value`',
+                    through='bbt_gather_output' if os.environ.get('BBT_BENCH_COMM') == 'cabi' and backend == 'nccl'
+                    else 'all_gather_into_tensor')],
+        data_path_collectives=0,
+        bound=dict(sharded='per-GPU HBM roofline x N (no exchange)',
+                   produced_gb_per_s_per_rank=round(per_gpu * 16 / 1e9, 1),     # 2 pol x complex64 per complete sample
+                   gathered='all-gather over xGMI: a rank receives the other ranks\' shares over its inbound '
+                            'links (153 GB/s each, 7 per GPU); it produces several times what one link carries, '
+                            'so gathered outputs are link-bound and `value` leaves them sharded',
+                   # whole-job complete samples/s a gather can sustain: world x link / (16 B x (world - 1))
+                   gathered_cap_msamples_per_s=dict(
+                       ring_one_link=round(link / 16 * world / max(world - 1, 1) / 1e6, 1),
+                       direct_all_links=round(min(7, max(world - 1, 1)) * link / 16 * world / max(world - 1, 1) / 1e6, 1))))
+
+
 def _timed_gather(args, torch, dist, sharding, comm, backend, dev, coll_dev, world, step, fence, z,
                   samples_per_step):
     """Steps that end with the collective (outputs gathered)."""
@@ -540,6 +606,28 @@ def dry_run_rank(args):
         dist.all_reduce(t)
         dist.barrier()
     line = dict(dry_run=True, n_gpus=world, rank_sum=int(t.item()))
+    if args.workload == 'headline' and os.environ.get('BBT_BENCH_DRYRUN') == 'collectives':
+        # the headline's exchange steps, walked without a GPU: the chirp hand-out with a stand-in
+        # payload through the same fall-back helper the real run uses (BBT_BENCH_INJECT applies),
+        # a stand-in gather, and the list of calls with their sizes and bounds
+        blocks = args.blocks or 768
+        payload = torch.arange(16, dtype=torch.float32) if rank == 0 else torch.zeros(16)
+        local = torch.arange(16, dtype=torch.float32)
+
+        def share():
+            if world > 1:
+                dist.broadcast(payload, 0)
+        used = chirp_shared_or_local(share, lambda: payload.copy_(local), rank)
+        assert torch.equal(payload, local)                # (either way every rank holds the chirp)
+
+        def gather():
+            mine = torch.full((2, 3), float(rank))
+            got = [torch.zeros_like(mine) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(got, mine)
+            return dict(gathered_ranks=[int(g[0, 0]) for g in got] if world > 1 else [rank])
+        line.update(chirp_broadcast_used=used, with_gather=gathered_or_error(gather),
+                    collectives=headline_collectives(world, blocks, os.environ.get('BBT_BENCH_BACKEND', 'nccl')))
     if args.workload == 'config4':
         import baseband_tasks_amd as bt
         from baseband_tasks_amd import sharding
@@ -637,14 +725,9 @@ def run_rank(args):
         assert (dd._ih_samples_per_frame, dd.samples_per_frame) == (N_FFT, spf)
         n_chan, ch_spf = N_CHAN, 512
         # chirp: rank 0 computes, everyone receives it (RCCL broadcast; no-op for one rank)
-        shared = True
-        try:
-            sharding.share_response(dd, torch, dist if world > 1 else None, dev, comm=comm)
-        except Exception as exc:          # the measurement stands without it: every rank evaluates the chirp itself
-            print(f'bench.py: rank {rank}: chirp broadcast failed ({type(exc).__name__}: {exc}); '
-                  'computing it locally', file=sys.stderr)
-            shared = False
-            dd._get_plan()
+        shared = chirp_shared_or_local(
+            lambda: sharding.share_response(dd, torch, dist if world > 1 else None, dev, comm=comm),
+            dd._get_plan, rank)
         sharding_note = ('independent time blocks per rank, chirp ' +
                          (f'broadcast over {"RCCL" if backend == "nccl" else backend}' if shared
                           else 'evaluated on every rank (the broadcast failed)')) if world > 1 else 'single GPU'
@@ -798,12 +881,10 @@ def run_rank(args):
     # ---- outputs gathered: time steps that end with the collective
     with_gather = None
     if world > 1 and not args.no_gather:
-        try:
-            with_gather = _timed_gather(args, torch, dist, sharding, comm, backend, dev, coll_dev, world,
-                                        step, fence, z, samples_per_step)
-        except Exception as exc:           # the sharded number stands; say why the gathered one is missing
-            with_gather = dict(error=f'{type(exc).__name__}: {exc}'[:300])
-            torch.cuda.synchronize()
+        with_gather = gathered_or_error(
+            lambda: _timed_gather(args, torch, dist, sharding, comm, backend, dev, coll_dev, world,
+                                  step, fence, z, samples_per_step),
+            torch.cuda.synchronize)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.workload == 'headline':

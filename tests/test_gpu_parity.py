@@ -2626,6 +2626,18 @@ def test_bench_two_ranks_share_this_gpu():
     assert d['verified']['ok'] and d['verified']['all_ranks_ok']
     assert d['with_gather'] and 'error' not in d['with_gather'], d['with_gather']
     assert d['with_gather']['gathered_shape'][0] == 2 * (24 * 836100 // 1024 // 512) * 512
+    assert 'broadcast' in d['config']['sharding']
+    # both collectives made to fail on both ranks: each evaluates the chirp itself, the gathered
+    # figure is reported missing -- and the sharded value stands, verified on every rank
+    env['BBT_BENCH_INJECT'] = 'bcast,gather'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+                        '--warmup', '1', '--blocks', '24', '--no-cpu'], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['verified']['ok'] and d['verified']['all_ranks_ok']
+    assert 'injected gather failure' in d['with_gather']['error']
+    assert 'the broadcast failed' in d['config']['sharding']
 
 
 def test_default_arguments_at_full_scale_golden(golden):

@@ -163,3 +163,32 @@ def test_bench_config4_layout_on_eight_ranks():
     assert d['gathered_shape'] == [3, 64, 64, 2, 2]
     assert d['gathered_subband_axis'] == list(range(64))
     assert d['chirp_columns_per_rank'] == 8 and d['chirp_bytes_per_rank'] == 8 * 2**24 * 8
+
+
+def test_bench_headline_collectives_dry_run_and_fallbacks():
+    """`BBT_BENCH_DRYRUN=collectives python bench.py --gpus 2` (gloo, no GPU) walks the headline's
+    two exchange steps through the helpers the real run uses: the chirp hand-out
+    (`chirp_shared_or_local`) and the gather (`gathered_or_error`), and lists what each rank would
+    send, how much, and which bound applies.  With `BBT_BENCH_INJECT=bcast,gather` both collectives
+    fail on every rank: every rank then evaluates the chirp itself, `with_gather` records the
+    error, and the run still ends with rank 0's one line and exit code 0 -- the sharded number
+    never depends on a collective."""
+    import json
+    r = _bench(dict(BBT_BENCH_DRYRUN='collectives'), '--gpus', '2')
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['chirp_broadcast_used'] is True and d['with_gather'] == dict(gathered_ranks=[0, 1])
+    c = d['collectives']
+    assert c['data_path_collectives'] == 0
+    ops = {call['op']: call for call in c['calls']}
+    assert ops['broadcast']['bytes'] == 2**20 * 8 + 8 and ops['broadcast']['root'] == 0
+    n_spec = (768 * 836100 // 1024 // 512) * 512
+    assert ops['all_gather']['bytes_sent_per_rank_per_step'] == n_spec * 1024 * 16
+    assert ops['all_gather']['bytes_received_per_rank_per_step'] == n_spec * 1024 * 16
+    cap = c['bound']['gathered_cap_msamples_per_s']
+    assert cap['ring_one_link'] < c['bound']['produced_gb_per_s_per_rank'] * 1e3 / 16 * 2      # link-bound
+    r = _bench(dict(BBT_BENCH_DRYRUN='collectives', BBT_BENCH_INJECT='bcast,gather'), '--gpus', '2')
+    assert r.returncode == 0, r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['chirp_broadcast_used'] is False and 'injected gather failure' in d['with_gather']['error']
+    assert r.stderr.count('chirp broadcast failed') == 2 and d['rank_sum'] == 3
