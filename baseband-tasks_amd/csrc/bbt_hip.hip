@@ -191,8 +191,15 @@ static int gen_threads(int elements) {          // elements <= BBT_GEN_EPT * thr
     int t = ((elements + BBT_GEN_EPT - 1) / BBT_GEN_EPT + 63) / 64 * 64;
     return t < 64 ? 64 : (t > 1024 ? 1024 : t);
 }
-static std::map<std::pair<int, int>, cf*> g_gen_tables;    // (device, n) -> W_n^k, k < n
-static int get_gen_table(GenGeo* g, cf** out);
+static std::map<std::pair<int, int>, cf*> g_gen_tables;    // (device, n) -> stage twiddles; -n: stages reversed
+static int get_gen_table(GenGeo* g, cf** out, bool reversed = false);
+// The same stages in reversed order: what the inverse of a convolution runs (fft_generic.hpp,
+// gen_conv_open), with its own stage tables.
+static int get_reversed(const GenGeo& g, GenGeo* gr, cf** out) {
+    *gr = g;
+    for (int s = 0; s < g.nfac; ++s) gr->fac[s] = g.fac[g.nfac - 1 - s];
+    return get_gen_table(gr, out, true);
+}
 static int make_big_twiddle(int64_t n, cf** lo, cf** hi);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a
@@ -215,7 +222,7 @@ static int ensure_dyn_lds(const void* func, size_t bytes) {
 // r = 1 .. R - 1, k < Ns -- contiguous in k, which is what neighbouring lanes differ in, so a
 // stage's twiddle loads are coalesced (gathered from one W_n^k table they touched up to 64 cache
 // lines per wave instruction).  The first stage (Ns = 1) has none.  Fills g->woff.
-static int get_gen_table(GenGeo* g, cf** out) {
+static int get_gen_table(GenGeo* g, cf** out, bool reversed) {
     int dev;
     HIP_TRY(hipGetDevice(&dev));
     const int n = g->n;
@@ -226,7 +233,8 @@ static int get_gen_table(GenGeo* g, cf** out) {
         ns *= g->fac[s];
     }
     std::lock_guard<std::mutex> lock(g_tab_mutex);
-    auto it = g_gen_tables.find({dev, n});
+    const int key = reversed ? -n : n;
+    auto it = g_gen_tables.find({dev, key});
     if (it != g_gen_tables.end()) {
         *out = it->second;
         return 0;
@@ -243,7 +251,7 @@ static int get_gen_table(GenGeo* g, cf** out) {
     }
     cf* d;
     if (upload(&d, h)) return 1;
-    g_gen_tables[{dev, n}] = d;
+    g_gen_tables[{dev, key}] = d;
     *out = d;
     return 0;
 }
@@ -652,7 +660,8 @@ struct bbt_osm_plan {
     // block lengths that are not powers of two (gen_kernels.hpp): N = n1 * n2,
     // n1 == 1 for N <= 8192
     bool generic = false;
-    GenGeo g1 = {}, g2 = {};
+    GenGeo g1 = {}, g2 = {}, g2r = {};      // g2r: the stages of g2 reversed (inverse of the row transform)
+    cf* wn2r = nullptr;
     cf* wn1 = nullptr;          // W_{n1}^k (shared table)
     cf* wn2 = nullptr;          // W_{n2}^k (shared table)
     cf* tlo = nullptr;          // W_N^i, i < 4096        (owned)
@@ -930,7 +939,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             const size_t lds = (size_t)p->n2 * sizeof(f4);
             if (ensure_dyn_lds((const void*)k_gen_osm_small, lds)) return 1;
             hipLaunchKernelGGL(k_gen_osm_small, dim3(ch.nblk * p->npair), dim3(gen_threads(p->n2)), lds,
-                               st, in, out, ch, p->S, p->resp, p->resp_index, p->g2, p->wn2);
+                               st, in, out, ch, p->S, p->resp, p->resp_index, p->g2, p->wn2, p->g2r, p->wn2r);
             if (timed) {
                 HIP_TRY(hipEventRecord(e[1], st));
                 HIP_TRY(hipEventRecord(e[2], st));
@@ -947,7 +956,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
                                ct, p->g1, p->wn1);
             if (timed) HIP_TRY(hipEventRecord(e[1], st));
             hipLaunchKernelGGL(k_gen_row, dim3(p->n1, ch.nblk * p->npair), dim3(gen_threads(p->n2)),
-                               lds_r, st, work, p->n1, p->resp, p->resp_index, p->npair, p->g2, p->wn2,
+                               lds_r, st, work, p->n1, p->resp, p->resp_index, p->npair, p->g2, p->wn2, p->g2r, p->wn2r,
                                p->tlo, p->thi);
             if (timed) HIP_TRY(hipEventRecord(e[2], st));
             hipLaunchKernelGGL((k_gen_col<false>), gcol, bcol, lds_c, st, in, out, work, ch, p->S, p->n2,
@@ -1215,7 +1224,7 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (p->generic) {
         if (!factor_7smooth(p->n2, &p->g2) || (p->n1 > 1 && !factor_7smooth(p->n1, &p->g1)))
             return bail(fail("bbt_osm_plan_create: cannot factor %d x %d", p->n1, p->n2));
-        if (get_gen_table(&p->g2, &p->wn2)) return bail(1);
+        if (get_gen_table(&p->g2, &p->wn2) || get_reversed(p->g2, &p->g2r, &p->wn2r)) return bail(1);
         if (p->n1 > 1) {
             if (get_gen_table(&p->g1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
                 return bail(1);

@@ -307,6 +307,245 @@ __device__ __forceinline__ void gen_fft(f4* __restrict__ lds, const GenGeo& g, i
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same transform with its two ends open: the FIRST stage takes its butterflies from a
+// source functor (global memory, with whatever factor the caller folds in) instead of the LDS
+// tile, the LAST stage hands its results to a sink functor instead of writing them back --
+// the fill pass before and the drain pass after the transform, one LDS round trip with a
+// barrier each, disappear.  For a convolution (forward, multiply, inverse) the inverse runs its
+// stages in REVERSED order: the forward's last stage leaves butterfly j with elements
+// j + r n/R, r < R, in registers, which is exactly what the inverse's first stage of the same
+// radix wants -- so the two share one stage (gen_stage_turn): multiply in registers, second
+// butterfly, one write.  S stages each way: 2 S + 3 round trips become 2 S - 1.
+//
+//   Src:  template <int R> void load(int j, int m, c2 (&v)[R])    v[r] = x[j + r m]
+//   Mul:  template <int R> void apply(int j, int m, c2 (&v)[R])   v[r] *= h[j + r m]
+//   Dst:  template <int R> void store(int j, int m, c2 (&v)[R])   y[j + r m] = v[r]
+// (m = n / R; a thread's butterflies are j = tid / ct + b nthr / ct, its column tid % ct.)
+template <int R>
+struct GenButterflies {                  // which butterflies of a stage of radix R a thread owns
+    static constexpr int MAXB = (BBT_GEN_EPT + R - 1) / R;
+};
+
+// first stage (ns == 1): source -> butterfly -> LDS at j R + r
+template <int SIGN, int R, class Src>
+__device__ __forceinline__ void gen_stage_first(f4* __restrict__ lds, int n, int ct, int tid, int nthr,
+                                                Src& src) {
+    constexpr int MAXB = GenButterflies<R>::MAXB;
+    const int m = n / R, lg = __ffs(ct) - 1;
+    const int col = tid & (ct - 1), j_first = tid >> lg, j_step = nthr >> lg;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int j = j_first + b * j_step;
+        if (j < m) {
+            c2 v[R];
+            src.template load<R>(j, m, v);
+            gen_butterfly<SIGN, R>(v);
+            f4* dst = lds + ((j * R) << lg) + col;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r << lg] = c2_to_f4(v[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+}
+
+// last stage (ns == n / R): LDS -> twiddle -> butterfly -> sink (natural order: j + r ns)
+template <int SIGN, int R, class Dst>
+__device__ __forceinline__ void gen_stage_last(const f4* __restrict__ lds, int n, int ct,
+                                               const cf* __restrict__ wn, int tid, int nthr, Dst& dst) {
+    constexpr int MAXB = GenButterflies<R>::MAXB;
+    const int m = n / R, lg = __ffs(ct) - 1;
+    const int col = tid & (ct - 1), j_first = tid >> lg, j_step = nthr >> lg;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int j = j_first + b * j_step;
+        if (j < m) {
+            c2 v[R];
+            const f4* src = lds + (j << lg) + col;
+            const int mstride = m << lg;
+            cf w[R];
+            w[1] = wn[j];                                   // (k == j: ns == m)
+#pragma unroll
+            for (int r = 2; r < R; ++r) w[r] = cmul(w[(r + 1) / 2], w[r / 2]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c2 t = f4_to_c2(src[r * mstride]);
+                if (r > 0) t = twmul<SIGN>(t, w[r]);
+                v[r] = t;
+            }
+            gen_butterfly<SIGN, R>(v);
+            dst.template store<R>(j, m, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the turn of a convolution: last forward stage, multiply, first inverse stage (same radix)
+template <int R, class Mul>
+__device__ __forceinline__ void gen_stage_turn(f4* __restrict__ lds, int n, int ct,
+                                               const cf* __restrict__ wn, int tid, int nthr, Mul& mul) {
+    constexpr int MAXB = GenButterflies<R>::MAXB;
+    const int m = n / R, lg = __ffs(ct) - 1;
+    const int col = tid & (ct - 1), j_first = tid >> lg, j_step = nthr >> lg;
+    c2 v[MAXB][R];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int j = j_first + b * j_step;
+        if (j < m) {
+            const f4* src = lds + (j << lg) + col;
+            const int mstride = m << lg;
+            cf w[R];
+            w[1] = wn[j];
+#pragma unroll
+            for (int r = 2; r < R; ++r) w[r] = cmul(w[(r + 1) / 2], w[r / 2]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c2 t = f4_to_c2(src[r * mstride]);
+                if (r > 0) t = twmul<-1>(t, w[r]);
+                v[b][r] = t;
+            }
+            gen_butterfly<-1, R>(v[b]);
+            mul.template apply<R>(j, m, v[b]);
+            gen_butterfly<+1, R>(v[b]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        const int j = j_first + b * j_step;
+        if (j < m) {
+            f4* dst = lds + ((j * R) << lg) + col;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r << lg] = c2_to_f4(v[b][r]);
+        }
+    }
+    __syncthreads();
+}
+
+// a single stage (n == R): everything on registers
+template <int R, class Src, class Mul, class Dst>
+__device__ __forceinline__ void gen_conv_single(int ct, int tid, int nthr, Src& src, Mul& mul, Dst& dst) {
+    if ((tid >> (__ffs(ct) - 1)) == 0) {
+        c2 v[R];
+        src.template load<R>(0, 1, v);
+        gen_butterfly<-1, R>(v);
+        mul.template apply<R>(0, 1, v);
+        gen_butterfly<+1, R>(v);
+        dst.template store<R>(0, 1, v);
+    }
+}
+
+#if BBT_GEN_MAXR >= 12
+#define BBT_GEN_RADIX_CASES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12)
+#elif BBT_GEN_MAXR >= 10
+#define BBT_GEN_RADIX_CASES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+#else
+#define BBT_GEN_RADIX_CASES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#endif
+
+// Transform with open ends: src -> ... -> dst (SIGN as gen_fft; g: the stage list, wn its
+// tables).  The tile needs no filling; on return nothing of the result is in LDS.
+template <int SIGN, class Src, class Dst>
+__device__ __forceinline__ void gen_fft_open(f4* __restrict__ lds, const GenGeo& g, int ct,
+                                             const cf* __restrict__ wn, int tid, int nthr, Src& src, Dst& dst) {
+    const int n = g.n, last = g.nfac - 1;
+    if (last == 0) {                     // one stage: source -> butterfly -> sink
+        if ((tid >> (__ffs(ct) - 1)) == 0) {
+            switch (g.fac[0]) {
+#define BBT_X(R_) case R_: { c2 v[R_]; src.template load<R_>(0, 1, v); gen_butterfly<SIGN, R_>(v); \
+                             dst.template store<R_>(0, 1, v); } break;
+                BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+                default: break;
+            }
+        }
+        return;
+    }
+    switch (g.fac[0]) {
+#define BBT_X(R_) case R_: gen_stage_first<SIGN, R_>(lds, n, ct, tid, nthr, src); break;
+        BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+        default: break;
+    }
+    int ns = g.fac[0];
+    for (int s = 1; s < last; ++s) {
+        const cf* w = wn + g.woff[s];
+        switch (g.fac[s]) {
+#define BBT_X(R_) case R_: gen_stage<SIGN, R_>(lds, n, ns, ct, w, tid, nthr); break;
+            BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+            default: break;
+        }
+        ns *= g.fac[s];
+    }
+    switch (g.fac[last]) {
+#define BBT_X(R_) case R_: gen_stage_last<SIGN, R_>(lds, n, ct, wn + g.woff[last], tid, nthr, dst); break;
+        BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+        default: break;
+    }
+}
+
+// Convolution with open ends: src -> forward (stages of g) -> mul -> inverse (stages of gr, the
+// SAME radices in reversed order, tables wnr) -> dst.
+template <class Src, class Mul, class Dst>
+__device__ __forceinline__ void gen_conv_open(f4* __restrict__ lds, const GenGeo& g, const GenGeo& gr, int ct,
+                                              const cf* __restrict__ wn, const cf* __restrict__ wnr, int tid,
+                                              int nthr, Src& src, Mul& mul, Dst& dst) {
+    const int n = g.n, last = g.nfac - 1;
+    if (last == 0) {
+        switch (g.fac[0]) {
+#define BBT_X(R_) case R_: gen_conv_single<R_>(ct, tid, nthr, src, mul, dst); break;
+            BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+            default: break;
+        }
+        return;
+    }
+    switch (g.fac[0]) {
+#define BBT_X(R_) case R_: gen_stage_first<-1, R_>(lds, n, ct, tid, nthr, src); break;
+        BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+        default: break;
+    }
+    int ns = g.fac[0];
+    for (int s = 1; s < last; ++s) {
+        const cf* w = wn + g.woff[s];
+        switch (g.fac[s]) {
+#define BBT_X(R_) case R_: gen_stage<-1, R_>(lds, n, ns, ct, w, tid, nthr); break;
+            BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+            default: break;
+        }
+        ns *= g.fac[s];
+    }
+    switch (g.fac[last]) {               // (== gr.fac[0])
+#define BBT_X(R_) case R_: gen_stage_turn<R_>(lds, n, ct, wn + g.woff[last], tid, nthr, mul); break;
+        BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+        default: break;
+    }
+    ns = gr.fac[0];
+    for (int s = 1; s < last; ++s) {
+        const cf* w = wnr + gr.woff[s];
+        switch (gr.fac[s]) {
+#define BBT_X(R_) case R_: gen_stage<+1, R_>(lds, n, ns, ct, w, tid, nthr); break;
+            BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+            default: break;
+        }
+        ns *= gr.fac[s];
+    }
+    switch (gr.fac[last]) {
+#define BBT_X(R_) case R_: gen_stage_last<+1, R_>(lds, n, ct, wnr + gr.woff[last], tid, nthr, dst); break;
+        BBT_GEN_RADIX_CASES(BBT_X)
+#undef BBT_X
+        default: break;
+    }
+}
+
 // W_N^m for m < N up to 2^26 from two tables evaluated in double on the host:
 //   lo[i] = W_N^i (i < 4096),  hi[j] = W_N^{4096 j}
 __device__ __forceinline__ cf big_twiddle(const cf* __restrict__ lo, const cf* __restrict__ hi, int m) {

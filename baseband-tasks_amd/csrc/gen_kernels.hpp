@@ -38,41 +38,94 @@ __device__ __forceinline__ f4 f4_mul_resp(f4 a, cf x, cf y) {     // stream A ti
 }
 __device__ __forceinline__ f4 f4_twmul(f4 a, cf w) { return f4_mul_resp(a, w, w); }
 
+// ---- sources, multipliers and sinks of the open-ended transforms (fft_generic.hpp) ----------
+// elements i = j + r m of one column of stream pairs, m apart
+
+// rows of a (n, S) stream: element i at base[i * stride] (stride in float2 units), external format
+struct GenStreamSrc {
+    const float2* base;
+    long long stride;
+    bool live;                           // (a column past the edge of the last tile reads zeros)
+    template <int R>
+    __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            v[r] = live ? f4_to_c2(ld_ext_f4(base + (long long)(j + r * m) * stride)) : czero();
+    }
+};
+// the same for the work buffer (internal format, f4 units)
+struct GenWorkSrc {
+    const f4* base;
+    long long stride;
+    bool live;
+    template <int R>
+    __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = live ? f4_to_c2(base[(long long)(j + r * m) * stride]) : czero();
+    }
+};
+struct GenWorkDst {
+    f4* base;
+    long long stride;
+    bool live;
+    template <int R>
+    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
+        if (!live) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r) base[(long long)(j + r * m) * stride] = c2_to_f4(v[r]);
+    }
+};
+// kept samples of an overlap-save block: element i of the block goes to output row i - valid_start
+struct GenValidDst {
+    float2* out;                         // out + (out_off * S + 2 sp), external format
+    long long stride;                    // S
+    long long first, step;               // block sample of element i: first + i * step
+    int valid_start, valid_count;
+    bool live;
+    template <int R>
+    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
+        if (!live) return;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long q = first + (long long)(j + r * m) * step - valid_start;
+            if (q >= 0 && q < valid_count) st_ext_f4(out + q * stride, c2_to_f4(v[r]));
+        }
+    }
+};
+// spectral multiply: element i times the response columns of the pair's two streams
+struct GenRespMul {
+    const cf* h0;
+    const cf* h1;
+    bool same;
+    template <int R>
+    __device__ __forceinline__ void apply(int j, int m, c2 (&v)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const cf x = h0[j + r * m];
+            const cf y = same ? x : h1[j + r * m];
+            v[r] = cmul2(v[r], c2{v2{x.x, y.x}, v2{x.y, y.y}});
+        }
+    }
+};
+
 // One workgroup per (block, pair): n = g.n <= 8192 elements of dynamic LDS.
+//   g / gr: the stages and their reversal (forward and inverse transform), wn / wnr their tables
 __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_osm_small(const float2* __restrict__ in,
                                                         float2* __restrict__ out, OsmChunk ch, int S,
                                                         const cf* __restrict__ resp,
                                                         const int* __restrict__ resp_index, GenGeo g,
-                                                        const cf* __restrict__ wn) {
+                                                        const cf* __restrict__ wn, GenGeo gr,
+                                                        const cf* __restrict__ wnr) {
     extern __shared__ f4 gen_lds[];
     const int npair = S >> 1, n = g.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int sp = blockIdx.x % npair;
     const OsmBlock blk = ch.b[blockIdx.x / npair];
-    const float2* src = in + (blk.in_off * S + 2 * sp);
-    {
-        f4 x[BBT_GEN_EPT];
-        BBT_GEN_FOR(e, i, n) x[e] = i < n ? ld_ext_f4(src + (long long)i * S) : f4{0.f, 0.f, 0.f, 0.f};
-        BBT_GEN_FOR(e, i, n) if (i < n) gen_lds[i] = x[e];
-    }
-    __syncthreads();
-    const cf* h0 = resp + (long long)resp_index[2 * sp] * n;
-    const cf* h1 = resp + (long long)resp_index[2 * sp + 1] * n;
-    gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
-    {
-        cf ha[BBT_GEN_EPT], hb[BBT_GEN_EPT];
-        BBT_GEN_FOR(e, i, n) {
-            ha[e] = i < n ? h0[i] : make_float2(0.f, 0.f);
-            hb[e] = i < n ? h1[i] : make_float2(0.f, 0.f);
-        }
-        BBT_GEN_FOR(e, i, n) if (i < n) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], hb[e]);
-    }
-    __syncthreads();
-    gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
-    BBT_GEN_FOR(e, i, n) {
-        const int r = i - blk.valid_start;
-        if (i < n && r >= 0 && r < blk.valid_count) st_ext_f4(out + ((blk.out_off + r) * S + 2 * sp), gen_lds[i]);
-    }
+    GenStreamSrc src{in + (blk.in_off * S + 2 * sp), S, true};
+    const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
+    GenRespMul mul{resp + (long long)c0 * n, resp + (long long)c1 * n, c0 == c1};
+    GenValidDst dst{out + (blk.out_off * S + 2 * sp), S, 0, 1, blk.valid_start, blk.valid_count, true};
+    gen_conv_open(gen_lds, g, gr, 1, wn, wnr, tid, nthr, src, mul, dst);
 }
 
 // Column pass: tile of `ct` columns n2 of one (block, pair), all N1 = g.n rows.
@@ -89,46 +142,67 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_col(const float2* _
     const int sp = blockIdx.x % npair, n2_0 = (blockIdx.x / npair) * ct;
     const int b = blockIdx.y;
     const OsmBlock blk = ch.b[b];
-    f4* w = reinterpret_cast<f4*>(work) + ((long long)(b * npair + sp) * N1) * N2;
-    const int total = N1 * ct;
-    const int lg = __ffs(ct) - 1;                  // (ct is a power of two that divides nthr)
-    const int n2 = n2_0 + (tid & (ct - 1)), row_step = nthr >> lg;
-    if (n2 < N2) {
-        // (four loads in flight per thread; with all eight the allocator spilled 700 dwords)
-        const long long step = (long long)row_step * N2;
-        if (FIRST) {
-            const float2* src = in + ((blk.in_off + (long long)(tid >> lg) * N2 + n2) * S + 2 * sp);
-#pragma unroll 4
-            for (int idx = tid; idx < total; idx += nthr, src += step * S) gen_lds[idx] = ld_ext_f4(src);
-        } else {
-            const f4* src = w + (long long)(tid >> lg) * N2 + n2;
-#pragma unroll 4
-            for (int idx = tid; idx < total; idx += nthr, src += step) gen_lds[idx] = *src;
-        }
+    const int n2 = n2_0 + (tid & (ct - 1));        // (ct is a power of two that divides nthr)
+    const bool live = n2 < N2;
+    f4* w = reinterpret_cast<f4*>(work) + ((long long)(b * npair + sp) * N1) * N2 + n2;
+    if (FIRST) {
+        GenStreamSrc src{in + ((blk.in_off + n2) * S + 2 * sp), (long long)N2 * S, live};
+        GenWorkDst dst{w, N2, live};
+        gen_fft_open<-1>(gen_lds, g, ct, wn, tid, nthr, src, dst);
     } else {
-        for (int idx = tid; idx < total; idx += nthr) gen_lds[idx] = f4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    gen_fft<FIRST ? -1 : +1>(gen_lds, g, ct, wn, tid, nthr);
-    if (n2 >= N2) return;
-    int n1 = tid >> lg;
-    for (int idx = tid; idx < total; idx += nthr, n1 += row_step) {
-        if (FIRST) {
-            w[(long long)n1 * N2 + n2] = gen_lds[idx];
-        } else {
-            const long long r = (long long)n1 * N2 + n2 - blk.valid_start;
-            if (r >= 0 && r < blk.valid_count) st_ext_f4(out + ((blk.out_off + r) * S + 2 * sp), gen_lds[idx]);
-        }
+        GenWorkSrc src{w, N2, live};
+        GenValidDst dst{out + (blk.out_off * S + 2 * sp), S, n2, N2, blk.valid_start, blk.valid_count, live};
+        gen_fft_open<+1>(gen_lds, g, ct, wn, tid, nthr, src, dst);
     }
 }
 
 // Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair).
 //   resp  : [C][N1][N2] = H[c][k1 + N1 k2] / N
-//   wn    : W_{N2}^k ;  tlo / thi : W_N^m tables (big_twiddle)
+//   g / gr, wn / wnr: stages of the N2-point transform and their reversal;  tlo / thi : W_N^m
+// The four-step twiddles W_N^{k1 i} of a butterfly's elements i = j + r m are a s^r with
+// a = W_N^{k1 j} (one look-up per butterfly) and s = W_N^{k1 m}, the same for the whole
+// workgroup: folded into the source and, conjugated, into the sink.
+struct GenRowSrc {
+    const f4* row;
+    const cf* tlo;
+    const cf* thi;
+    int k1;
+    long long n_total;
+    template <int R>
+    __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
+        const cf a = big_twiddle(tlo, thi, k1 * j);
+        cf s[R];
+        s[1] = big_twiddle(tlo, thi, (int)(((long long)k1 * m) % n_total));
+#pragma unroll
+        for (int r = 2; r < R; ++r) s[r] = cmul(s[(r + 1) / 2], s[r / 2]);
+        v[0] = twmul<-1>(f4_to_c2(row[j]), a);
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[r] = twmul<-1>(f4_to_c2(row[j + r * m]), cmul(a, s[r]));
+    }
+};
+struct GenRowDst {
+    f4* row;
+    const cf* tlo;
+    const cf* thi;
+    int k1;
+    long long n_total;
+    template <int R>
+    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
+        const cf a = big_twiddle(tlo, thi, k1 * j);
+        cf s[R];
+        s[1] = big_twiddle(tlo, thi, (int)(((long long)k1 * m) % n_total));
+#pragma unroll
+        for (int r = 2; r < R; ++r) s[r] = cmul(s[(r + 1) / 2], s[r / 2]);
+        row[j] = c2_to_f4(twmul<+1>(v[0], a));
+#pragma unroll
+        for (int r = 1; r < R; ++r) row[j + r * m] = c2_to_f4(twmul<+1>(v[r], cmul(a, s[r])));
+    }
+};
 __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restrict__ work, int N1,
                                                   const cf* __restrict__ resp,
                                                   const int* __restrict__ resp_index, int npair,
-                                                  GenGeo g, const cf* __restrict__ wn,
+                                                  GenGeo g, const cf* __restrict__ wn, GenGeo gr,
+                                                  const cf* __restrict__ wnr,
                                                   const cf* __restrict__ tlo,
                                                   const cf* __restrict__ thi) {
     extern __shared__ f4 gen_lds[];
@@ -136,57 +210,28 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restr
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int k1 = blockIdx.x, sp = blockIdx.y % npair;
     f4* row = reinterpret_cast<f4*>(work) + ((long long)blockIdx.y * N1 + k1) * N2;
-    // The four-step twiddles W_N^{k1 n2} of a thread's elements n2 = tid + e nthr are
-    // a s^e with a = W_N^{k1 tid} and s = W_N^{k1 nthr} (the same for the whole workgroup): two
-    // table look-ups and products at most four roundings deep instead of a look-up (two loads)
-    // per element and direction -- like the stage twiddles, loads were what this kernel waited for.
-    auto four_step = [&](cf (&tw)[BBT_GEN_EPT]) {
-        const cf a = big_twiddle(tlo, thi, k1 * tid);
-        cf sp_[BBT_GEN_EPT];
-        sp_[1] = big_twiddle(tlo, thi, (int)(((long long)k1 * nthr) % ((long long)N1 * N2)));
-#pragma unroll
-        for (int e = 2; e < BBT_GEN_EPT; ++e) sp_[e] = cmul(sp_[(e + 1) / 2], sp_[e / 2]);
-        tw[0] = a;
-#pragma unroll
-        for (int e = 1; e < BBT_GEN_EPT; ++e) tw[e] = cmul(a, sp_[e]);
-    };
-    {
-        f4 x[BBT_GEN_EPT];
-        cf tw[BBT_GEN_EPT];
-        BBT_GEN_FOR(e, i, N2) x[e] = i < N2 ? row[i] : f4{0.f, 0.f, 0.f, 0.f};
-        four_step(tw);
-        BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_twmul(x[e], tw[e]);
-    }
-    __syncthreads();
-    gen_fft<-1>(gen_lds, g, 1, wn, tid, nthr);
-    {
-        const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
-        const cf* h0 = resp + ((long long)c0 * N1 + k1) * N2;
-        const cf* h1 = resp + ((long long)c1 * N1 + k1) * N2;
-        cf ha[BBT_GEN_EPT], hb[BBT_GEN_EPT];
-        if (c0 == c1) {                                  // (both streams of the pair: one column)
-            BBT_GEN_FOR(e, i, N2) ha[e] = i < N2 ? h0[i] : make_float2(0.f, 0.f);
-            BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], ha[e]);
-        } else {
-            BBT_GEN_FOR(e, i, N2) {
-                ha[e] = i < N2 ? h0[i] : make_float2(0.f, 0.f);
-                hb[e] = i < N2 ? h1[i] : make_float2(0.f, 0.f);
-            }
-            BBT_GEN_FOR(e, i, N2) if (i < N2) gen_lds[i] = f4_mul_resp(gen_lds[i], ha[e], hb[e]);
-        }
-    }
-    __syncthreads();
-    gen_fft<+1>(gen_lds, g, 1, wn, tid, nthr);
-    {
-        cf tw[BBT_GEN_EPT];
-        four_step(tw);
-        BBT_GEN_FOR(e, i, N2) if (i < N2) row[i] = f4_twmul(gen_lds[i], make_float2(tw[e].x, -tw[e].y));
-    }
+    const long long n_total = (long long)N1 * N2;
+    GenRowSrc src{row, tlo, thi, k1, n_total};
+    const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
+    GenRespMul mul{resp + ((long long)c0 * N1 + k1) * N2, resp + ((long long)c1 * N1 + k1) * N2, c0 == c1};
+    GenRowDst dst{row, tlo, thi, k1, n_total};
+    gen_conv_open(gen_lds, g, gr, 1, wn, wnr, tid, nthr, src, mul, dst);
 }
 
 // Batched transforms over contiguous groups of n = g.n complete samples, for a
 // tile of `ct` stream pairs (ct * 16 contiguous bytes per complete sample).
 //   grid (n_fft * (npair / ct))
+struct GenScaledDst {
+    float2* base;
+    long long stride;
+    float scale;
+    template <int R>
+    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            st_ext_f4(base + (long long)(j + r * m) * stride, c2_to_f4(v[r]) * scale);
+    }
+};
 template <int SIGN>
 __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_fft_rows(const float2* __restrict__ in,
                                                        float2* __restrict__ out, int S, int ct,
@@ -196,22 +241,10 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_fft_rows(const floa
     const int npair = S >> 1, n = g.n, npg = npair / ct;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const long long i = blockIdx.x / npg;
-    const int sp0 = (blockIdx.x % npg) * ct;
-    const int total = n * ct;
-    const float2* src = in + (i * n * S + 2 * sp0);
-    const int lg = __ffs(ct) - 1;                  // (ct is a power of two that divides nthr)
-    const int c = tid & (ct - 1), row0 = tid >> lg, row_step = nthr >> lg;
-    {
-        f4 x[BBT_GEN_EPT];
-        BBT_GEN_FOR(e, idx, total)
-            x[e] = idx < total ? ld_ext_f4(src + ((long long)(row0 + e * row_step) * S + 2 * c)) : f4{0.f, 0.f, 0.f, 0.f};
-        BBT_GEN_FOR(e, idx, total) if (idx < total) gen_lds[idx] = x[e];
-    }
-    __syncthreads();
-    gen_fft<SIGN>(gen_lds, g, ct, wn, tid, nthr);
-    float2* dst = out + (i * n * S + 2 * sp0);
-    BBT_GEN_FOR(e, idx, total)
-        if (idx < total) st_ext_f4(dst + ((long long)(row0 + e * row_step) * S + 2 * c), gen_lds[idx] * scale);
+    const int sp = (blockIdx.x % npg) * ct + (tid & (ct - 1));       // (ct: a power of two dividing nthr)
+    GenStreamSrc src{in + (i * n * S + 2 * sp), S, true};
+    GenScaledDst dst{out + (i * n * S + 2 * sp), S, scale};
+    gen_fft_open<SIGN>(gen_lds, g, ct, wn, tid, nthr, src, dst);
 }
 
 // Splice the spectrum that straddles a block seam (see k_seam_fix) for any
