@@ -152,6 +152,12 @@ def lib():
     if _lib is None:
         with _lock:
             if _lib is None:
+                # A process that uses the host path has more HIP streams (plan lanes and tail,
+                # upload, download, the caller's) than the 4 hardware queues ROCm maps streams to
+                # by default; an upload and a download that share one take turns (measured: 27
+                # GB/s each way instead of 41-45).  Only effective if the HIP runtime has not been
+                # initialised yet; an explicit setting wins.
+                os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
                 _preload_torch_runtime()
                 if not os.path.exists(LIB_PATH):
                     raise HipLibraryMissing(

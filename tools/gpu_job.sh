@@ -106,14 +106,14 @@ sq)
 evidence)
     suite || exit 1
     prof3 headline python3 $R/bench.py --steps 4 --warmup 1 --no-cpu --no-verify --no-host-path --no-traffic
-    prof3 config4 python3 $R/bench.py --workload config4 --steps 2 --warmup 1 --no-verify --no-traffic
+    prof3 config4 python3 $R/bench.py --workload config4 --steps 2 --warmup 2 --no-verify --no-traffic
     for c in config1 config2 config3 config5; do prof3 $c python3 $R/tools/bench_one.py $c --reps 4; done
     timeline
     sq headline python3 $R/bench.py --steps 2 --warmup 1 --blocks 96 --no-cpu --no-verify --no-host-path --no-traffic
     for c in config1 config2 config3 config5; do timeout -k 10 200 python3 tools/bench_one.py $c; done > $OUT/bench_one.jsonl 2> $OUT/bench_one.err
     cat $OUT/bench_one.jsonl
     timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err; say "bench rc=$?"
-    timeout -k 10 500 python3 bench.py --workload config4 --steps 3 --warmup 1 --blocks 4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; say "c4 rc=$?"
+    timeout -k 10 500 python3 bench.py --workload config4 --steps 3 --warmup 2 --blocks 4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; say "c4 rc=$?"
     timeout -k 10 900 python3 tools/bench_next.py > $OUT/next_rows.jsonl 2> $OUT/next_rows.err; say "next rc=$?"
     BBT_BENCH_BACKEND=gloo timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --blocks 192 --no-cpu --no-host-path > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err; say "gloo2 rc=$?"
     timeout -k 10 300 python3 tools/bench_generic.py > $OUT/generic.txt 2>&1; say "generic rc=$?"
