@@ -595,3 +595,102 @@ def test_host_uploader_takes_the_block_before_the_ordering_event_and_loads_each_
     assert up.fetch(32, 8).shape == (8, 1)             # the read-ahead is dropped, [32, 40) loaded
     assert up.loads == 3
     up.close()
+
+
+class _FakeLib:
+    """libbbt_hip.so as a log: every entry point returns 0, allocations hand out numbered
+    addresses, plan info says 'two levels' (a plan with lanes)."""
+
+    def __init__(self):
+        self.log = []
+        self.next_ptr = 0x100000
+        self.events = 0
+
+    def __getattr__(self, name):
+        def call(*args):
+            if name == 'bbt_malloc':
+                args[0]._obj.value = self.next_ptr
+                self.next_ptr += 0x100000
+            elif name == 'bbt_event_create_ordering':
+                self.events += 1
+                args[0]._obj.value = 0xE000 + self.events
+            elif name == 'bbt_osm_plan_create':
+                args[0]._obj.value = 0xABC0
+            elif name == 'bbt_osm_plan_info':
+                args[3]._obj.value = 256                 # n1
+                args[4]._obj.value = 4096
+                return 0
+            def plain(a):
+                return getattr(a, 'value', a)
+            self.log.append((name,) + tuple(plain(a) for a in args if isinstance(a, (int, type(None))) or hasattr(a, 'value')))
+            return 0
+        return call
+
+
+def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch):
+    """`hip.OsmPlan._call` without a GPU (a logging stand-in for the library): a plan call whose
+    output the package owns is issued with `bbt_osm_plan_defer`; its completion event stays with the
+    output's AND the input's allocation; whatever asks for either address next first queues the
+    wait (`DeviceArray.ptr`), once per allocation, and the event returns to the pool only after
+    both have; a task's cache alternates between two buffers while a call is owed; a foreign
+    output (no `_Allocation`) is never deferred.  Reference: consecutive frame reads,
+    base.py:427-436."""
+    from baseband_tasks_amd import hip
+    from baseband_tasks_amd.device_task import DeviceTaskMixin
+    fake = _FakeLib()
+    monkeypatch.setattr(hip, '_lib', fake)
+    monkeypatch.setattr(hip, 'DEFER_JOIN', True)
+    monkeypatch.setattr(hip, '_events', hip._EventPool())
+    plan = hip.OsmPlan(2**20, 2, np.zeros((1, 2**20), np.complex64))
+    assert plan._has_lanes
+    x = hip.DeviceArray((2**20, 2), np.complex64)
+    y = hip.DeviceArray((1000, 2), np.complex64)
+    desc = ([0], [0], [10], [1000])
+    plan.execute(x, y, *desc)
+    names = [e[0] for e in fake.log]
+    assert names.index('bbt_osm_plan_defer') < names.index('bbt_osm_execute')
+    ev = [e for e in fake.log if e[0] == 'bbt_osm_plan_defer'][0][2]
+    assert y.pending and x.pending and y.owner.pending.done is x.owner.pending.done
+    assert y.owner.pending.done.refs == 2 and not hip._events._idle
+    # views share the allocation's state; reading the address of one queues the wait, once
+    view = y[10:20].reshape(20)
+    assert view.pending
+    n0 = len(fake.log)
+    assert view.ptr == y._ptr + 10 * 16
+    assert fake.log[n0:] == [('bbt_stream_wait_event', None, ev)] and not y.pending and x.pending
+    assert y.ptr and len(fake.log) == n0 + 1            # (settled: no second wait)
+    # the next call on the same input: the input's turn to wait, then the event is free again
+    n0 = len(fake.log)
+    plan.execute(x, y, *desc)
+    after = [e for e in fake.log[n0:] if e[0] in ('bbt_stream_wait_event', 'bbt_osm_plan_defer', 'bbt_osm_execute')]
+    assert after[0] == ('bbt_stream_wait_event', None, ev) and after[1][0] == 'bbt_osm_plan_defer'
+    assert after[1][2] == ev                             # (the pooled event, taken again)
+    # a block that is freed while a call is owed is ordered first
+    n0 = len(fake.log)
+    y_ptr = y._ptr
+    del view, y
+    tail = [e[0] for e in fake.log[n0:]]
+    assert tail == ['bbt_stream_wait_event', 'bbt_free'] and fake.log[-1][1] == y_ptr
+    # foreign memory as output: a joined call
+    class Foreign:
+        pass
+    z = hip.DeviceArray((1000, 2), np.complex64, ptr=0x7000000, owner=Foreign())
+    n0 = len(fake.log)
+    plan.execute(x, z, *desc)
+    assert 'bbt_osm_plan_defer' not in [e[0] for e in fake.log[n0:]] and not z.pending
+
+    # a task's cache alternates while the previous run is owed, and stays put once it is not
+    class Task(DeviceTaskMixin):
+        sample_shape = (2,)
+        dtype = np.dtype(np.complex64)
+    t = Task()
+    a = t._out_buffer(100)
+    a.owner.pending = hip._Pending(hip._Done(hip._events.take(), 1), ())
+    b = t._out_buffer(100)
+    assert b.owner is not a.owner and t._cache_buffer_b.owner is a.owner
+    assert t._out_buffer(100).owner is b.owner           # (nothing owed on b: no switch)
+    b.owner.pending = hip._Pending(hip._Done(hip._events.take(), 1), ())
+    c = t._out_buffer(100)
+    assert c.owner is a.owner                            # back to the first one ...
+    n0 = len(fake.log)
+    assert c.ptr and fake.log[n0][0] == 'bbt_stream_wait_event'      # ... after the call before last
