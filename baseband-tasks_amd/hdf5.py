@@ -19,7 +19,11 @@ astropy's loader resolves (``!astropy.units.Quantity``, ``!astropy.time.Time``,
 h5py + astropy YAML loader (in the build container's second interpreter, the
 way the reference's ``HDF5Header.fromfile`` does); the reference's own reader
 class cannot be run here (it imports `baseband`).  `open(name, 'r')` reads the
-files this module writes (not HDF5 files in general).
+files this module writes AND the files the reference's own writer produces
+(h5py with default settings: superblock 0, symbol-table groups, version-1
+object headers, the header as a variable-length string; tests/golden/
+reference_style.h5 is such a file, made by the real h5py + astropy) -- raw,
+contiguous payloads; not HDF5 files in general (no chunking, no filters).
 """
 import base64
 import os
@@ -270,111 +274,296 @@ class HDF5StreamWriter:
         self.close()
 
 
-def _parse_yaml_scalar(text, key):
-    for line in text.splitlines():
-        if line.startswith(key + ':'):
-            return line[len(key) + 1:].strip()
-    return None
+# --------------------------------------------------------------------------- the YAML header
+_SI = {'': 1., 'k': 1e3, 'M': 1e6, 'G': 1e9, 'T': 1e12, 'm': 1e-3, 'u': 1e-6, 'n': 1e-9}
 
 
-def _parse_array(text, key):
-    lines = text.splitlines()
-    for i, line in enumerate(lines):
-        if line.startswith(key + ':'):
-            block = []
-            for ln in lines[i + 1:]:
-                if ln and not ln.startswith(' '):
-                    break
-                block.append(ln)
-            body = '\n'.join(block)
-            if 'buffer:' not in body:
-                return None
-            j = next(k for k, ln in enumerate(block) if 'buffer:' in ln)
-            b64 = ''
-            for ln in block[j + 1:]:
-                s = ln.strip()
-                if ':' in s:
-                    break
-                b64 += s
-            dt = next(ln.split(':', 1)[1].strip() for ln in block if ln.strip().startswith('dtype:'))
-            shp = next(ln.split('[', 1)[1].split(']')[0] for ln in block if ln.strip().startswith('shape:'))
-            shape = tuple(int(s) for s in shp.split(',') if s.strip())
-            raw = base64.b64decode(base64.b64decode(b64))
-            return np.frombuffer(raw, dtype=np.dtype(dt)).reshape(shape).copy()
-    return None
+def _unit_in_hz(unit):
+    """Factor that turns a value in ``unit`` (astropy's string for a frequency unit: Hz with an SI
+    prefix, or one over a time unit) into Hz."""
+    unit = unit.strip()
+    if unit.endswith('Hz') and unit[:-2] in _SI:
+        return _SI[unit[:-2]]
+    if unit.startswith('1 / ') and unit.endswith('s') and unit[4:-1] in _SI:
+        return 1. / _SI[unit[4:-1]]
+    raise OSError(f"header: cannot interpret the unit {unit!r} as a frequency.")
 
 
-class HDF5StreamReader(Base):
-    """Read a file written by `HDF5StreamWriter` (samples through a memory map)."""
+class _Quantity:
+    def __init__(self, value, unit):
+        self.value, self.unit = value, unit
 
-    def __init__(self, name):
-        raw = np.memmap(name, mode='r')
-        head = bytes(raw[:48])
-        if head[:8] != _SIGNATURE or head[8] not in (2, 3) or lookup3(head[:44]) != struct.unpack('<I', head[44:48])[0]:
-            raise OSError(f"{name}: not an HDF5 file this reader understands (superblock).")
-        root = struct.unpack('<Q', head[36:44])[0]
-        links = dict(self._links(raw, root))
-        if not {'header', 'payload'} <= set(links):
-            raise OSError(f"{name}: no 'header' and 'payload' datasets.")
-        h_addr, h_size, _, _ = self._dataset(raw, links['header'])
-        text = bytes(raw[h_addr:h_addr + h_size]).decode()
-        p_addr, p_size, shape, _ = self._dataset(raw, links['payload'])
-        dtype = np.dtype(_parse_yaml_scalar(text, 'dtype'))
-        self._text = text
-        self._data = np.ndarray(shape, dtype, buffer=raw, offset=p_addr)
-        line = next(ln for ln in text.replace('\n  ', ' ').splitlines() if ln.startswith('time:'))
-        jd1 = float(line.split('jd1:')[1].split(',')[0])
-        jd2 = float(line.split('jd2:')[1].split(',')[0])
-        rate = float(text.split('sample_rate:')[1].split('value:')[1].split()[0])
-        kwargs = {}
-        freq = _parse_array(text, 'frequency')
-        if freq is None and 'frequency:' in text:
-            freq = float(text.split('frequency:')[1].split('value:')[1].split()[0])
-        if freq is not None:
-            kwargs['frequency'] = freq
-        for key in ('sideband', 'polarization'):
-            value = _parse_array(text, key)
-            if value is not None:
-                kwargs[key] = value
-        super().__init__(shape=tuple(shape), start_time=Time.from_jd(jd1, jd2), sample_rate=rate,
-                         samples_per_frame=min(shape[0], 1 << 20) if shape[0] else 1, dtype=dtype, **kwargs)
+    def hz(self):
+        return np.asarray(self.value, dtype=np.float64) * _unit_in_hz(self.unit)
 
-    @staticmethod
-    def _messages(raw, addr):
-        head = bytes(raw[addr:addr + 16])
-        if head[:4] != b'OHDR' or head[4] != 2:
+
+def parse_header(text):
+    """The header dict of a 'header' dataset: astropy's YAML (io/hdf5/header.py:66-81: dumped and
+    loaded with astropy.io.misc.yaml) read with PyYAML and constructors for the four tags that
+    occur -- units, quantities, times, arrays -- astropy itself being absent where this runs.
+    Quantities come back in Hz (float or array), the time as `units.Time`."""
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    def unit(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        return str(m.get('unit', ''))
+
+    def quantity(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        return _Quantity(m['value'], m['unit'])
+
+    def time(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        if str(m.get('scale', 'utc')).lower() != 'utc':
+            raise OSError(f"header: time scale {m.get('scale')!r} is not supported (utc only).")
+        return Time.from_jd(float(m['jd1']), float(m['jd2']))
+
+    def ndarray(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        raw = m['buffer']
+        raw = base64.b64decode(raw if isinstance(raw, bytes) else raw.encode())   # (astropy encodes, then YAML does)
+        order = 'F' if str(m.get('order', 'C')).upper().startswith('F') else 'C'
+        return np.frombuffer(raw, dtype=np.dtype(str(m['dtype']))).reshape(tuple(m['shape']), order=order).copy()
+
+    Loader.add_constructor('!astropy.units.Unit', unit)
+    Loader.add_constructor('!astropy.units.Quantity', quantity)
+    Loader.add_constructor('!astropy.time.Time', time)
+    Loader.add_constructor('!numpy.ndarray', ndarray)
+    Loader.add_constructor('tag:yaml.org,2002:python/tuple', lambda loader, node: tuple(loader.construct_sequence(node)))
+    items = yaml.load(text, Loader=Loader)
+    if not isinstance(items, dict) or not {'sample_shape', 'samples_per_frame', 'sample_rate', 'time'} <= set(items):
+        raise OSError("header: sample_shape, samples_per_frame, sample_rate and time are required "
+                      "(io/hdf5/header.py:58-60).")
+    for key in ('sample_rate', 'frequency'):
+        if isinstance(items.get(key), _Quantity):
+            items[key] = items[key].hz()
+    return items
+
+
+# --------------------------------------------------------------------------- the file structure
+class _File:
+    """The little of the HDF5 format needed to find two datasets in the root group, in both
+    generations of the on-disk structures: what this module writes (superblock 2, version-2 object
+    headers, compact links) and what h5py / libhdf5 write by default, i.e. what the reference's
+    own writer produces (superblock 0, symbol-table group: B-tree + local heap, version-1 object
+    headers with continuation blocks, variable-length strings in the global heap)."""
+
+    def __init__(self, raw):
+        self.raw = raw
+        head = bytes(raw[:96])
+        if head[:8] != _SIGNATURE:
+            raise OSError("not an HDF5 file (signature).")
+        version = head[8]
+        if version in (2, 3):
+            if lookup3(head[:44]) != struct.unpack('<I', head[44:48])[0]:
+                raise OSError("superblock checksum.")
+            if head[9] != 8 or head[10] != 8:
+                raise OSError("only 8-byte offsets and lengths are supported.")
+            self.root = struct.unpack('<Q', head[36:44])[0]
+        elif version in (0, 1):
+            if head[13] != 8 or head[14] != 8:
+                raise OSError("only 8-byte offsets and lengths are supported.")
+            base = 24 + (4 if version == 1 else 0)
+            if struct.unpack('<Q', head[base:base + 8])[0] != 0:
+                raise OSError("a non-zero base address is not supported.")
+            # root group symbol table entry: link name offset, object header address, ...
+            self.root = struct.unpack('<Q', head[base + 40:base + 48])[0]
+        else:
+            raise OSError(f"superblock version {version} is not supported.")
+
+    def bytes(self, addr, n):
+        return bytes(self.raw[addr:addr + n])
+
+    # -- object headers
+    def messages(self, addr):
+        """(type, data) of every message of the object header at ``addr``."""
+        if self.bytes(addr, 4) == b'OHDR':
+            yield from self._messages_v2(addr)
+        elif self.raw[addr] == 1:
+            yield from self._messages_v1(addr)
+        else:
+            raise OSError("object header version not supported by this reader.")
+
+    def _messages_v2(self, addr):
+        head = self.bytes(addr, 16)
+        if head[4] != 2:
             raise OSError("object header version not supported by this reader.")
         flags = head[5]
         pos = addr + 6 + (16 if flags & 0x20 else 0) + (4 if flags & 0x10 else 0)
         width = 1 << (flags & 3)
-        size = int.from_bytes(bytes(raw[pos:pos + width]), 'little')
+        size = int.from_bytes(self.bytes(pos, width), 'little')
         pos += width
-        end = pos + size
-        while pos + 4 <= end:
-            kind, n, _ = struct.unpack('<BHB', bytes(raw[pos:pos + 4]))
-            pos += 4 + (2 if flags & 0x04 else 0)
-            yield kind, bytes(raw[pos:pos + n])
-            pos += n
+        blocks = [(pos, pos + size)]
+        while blocks:
+            pos, end = blocks.pop(0)
+            while pos + 4 <= end:
+                kind, n, _ = struct.unpack('<BHB', self.bytes(pos, 4))
+                pos += 4 + (2 if flags & 0x04 else 0)
+                data = self.bytes(pos, n)
+                pos += n
+                if kind == 0x10:                           # continuation: 'OCHK' block
+                    off, length = struct.unpack('<QQ', data[:16])
+                    blocks.append((off + 4, off + length - 4))
+                else:
+                    yield kind, data
 
-    @classmethod
-    def _links(cls, raw, addr):
-        for kind, data in cls._messages(raw, addr):
-            if kind == 0x06 and data[0] == 1 and data[1] == 0:
-                n = data[2]
-                yield data[3:3 + n].decode(), struct.unpack('<Q', data[3 + n:11 + n])[0]
+    def _messages_v1(self, addr):
+        _, _, count, _, size = struct.unpack('<BBHII', self.bytes(addr, 12))
+        blocks = [(addr + 16, addr + 16 + size)]           # (the prefix is padded to 8 bytes)
+        while blocks and count > 0:
+            pos, end = blocks.pop(0)
+            while pos + 8 <= end and count > 0:
+                kind, n, _ = struct.unpack('<HHB', self.bytes(pos, 5))
+                data = self.bytes(pos + 8, n)
+                pos += 8 + n
+                count -= 1
+                if kind == 0x10:
+                    off, length = struct.unpack('<QQ', data[:16])
+                    blocks.append((off, off + length))
+                else:
+                    yield kind, data
 
-    @classmethod
-    def _dataset(cls, raw, addr):
-        shape, address, size = (), None, None
-        for kind, data in cls._messages(raw, addr):
-            if kind == 0x01:
+    # -- groups
+    def links(self, addr):
+        """name -> object header address of the group whose object header is at ``addr``."""
+        out = {}
+        for kind, data in self.messages(addr):
+            if kind == 0x06 and data[0] == 1:              # link message (new-style groups)
+                flags = data[1]
+                pos = 2 + (1 if flags & 0x08 else 0) + (8 if flags & 0x04 else 0) + (1 if flags & 0x10 else 0)
+                width = 1 << (flags & 3)
+                n = int.from_bytes(data[pos:pos + width], 'little')
+                pos += width
+                name = data[pos:pos + n].decode()
+                if not flags & 0x08 or data[2] == 0:       # hard link
+                    out[name] = struct.unpack('<Q', data[pos + n:pos + n + 8])[0]
+            elif kind == 0x11:                             # symbol table message (old-style groups)
+                btree, heap = struct.unpack('<QQ', data[:16])
+                out.update(self._symbol_table(btree, heap))
+        return out
+
+    def _symbol_table(self, btree, heap):
+        h = self.bytes(heap, 32)
+        if h[:4] != b'HEAP':
+            raise OSError("local heap signature.")
+        segment = struct.unpack('<Q', h[24:32])[0]
+
+        def name(offset):
+            end = offset
+            while self.raw[segment + end] != 0:
+                end += 1
+            return self.bytes(segment + offset, end - offset).decode()
+
+        out = {}
+        nodes = [btree]
+        while nodes:
+            node = nodes.pop()
+            head = self.bytes(node, 24)
+            if head[:4] == b'TREE':
+                if head[4] != 0:
+                    raise OSError("group B-tree node type.")
+                used = struct.unpack('<H', head[6:8])[0]
+                for i in range(used):                      # key 0, child 0, key 1, child 1, ...
+                    nodes.append(struct.unpack('<Q', self.bytes(node + 24 + 8 + 16 * i, 8))[0])
+            elif head[:4] == b'SNOD':
+                count = struct.unpack('<H', head[6:8])[0]
+                for i in range(count):
+                    off, obj = struct.unpack('<QQ', self.bytes(node + 8 + 40 * i, 16))
+                    out[name(off)] = obj
+            else:
+                raise OSError("symbol table node signature.")
+        return out
+
+    # -- datasets
+    def dataset(self, addr):
+        """(data address, bytes, shape, element size, datatype class, inline data) of a dataset."""
+        shape, address, size, inline = (), None, None, None
+        elem, cls = None, None
+        for kind, data in self.messages(addr):
+            if kind == 0x01:                               # dataspace
                 rank = data[1]
-                shape = tuple(struct.unpack('<Q', data[4 + 8 * i:12 + 8 * i])[0] for i in range(rank))
-            elif kind == 0x08 and data[1] == 1:
-                address, size = struct.unpack('<QQ', data[2:18])
-        if address is None:
-            raise OSError("dataset is not stored contiguously.")
-        return address, size, shape, None
+                first = 8 if data[0] == 1 else 4
+                shape = tuple(struct.unpack('<Q', data[first + 8 * i:first + 8 + 8 * i])[0] for i in range(rank))
+            elif kind == 0x03:                             # datatype
+                cls = data[0] & 0x0F
+                elem = struct.unpack('<I', data[4:8])[0]
+            elif kind == 0x08:                             # layout
+                if data[0] not in (3, 4):
+                    raise OSError(f"data layout message version {data[0]} is not supported.")
+                if data[1] == 1:
+                    address, size = struct.unpack('<QQ', data[2:18])
+                elif data[1] == 0:
+                    n = struct.unpack('<H', data[2:4])[0]
+                    inline = data[4:4 + n]
+                else:
+                    raise OSError("dataset is not stored contiguously (chunked or virtual layouts are not read).")
+        if address is None and inline is None:
+            raise OSError("dataset has no data layout.")
+        if address == _UNDEF:
+            raise OSError("dataset has no storage allocated (it was never written).")
+        return address, size, shape, elem, cls, inline
+
+    def text(self, addr):
+        """The string a scalar string dataset holds: fixed length in place, or variable length in
+        the global heap (what ``create_dataset('header', data=str)`` of h5py makes)."""
+        address, size, shape, elem, cls, inline = self.dataset(addr)
+        body = inline if inline is not None else self.bytes(address, size)
+        if cls == 9:                                       # variable length: (length, heap address, index)
+            length, heap, index = struct.unpack('<IQI', body[:16])
+            head = self.bytes(heap, 16)
+            if head[:4] != b'GCOL':
+                raise OSError("global heap signature.")
+            end = heap + struct.unpack('<Q', head[8:16])[0]
+            pos = heap + 16
+            while pos + 16 <= end:
+                idx, _, _, n = struct.unpack('<HHIQ', self.bytes(pos, 16))
+                if idx == index:
+                    return self.bytes(pos + 16, min(n, length)).decode()
+                if idx == 0:
+                    break
+                pos += 16 + (n + 7) // 8 * 8
+            raise OSError("global heap object not found.")
+        return body.split(b'\0', 1)[0].decode()
+
+
+class HDF5StreamReader(Base):
+    """Read a stream in the reference's intermediate HDF5 format (io/hdf5/base.py:129-222 with
+    ``mode='r'``): a file with a 'header' (YAML) and a 'payload' dataset in its root group, written
+    by this module OR by the reference itself (h5py with default settings; tests/golden/
+    reference_style.h5 was made that way).  Raw payloads only (float32 / float64 / complex64 /
+    complex128, stored contiguously): ``bps``-coded payloads (io/hdf5/payload.py:181-) are
+    refused.  Samples come through a memory map."""
+
+    def __init__(self, name):
+        raw = np.memmap(name, mode='r')
+        try:
+            f = _File(raw)
+            links = f.links(f.root)
+            if not {'header', 'payload'} <= set(links):
+                raise OSError("no 'header' and 'payload' datasets.")
+            text = f.text(links['header'])
+            items = parse_header(text)
+            if 'bps' in items:
+                raise OSError("encoded payloads (a header with 'bps') are not supported.")
+            address, size, shape, elem, cls, inline = f.dataset(links['payload'])
+            if inline is not None:
+                raise OSError("compact payloads are not supported.")
+        except OSError as exc:
+            raise OSError(f"{name}: not an HDF5 stream file this reader understands ({exc})") from None
+        dtype = np.dtype(str(items.get('dtype', 'c8' if (cls == 6 and elem == 8) else 'f4')))
+        if dtype.itemsize != elem:
+            raise OSError(f"{name}: header dtype {dtype} does not match the {elem}-byte payload elements.")
+        sample_shape = tuple(int(d) for d in items['sample_shape'])
+        if tuple(shape[1:]) != sample_shape:
+            raise OSError(f"{name}: payload shape {shape} does not match sample_shape {sample_shape}.")
+        self._text = text
+        self._data = np.ndarray(shape, dtype, buffer=raw, offset=address)
+        kwargs = {key: items[key] for key in ('frequency', 'sideband', 'polarization') if items.get(key) is not None}
+        super().__init__(shape=tuple(shape), start_time=items['time'], sample_rate=float(items['sample_rate']),
+                         samples_per_frame=min(shape[0], 1 << 20) if shape[0] else 1, dtype=dtype, **kwargs)
 
     def host_view(self, start, count):
         return None
@@ -404,7 +593,7 @@ def open(name, mode='r', **kwargs):
     """Open an HDF5 file of the reference's intermediate format as a stream
     (reference io/hdf5/base.py:129-222): ``mode='w'`` with ``template=`` (and /
     or the header values as keywords) gives a writer, ``'r'`` a reader for
-    files written by this module."""
+    files written by this module or by the reference's own writer."""
     if mode == 'w':
         return HDF5StreamWriter(name, **kwargs)
     if mode == 'r':

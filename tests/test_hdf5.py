@@ -103,3 +103,67 @@ def test_not_an_hdf5_file(tmp_path):
         hdf5.open(name)
     with pytest.raises(ValueError):
         hdf5.open(name, 'a')
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_reads_a_file_written_the_way_the_reference_writes_it():
+    """tests/golden/reference_style.h5 was written by the REAL h5py + astropy with the calls of the
+    reference's writer (tests/golden/make_hdf5_fixture.py: `fh.create_dataset('header',
+    data=yaml.dump(header))`, `fh.create_dataset('payload', shape, dtype)`; io/hdf5/header.py:76-81,
+    payload.py:72-79): superblock 0, symbol-table root group, version-1 object headers, the header a
+    variable-length string in the global heap, units as astropy dumps them (MHz, a YAML anchor shared
+    between two quantities).  `hdf5.open(name)` must see what h5py + astropy saw
+    (reference_style.json) -- so a user's existing intermediate files keep working."""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(GOLDEN, 'reference_style.json')))
+    fr = hdf5.open(os.path.join(GOLDEN, 'reference_style.h5'))
+    assert list(fr.shape) == want['payload_shape'] and fr.dtype == np.complex64
+    assert fr.sample_rate == want['sample_rate_hz'] == 16e6
+    assert fr.start_time == bt.Time('2020-01-01T00:00:00')
+    assert np.array_equal(np.ravel(fr.frequency), want['frequency_hz'])
+    assert [int(s) for s in np.ravel(fr.sideband)] == want['sideband']
+    assert [str(p) for p in np.ravel(fr.polarization)] == want['polarization']
+    data = fr.read()
+    assert hashlib.sha256(np.ascontiguousarray(data).tobytes()).hexdigest() == want['payload_sha256']
+    fr.seek(100)
+    assert np.array_equal(fr.read(50), data[100:150])
+    # and it is a stream like any other: a task reads from it
+    sq = bt.SetAttribute(fr, frequency=np.array([1e9, 1e9]))
+    assert sq.shape == fr.shape
+    fr.close()
+
+
+def test_header_parser_handles_astropys_dump():
+    """The YAML of a reference-written header, parsed without astropy: units with SI prefixes and
+    reciprocal seconds, anchors, tuples, arrays (doubly base64-encoded buffers), the time."""
+    import json
+    text = json.load(open(os.path.join(GOLDEN, 'reference_style.json')))['header_text']
+    items = hdf5.parse_header(text)
+    assert items['sample_shape'] == (2,) and items['samples_per_frame'] == 300 and items['dtype'] == 'c8'
+    assert items['sample_rate'] == 16e6 and np.array_equal(items['frequency'], [1e9, 1.016e9])
+    assert items['sideband'].dtype == np.int8 and items['polarization'].dtype.kind == 'U'
+    other = text.replace('{unit: MHz}', '{unit: 1 / us}')
+    assert hdf5.parse_header(other)['sample_rate'] == 16e6
+    with pytest.raises(OSError, match='unit'):
+        hdf5.parse_header(text.replace('{unit: MHz}', '{unit: furlong}'))
+    with pytest.raises(OSError, match='required'):
+        hdf5.parse_header('dtype: c8\n')
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason='needs the build container\'s h5py + astropy interpreter')
+def test_fixture_script_reproduces_the_committed_payload(tmp_path):
+    """The committed fixture is what its script makes (same header text, same payload bytes)."""
+    import json
+    import shutil
+    import subprocess
+    work = tmp_path / 'golden'
+    work.mkdir()
+    shutil.copy(os.path.join(GOLDEN, 'make_hdf5_fixture.py'), work)
+    subprocess.run([CONDA, '-W', 'ignore', str(work / 'make_hdf5_fixture.py')], check=True, capture_output=True,
+                   timeout=300)
+    new = json.load(open(work / 'reference_style.json'))
+    old = json.load(open(os.path.join(GOLDEN, 'reference_style.json')))
+    assert new == old
