@@ -118,6 +118,8 @@ evidence)
     BBT_BENCH_BACKEND=gloo timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --blocks 192 --no-cpu --no-host-path > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err; say "gloo2 rc=$?"
     timeout -k 10 300 python3 tools/bench_generic.py > $OUT/generic.txt 2>&1; say "generic rc=$?"
     timeout -k 10 300 python3 tools/bench_host_path.py --blocks 192 --run 16 > $OUT/host_path.jsonl 2> $OUT/host_path.err; say "host rc=$?"
+    timeout -k 10 300 python3 tools/pcie_probe.py > $OUT/pcie.txt 2>&1; say "pcie rc=$?"
+    timeout -k 10 300 python3 tools/import_order.py torch-first > $OUT/import_order.txt 2>&1 && timeout -k 10 300 python3 tools/import_order.py lib-first >> $OUT/import_order.txt 2>&1; say "import order rc=$?"
     for f in bench bench_c4 bench_gloo2; do value $OUT/$f.json $f; done
     cat $OUT/status.txt ;;
 *)

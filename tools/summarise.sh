@@ -18,4 +18,6 @@ cp $G/bench_one.jsonl profiles/${TAG}_bench_one.jsonl
 [ -f $G/next_rows.jsonl ] && cp $G/next_rows.jsonl profiles/${TAG}_next_rows.jsonl
 [ -f $G/generic.txt ] && grep -v amdgpu.ids $G/generic.txt > profiles/${TAG}_generic_lengths.txt
 [ -f $G/host_path.jsonl ] && cp $G/host_path.jsonl profiles/${TAG}_host_path.jsonl
+[ -f $G/pcie.txt ] && grep -v amdgpu.ids $G/pcie.txt > profiles/${TAG}_pcie_probe.txt
+[ -f $G/import_order.txt ] && grep -v amdgpu.ids $G/import_order.txt > profiles/${TAG}_import_order.txt
 ls profiles | grep ${TAG}_ | wc -l
