@@ -2124,8 +2124,14 @@ struct bbt_shift_plan {
     // buffers of a call are aligned to it)
     int merged_n_elem = 0, merged_bytes = 0;
     int* merged_offset = nullptr;
+    // tiled form (k_shift_tiled): per group of merged elements that fill a cache line, the
+    // smallest offset and the span of the offsets; 0 groups: gather only
+    int n_group = 0, window = 0;
+    int* group_lo = nullptr;
+    int* group_span = nullptr;
 };
 
+extern "C" int bbt_shift_plan_destroy(bbt_shift_plan* p);
 extern "C" int bbt_shift_plan_create(bbt_shift_plan** plan, int n_elem, int elem_bytes,
                                      const int32_t* offsets_host) {
     ARG_TRY(plan && offsets_host, "bbt_shift_plan_create: null argument");
@@ -2161,6 +2167,40 @@ extern "C" int bbt_shift_plan_create(bbt_shift_plan** plan, int n_elem, int elem
         return 1;
     }
     p->merged_offset = p->offset + n_elem;
+    // groups of merged elements that fill a 128-byte line: the tiled kernel stages their input
+    // lines in LDS.  Window: 1024 rows (128 KiB, one workgroup per CU) when some group's offsets
+    // span more than 128 rows, else 512 (two per CU); half of it is output rows.
+    const int g_elems = 128 / p->merged_bytes;
+    if (p->merged_bytes >= 8 && p->merged_n_elem % g_elems == 0) {
+        const int ng = p->merged_n_elem / g_elems;
+        std::vector<int> lo(ng), span(ng);
+        int tiled = 0, widest = 0;
+        for (int g = 0; g < ng; ++g) {
+            int a = merged[g * g_elems], b = a;
+            for (int k = 1; k < g_elems; ++k) {
+                a = std::min(a, merged[g * g_elems + k]);
+                b = std::max(b, merged[g * g_elems + k]);
+            }
+            lo[g] = a;
+            span[g] = b - a;
+            if (span[g] <= 512) {
+                ++tiled;
+                widest = std::max(widest, span[g]);
+            }
+        }
+        if (2 * tiled >= ng) {                 // (mostly scattered offsets: the gather kernel as before)
+            if (hipMalloc((void**)&p->group_lo, 2 * ng * sizeof(int)) != hipSuccess ||
+                hipMemcpy(p->group_lo, lo.data(), ng * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(p->group_lo + ng, span.data(), ng * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                fail("bbt_shift_plan_create: uploading the group table failed");
+                bbt_shift_plan_destroy(p);
+                return 1;
+            }
+            p->group_span = p->group_lo + ng;
+            p->n_group = ng;
+            p->window = widest > 128 ? 1024 : 512;
+        }
+    }
     *plan = p;
     return 0;
 }
@@ -2168,6 +2208,7 @@ extern "C" int bbt_shift_plan_create(bbt_shift_plan** plan, int n_elem, int elem
 extern "C" int bbt_shift_plan_destroy(bbt_shift_plan* p) {
     if (!p) return 0;
     if (p->offset) hipFree(p->offset);
+    if (p->group_lo) hipFree(p->group_lo);
     delete p;
     return 0;
 }
@@ -2193,6 +2234,24 @@ extern "C" int bbt_shift_execute(bbt_shift_plan* p, const void* in_dev, void* ou
     ARG_TRY(gx < (1ll << 31) && gy <= 65535, "bbt_shift_execute: too many elements for one call");
     const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (wide && p->n_group) {
+        const int rows = p->window / 2;
+        const long long tx = (n_out + rows - 1) / rows;
+        ARG_TRY(tx < (1ll << 31) && p->n_group <= 65535, "bbt_shift_execute: too many elements for one call");
+        const dim3 tgrid((unsigned)tx, (unsigned)p->n_group);
+        const size_t lds = (size_t)p->window * 128;
+        if (bytes == 16) {
+            if (ensure_dyn_lds((const void*)k_shift_tiled<float4>, lds)) return 1;
+            hipLaunchKernelGGL((k_shift_tiled<float4>), tgrid, block, lds, st, (const float4*)in_dev, (float4*)out_dev,
+                               (long long)n_out, n_elem, offset, p->group_lo, p->group_span, p->window);
+        } else {
+            if (ensure_dyn_lds((const void*)k_shift_tiled<float2>, lds)) return 1;
+            hipLaunchKernelGGL((k_shift_tiled<float2>), tgrid, block, lds, st, (const float2*)in_dev, (float2*)out_dev,
+                               (long long)n_out, n_elem, offset, p->group_lo, p->group_span, p->window);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (bytes == 16)
         hipLaunchKernelGGL((k_shift_samples<float4, ITER>), grid, block, 0, st, (const float4*)in_dev,
                            (float4*)out_dev, (long long)n_out, n_elem, lg_le, offset);

@@ -1663,6 +1663,47 @@ __global__ __launch_bounds__(256) void k_shift_samples(const T* __restrict__ in,
         if (r < n_rows) out[r * n_elem + e] = in[(r + off) * n_elem + e];
 }
 
+// The same, tiled: a workgroup takes one GROUP of neighbouring elements that fill a cache line
+// (G = 128 / sizeof(T)) over `rows` output rows.  Its input lines -- rows [r0 + lo, r0 + rows + hi),
+// lo / hi the smallest / largest offset in the group -- are staged in LDS, each read once and
+// whole (the gather above has every lane ask for its own 16 bytes of a different line, and
+// every line asked for G times), then the output rows are assembled from there.  Worth it while
+// the group's offsets span less than half the window (neighbouring sub-bands of a dispersed
+// band do); a group that spans more takes the gather path in the same launch.
+//   group_lo[g], group_span[g] : smallest offset and hi - lo of group g;  window: LDS rows
+template <typename T>
+__global__ __launch_bounds__(256) void k_shift_tiled(const T* __restrict__ in, T* __restrict__ out,
+                                                     long long n_rows, int n_elem,
+                                                     const int* __restrict__ offset,
+                                                     const int* __restrict__ group_lo,
+                                                     const int* __restrict__ group_span, int window) {
+    constexpr int G = 128 / (int)sizeof(T);
+    constexpr int STEP = 256 / G;                      // rows a workgroup touches per instruction
+    extern __shared__ unsigned char shift_lds_raw[];
+    T* lds = reinterpret_cast<T*>(shift_lds_raw);
+    const int g = blockIdx.y, elem = threadIdx.x % G, row0 = threadIdx.x / G;
+    const int e = g * G + elem;
+    const int lo = group_lo[g], span = group_span[g];
+    const int rows = window / 2;                       // output rows per workgroup
+    const long long r0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * rows;
+    if (r0 >= n_rows) return;
+    const int nr = (int)(n_rows - r0 < rows ? n_rows - r0 : rows);
+    const long long off = offset[e];
+    if (span > window - rows) {                        // offsets too far apart: gather
+        for (int r = row0; r < nr; r += STEP) out[(r0 + r) * n_elem + e] = in[(r0 + r + off) * n_elem + e];
+        return;
+    }
+    const int wrows = nr + span;
+    const T* src = in + ((r0 + lo) * n_elem + e);
+#pragma unroll 8
+    for (int w = row0; w < wrows; w += STEP) lds[w * G + elem] = src[(long long)w * n_elem];
+    __syncthreads();
+    const int d = (int)off - lo;
+    T* dst = out + (r0 * n_elem + e);
+#pragma unroll 8
+    for (int r = row0; r < nr; r += STEP) dst[(long long)r * n_elem] = lds[(r + d) * G + elem];
+}
+
 // Power with the polarization axis anywhere in the sample (reference
 // functions.py:131-143 takes any axis): a complete sample is (outer, 2, inner)
 // complex, X = [:, 0, :], Y = [:, 1, :]; out (n_out, outer, 4, inner) float32 =

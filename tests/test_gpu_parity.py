@@ -961,6 +961,38 @@ def test_inverse_polyphase_filter_bank_one_stream_short_odd_last_frame():
     assert np.abs(y[2000:6000] - x[lo + 2000:lo + 6000]).std() < 0.15
 
 
+def test_shift_samples_tiled_gather_and_mixed_groups():
+    """`ShiftSamples` on wide samples (64 sub-bands x 2 pol): neighbouring sub-bands whose shifts lie
+    close together go through the tiled kernel (input lines staged in LDS), groups whose shifts
+    are scattered through the gather path of the same launch, unaligned or odd layouts through the
+    plain gather kernel -- always `data[indices]` exactly (reference sampling.py:380-425), for
+    whole reads, reads that end inside a tile and the last short tile."""
+    rng = np.random.default_rng(77)
+    n = 40000
+    x = rng.standard_normal((n, 64, 4), dtype=np.float32).view(np.complex64)       # (n, 64, 2)
+    cases = dict(
+        monotone=np.round(3000. * (1. - (400. / (400. + 6.25 * np.arange(64)))**2) / (1. - (400. / 800.)**2)),
+        small=np.arange(64) % 5,
+        scattered=(np.arange(64) * 37) % 1000,
+        mixed=np.where(np.arange(64) < 32, np.arange(64) * 3, (np.arange(64) * 211) % 2900),
+        per_pol=None)
+    for name, shift in cases.items():
+        if shift is None:                       # every stream its own shift: 8-byte elements, 16 per line
+            shift = rng.integers(0, 60, size=(64, 2))
+        else:
+            shift = shift.reshape(64, 1)
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=8192)
+        sh = bt.ShiftSamples(ds, shift, samples_per_frame=8192)
+        full = np.broadcast_to(shift, (64, 2)).astype(int)
+        off = full.max() - full
+        rows = np.arange(sh.shape[0])
+        want = x[rows[:, None, None] + off[None], np.arange(64)[None, :, None], np.arange(2)[None, None, :]]
+        got = sh.read()
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        sh.seek(12345)
+        assert np.array_equal(sh.read(7001), want[12345:12345 + 7001]), name
+
+
 def test_time_delay_golden(golden):
     nh = noise(3000, (2,), 1000, seed=23, fs=1 * u.MHz, frequency=300 * u.MHz,
                sideband=np.array([1, -1]))

@@ -95,6 +95,19 @@ def f2_shift(reps):
     return dict(units=sh.shape[0] * 128, unit='elements', bytes_per_unit=16, seconds=dt)
 
 
+def f2_dedisperse_samples(reps):
+    """Incoherent dedispersion of a channelized band: 64 sub-bands of 6.25 MHz at 400-800 MHz, 2 pol,
+    DM chosen so that the delays span ~3000 samples (monotone in frequency, as real ones are)."""
+    n = 2**21
+    x = randn_c64(n, (64, 2))
+    freq = (403.125e6 + 6.25e6 * np.arange(64)).reshape(64, 1)
+    ds = bt.DeviceStream(x, T0, 6.25e6, samples_per_frame=2**16, frequency=freq, sideband=1)
+    sh = bt.DedisperseSamples(ds, 0.025, samples_per_frame=2**16)
+    dt = timed(lambda: restart([sh], sh, sh.shape[0]), reps)
+    return dict(units=sh.shape[0] * 128, unit='elements', bytes_per_unit=16, seconds=dt,
+                note=f'delays up to {int(np.ptp(sh._shift))} samples')
+
+
 def _unpack_resident(raw, n_frames, frame_nbytes, header_nbytes, bits, spf, n_thread, n_elem, code, reps):
     """bbt_unpack on frames already in HBM (the kernel alone)."""
     hip = bt.hip
@@ -343,7 +356,7 @@ ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_
             pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
             dedisperse_single=dedisperse_single, dedisperse_default=dedisperse_default, chan_single_1024=chan_single_1024,
             fused_single=fused_single, fused_real=fused_real,
-            f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
+            f1_detect=f1_detect, f1_fused=f1_fused, f2_shift=f2_shift, f2_dedisperse_samples=f2_dedisperse_samples, f3_vdif=f3_vdif, f3_vdif_read=f3_vdif_read,
             f3_dada=f3_dada,
             f4_dechan=f4_dechan, f4_ipfb=f4_ipfb)
 
