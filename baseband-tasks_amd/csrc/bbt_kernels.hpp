@@ -1684,12 +1684,15 @@ __global__ __launch_bounds__(256) void k_shift_tiled(const T* __restrict__ in, T
     const int g = blockIdx.y, elem = threadIdx.x % G, row0 = threadIdx.x / G;
     const int e = g * G + elem;
     const int lo = group_lo[g], span = group_span[g];
-    const int rows = window / 2;                       // output rows per workgroup
+    // output rows per workgroup: what the window leaves beside the span of the group's offsets
+    // (the grid is sized for the smallest case, window / 2; surplus workgroups leave at once)
+    const bool tiled = span <= window / 2;
+    const int rows = tiled ? window - span : window / 2;
     const long long r0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * rows;
     if (r0 >= n_rows) return;
     const int nr = (int)(n_rows - r0 < rows ? n_rows - r0 : rows);
     const long long off = offset[e];
-    if (span > window - rows) {                        // offsets too far apart: gather
+    if (!tiled) {                                      // offsets too far apart: gather
         for (int r = row0; r < nr; r += STEP) out[(r0 + r) * n_elem + e] = in[(r0 + r + off) * n_elem + e];
         return;
     }
