@@ -2419,13 +2419,25 @@ extern "C" int bbt_unpack_masked(const void* raw_dev, void* out_dev, int64_t n_f
     const long long by = (per_frame / g + 256 * BBT_UNPACK_ITER - 1) / (256 * BBT_UNPACK_ITER);
     ARG_TRY(by <= 65535, "bbt_unpack: frames of %lld components are too long", per_frame);
     const dim3 grid((unsigned)n_frames, (unsigned)by);
-#define BBT_UNPACK(G_)                                                                           \
-    hipLaunchKernelGGL((k_unpack<G_>), grid, dim3(256), 0, (hipStream_t)stream,                  \
-                       (const unsigned char*)raw_dev, (float*)out_dev, frame_bytes, header_bytes, \
-                       bits, samples_per_frame, n_thread, n_elem, code, (const unsigned char*)valid_dev)
-    if (g == 4) BBT_UNPACK(4);
-    else if (g == 2) BBT_UNPACK(2);
-    else BBT_UNPACK(1);
+    int lg_e = -1;
+    for (int k = 0; k < 16; ++k)
+        if ((1 << k) == n_elem) lg_e = k;
+#define BBT_UNPACK_B(G_, B_)                                                                       \
+    hipLaunchKernelGGL((k_unpack<G_, B_>), grid, dim3(256), 0, (hipStream_t)stream,                \
+                       (const unsigned char*)raw_dev, (float*)out_dev, frame_bytes, header_bytes,  \
+                       bits, samples_per_frame, n_thread, n_elem, code, (const unsigned char*)valid_dev, lg_e)
+#define BBT_UNPACK(G_)                                  \
+    switch (bits) {                                     \
+        case 1: BBT_UNPACK_B(G_, 1); break;             \
+        case 2: BBT_UNPACK_B(G_, 2); break;             \
+        case 4: BBT_UNPACK_B(G_, 4); break;             \
+        case 8: BBT_UNPACK_B(G_, 8); break;             \
+        default: BBT_UNPACK_B(G_, 0); break;            \
+    }
+    if (g == 4) { BBT_UNPACK(4) }
+    else if (g == 2) { BBT_UNPACK(2) }
+    else { BBT_UNPACK(1) }
+#undef BBT_UNPACK_B
 #undef BBT_UNPACK
     HIP_TRY(hipGetLastError());
     return 0;

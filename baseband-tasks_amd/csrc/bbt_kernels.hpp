@@ -2001,12 +2001,17 @@ __device__ __forceinline__ float unpack_level(unsigned v, int bits, int code) {
 // `valid` (optional): one byte per frame; frames flagged 0 (invalid or missing in
 // the file: their bytes are whatever the host put there) are written as zeros,
 // the fill value of `baseband`'s readers.
-template <int G>
+// BITS: the width as a compile-time constant (0: run-time `bits`), so that the level of a code
+// is a few selects or one fused multiply-add instead of a ladder of run-time tests; lg_e >= 0:
+// E is that power of two (the usual case) and the component -> (sample, element) split is a
+// shift instead of a 32-bit division per group.  (2-bit VDIF x 8 channels: 0.41 -> see DESIGN.)
+template <int G, int BITS = 0>
 __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict__ raw,
                                                 float* __restrict__ out, int frame_bytes,
-                                                int header_bytes, int bits, int spf, int n_thread,
+                                                int header_bytes, int bits_rt, int spf, int n_thread,
                                                 int E, int code,
-                                                const unsigned char* __restrict__ valid) {
+                                                const unsigned char* __restrict__ valid, int lg_e) {
+    const int bits = BITS ? BITS : bits_rt;
     const unsigned frame = blockIdx.x;
     const bool good = valid == nullptr || valid[frame] != 0;
     const unsigned set = frame / (unsigned)n_thread, thr = frame - set * (unsigned)n_thread;
@@ -2019,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_unpack(const unsigned char* __restrict_
     for (int it = 0; it < BBT_UNPACK_ITER; ++it) {
         const unsigned q = ((blockIdx.y * BBT_UNPACK_ITER + it) * 256u + threadIdx.x) * G;   // component in the frame
         if (q >= n_comp) return;
-        const unsigned t = q / (unsigned)E, e = q - t * (unsigned)E;
+        const unsigned t = lg_e >= 0 ? q >> lg_e : q / (unsigned)E, e = q - t * (unsigned)E;
         const unsigned bit = q * (unsigned)bits;                    // G * bits divides 32, or is 64
         unsigned long long w = payload[bit >> 5];
         if (G * bits > 32) w |= (unsigned long long)payload[(bit >> 5) + 1] << 32;
