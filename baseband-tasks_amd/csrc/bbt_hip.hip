@@ -731,6 +731,8 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
                         hipStream_t st) {
     // lanes over groups of pairs when there are many (see k_osm_small); the
     // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
+    // (8 pairs for 1024 points -- 128-byte runs, 80 KiB, one 512-thread workgroup per CU -- measured
+    // slower than 4: inverse filter bank 56.9 against 62.1 G)
     constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
     constexpr size_t lds1 = FftGeo<N>::LDS_ELEMS * sizeof(v2);
     const int nblk = ch.reg_count ? ch.reg_count : ch.nblk;
