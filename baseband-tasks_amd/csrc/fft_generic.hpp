@@ -365,9 +365,14 @@ __device__ __forceinline__ void gen_stage_last(const f4* __restrict__ lds, int n
             const f4* src = lds + (j << lg) + col;
             const int mstride = m << lg;
             cf w[R];
+#if BBT_GEN_TW_POWERS
             w[1] = wn[j];                                   // (k == j: ns == m)
 #pragma unroll
             for (int r = 2; r < R; ++r) w[r] = cmul(w[(r + 1) / 2], w[r / 2]);
+#else
+#pragma unroll
+            for (int r = 1; r < R; ++r) w[r] = wn[(r - 1) * m + j];
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 c2 t = f4_to_c2(src[r * mstride]);
@@ -396,9 +401,14 @@ __device__ __forceinline__ void gen_stage_turn(f4* __restrict__ lds, int n, int 
             const f4* src = lds + (j << lg) + col;
             const int mstride = m << lg;
             cf w[R];
+#if BBT_GEN_TW_POWERS
             w[1] = wn[j];
 #pragma unroll
             for (int r = 2; r < R; ++r) w[r] = cmul(w[(r + 1) / 2], w[r / 2]);
+#else
+#pragma unroll
+            for (int r = 1; r < R; ++r) w[r] = wn[(r - 1) * m + j];
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 c2 t = f4_to_c2(src[r * mstride]);
