@@ -600,7 +600,7 @@ def test_short_channelizer(n):
 
 def test_two_level_blocks_on_sixteen_streams():
     """2^17-sample blocks (256 x 512) on 16 and 24 streams: with the stream pairs in eights the
-    column passes take tiles of 8 pairs x 8 (first) / 4 (last) columns (BBT_COL_WIDE), with 12
+    column passes take tiles of 8 pairs x 8 (first) / 4 (last) columns, with 12
     pairs groups of four; plain, with per-stream responses, and with the channelizer folded in."""
     n_fft = 2**17
     for n_stream in (16, 24):

@@ -1,6 +1,6 @@
 """Dedisperse (2^20-sample blocks, DM 100 at 1000 MHz) on S complex streams resident in HBM: G complete
 samples/s and the fraction of 8 TB/s on the algorithmic bytes (dev tool for the many-stream tile choices,
-BBT_COL_PP / BBT_COL_WIDE).  python tools/bench_streams.py [S ...]"""
+the pair-grouped column tiles).  python tools/bench_streams.py [S ...]"""
 import gc
 import json
 import os
@@ -41,7 +41,7 @@ for s in [int(a) for a in sys.argv[1:]] or [16]:
     n = dd.shape[0]
     alg = (8 * 2**20 / spf + 8) * s
     print(json.dumps(dict(streams=s, blocks=blocks, gsamples_per_s=round(n / dt / 1e9, 3),
-                          frac=round(n / dt * alg / 8e12, 4), wide=os.environ.get('BBT_COL_WIDE'))), flush=True)
+                          frac=round(n / dt * alg / 8e12, 4))), flush=True)
     dd.close()
     del x, ds, dd
     gc.collect()
