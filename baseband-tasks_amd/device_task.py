@@ -206,9 +206,7 @@ class DeviceTaskMixin:
             runs.append((f0, f1, pos, done, n))
             pos += n
             done += n
-        if self._download is None:
-            self._download = host_pipeline.Stream()
-        down = self._download
+        down = host_pipeline.copy_streams()[1]
         # two result buffers in turn: run m + 2 is computed into the buffer run m came from, once
         # that run has gone down
         buffers = [self._cache_buffer, self._cache_buffer_b]
@@ -237,7 +235,6 @@ class DeviceTaskMixin:
         down.synchronize()
         return out
 
-    _download = None
     _cache_buffer_b = None
 
     def read(self, count=None, out=None):

@@ -230,6 +230,37 @@ def current_stream_wait(event):
     hip.check(hip.lib().bbt_stream_wait_event(hip.get_stream(), event._h))
 
 
+# The copy engine of a HIP stream is chosen at its FIRST copy and kept (measured on MI355X, ROCm
+# 7.2, round 4: `H2D on s1; sync; D2H on s2; sync` and both streams share one SDMA engine from then
+# on -- 28.6 GB/s each way whatever is done later; first copies issued together: 48.5 GB/s each
+# way).  A reader's first run uploads, computes and downloads one after the other, which is the
+# bad order.  So the process has ONE upload and ONE download stream, created together and primed
+# with a concurrent pair of small copies; every `HostUploader` and every task's download use them
+# (one bus, one queue per direction: nothing is lost by sharing).
+_copy_pair = None
+_copy_pair_lock = threading.Lock()
+
+
+def copy_streams():
+    """(upload stream, download stream) of this process, on different copy engines."""
+    global _copy_pair
+    if _copy_pair is None:
+        with _copy_pair_lock:
+            if _copy_pair is None:
+                up, down = Stream(), Stream()
+                n = 8 << 20
+                a, b = pinned_empty((n,), np.uint8), pinned_empty((n,), np.uint8)
+                da, db = hip.DeviceArray((n,), np.uint8), hip.DeviceArray((n,), np.uint8)
+                lib = hip.lib()
+                for _ in range(2):                       # (both queued before either can finish)
+                    hip.check(lib.bbt_memcpy_h2d(da.ptr, a.ctypes.data, n, up.handle))
+                    hip.check(lib.bbt_memcpy_d2h(b.ctypes.data, db.ptr, n, down.handle))
+                up.synchronize()
+                down.synchronize()
+                _copy_pair = (up, down)
+    return _copy_pair
+
+
 # --------------------------------------------------------------------------- uploads
 class _Upload:
     __slots__ = ('start', 'count', 'dev', 'event', 'staging')
@@ -250,7 +281,7 @@ class HostUploader:
         self._ih = weakref.ref(ih)
         self._row = tuple(ih.shape[1:])
         self._dtype = np.dtype(ih.dtype)
-        self._stream = Stream()
+        self._stream = copy_streams()[0]
         self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='bbt-upload')
         self._device = hip.get_device() if hasattr(hip, 'get_device') else 0
         self._pending = None            # (start, count, future): the one load in flight

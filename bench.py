@@ -308,8 +308,10 @@ def host_path(bt, torch, blocks=96, reps=3):
                 c()
         s1.synchronize(), s2.synchronize()
         return reps * m / (time.perf_counter() - t0) / 1e9
-    alone = min(rate(up), rate(down))
+    # (both directions FIRST: a stream keeps the copy engine of its first copy, and two streams
+    # whose first copies do not overlap end up sharing one -- host_pipeline.copy_streams)
     duplex = rate(up, down)
+    alone = min(rate(up), rate(down))
     packed = None
     try:
         packed = host_path_packed(bt, hp, blocks, run, reps)
@@ -322,10 +324,10 @@ def host_path(bt, torch, blocks=96, reps=3):
                what='Channelize(Dedisperse(HostStream over page-locked memory)).read() -> NumPy array: '
                     'PCIe both ways, three streams (upload / transforms / download of consecutive runs '
                     'overlap).  pcie_gbps_one_way_alone / _each_way_together: 256 MiB copies on two fresh '
-                    'streams of this process, one direction / both at once -- the latter is a floor, not a '
-                    'bound: the streams of a process share GPU_MAX_HW_QUEUES hardware queues (raised to 16 '
-                    'here; with the default 4 the upload and the download can land on one queue and take '
-                    'turns: 28 GB/s each way where separate queues give 45-49)',
+                    'streams, both directions at once first (a stream keeps the copy engine of its first '
+                    'copy: two streams whose first copies do not overlap share one engine and take turns, '
+                    '28.6 GB/s each way, which is what held this path at 1.7 G before the process-wide primed '
+                    'stream pair of host_pipeline.copy_streams)',
                packed_input=packed)
     ch.close()
     dd.close()

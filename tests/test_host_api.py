@@ -557,6 +557,7 @@ def test_host_uploader_takes_the_block_before_the_ordering_event_and_loads_each_
     fake = _FakeHip()
     monkeypatch.setattr(hp, 'hip', fake)
     monkeypatch.setattr(hp, 'is_pinned', lambda a: True)
+    monkeypatch.setattr(hp, '_copy_pair', (hp.Stream(), hp.Stream()))      # (no priming copies without a GPU)
     data = np.arange(64 * 2, dtype=np.float32).view(np.complex64).reshape(64, 1)
 
     class Src:

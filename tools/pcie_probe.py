@@ -36,6 +36,21 @@ def rate(label, fn, reps=5, nbytes=n):
     print(f'{label:44s} {nbytes / dt / 1e9:7.2f} GB/s')
 
 
+# Both directions at once FIRST, on the fresh streams: the copy engine of a stream is chosen at its
+# first copy and kept; if the first copies of s1 and s2 do not overlap (as in the lines below, run
+# in this order in rounds 3 and 4: 28.6 GB/s each way) the two streams share one engine for good.
+rate('H2D + D2H pinned, first use of both streams together (each way)',
+     lambda: (hip.check(L.bbt_memcpy_h2d(dev_a.ptr, pin_a.ctypes.data, n, s1.handle)),
+              hip.check(L.bbt_memcpy_d2h(pin_b.ctypes.data, dev_b.ptr, n, s2.handle))))
+s3, s4 = hp.Stream(), hp.Stream()
+hip.check(L.bbt_memcpy_h2d(dev_a.ptr, pin_a.ctypes.data, n, s3.handle)); s3.synchronize()
+hip.check(L.bbt_memcpy_d2h(pin_b.ctypes.data, dev_b.ptr, n, s4.handle)); s4.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    hip.check(L.bbt_memcpy_h2d(dev_a.ptr, pin_a.ctypes.data, n, s3.handle))
+    hip.check(L.bbt_memcpy_d2h(pin_b.ctypes.data, dev_b.ptr, n, s4.handle))
+s3.synchronize(); s4.synchronize()
+print(f"{'H2D + D2H pinned, streams first used one after the other (each way)':44s} {5 * n / (time.perf_counter() - t0) / 1e9:7.2f} GB/s")
 rate('H2D pinned (hipHostMalloc)', lambda: hip.check(L.bbt_memcpy_h2d(dev_a.ptr, pin_a.ctypes.data, n, s1.handle)))
 rate('D2H pinned', lambda: hip.check(L.bbt_memcpy_d2h(pin_b.ctypes.data, dev_b.ptr, n, s2.handle)))
 rate('H2D + D2H pinned, two streams (each way)', lambda: (hip.check(L.bbt_memcpy_h2d(dev_a.ptr, pin_a.ctypes.data, n, s1.handle)),
