@@ -152,16 +152,43 @@ class DeviceTaskMixin:
         first = self.offset // spf
         last = (self.offset + count - 1) // spf + 1
         if last - first > self.max_frames_per_call:
-            # too much for one cache: assemble piecewise into a fresh array
+            # too much for one cache: assemble piecewise into a fresh array.  `max_frames_per_call`
+            # bounds what a run asks of the upstream task (its cache); when the frames are
+            # computed straight into the result from a stream that is resident in HBM anyway,
+            # nothing needs bounding and all whole frames go in one run
             out = DeviceArray((count,) + tuple(self.sample_shape), self._device_dtype)
+            per = self.max_frames_per_call
+            try:
+                span = self._input_span(first, first + 1)
+            except Exception:
+                span = None
+            if span is not None and getattr(span[0], '_resident', False):
+                per = last - first
             done = 0
             while done < count:
                 pos = self.offset
                 f0 = pos // spf
-                f1 = min(last, f0 + self.max_frames_per_call)
-                cache, c0 = self._ensure_frames(f0, f1)
-                n = min(count - done, self._frame_span(f0, f1)[1] - pos)
-                out[done:done + n].copy_from_device(cache[pos - c0:pos - c0 + n])
+                left = count - done
+                direct = pos == f0 * spf                  # (a run that starts inside a frame: that frame, via the cache)
+                f1 = f0 + 1
+                if direct:
+                    f1 = min(last, f0 + per)
+                    if self._frame_span(f0, f1)[1] - pos > left:
+                        f1 = f0 + left // spf             # whole frames only; the rest of the request is a partial one
+                    if f1 == f0:
+                        direct, f1 = False, f0 + 1
+                s0, s1 = self._frame_span(f0, f1)
+                n = min(left, s1 - pos)
+                if direct:
+                    # whole frames: computed straight into their place -- no cache, no copy; the
+                    # runs fill disjoint slices of the fresh array, so deferred plan calls need not
+                    # wait for each other (`DeviceArray.fresh`) and the lanes run on from run to run
+                    piece = out[done:done + n]
+                    piece.fresh = True
+                    self._compute_frames(f0, f1, piece)
+                else:
+                    cache, c0 = self._ensure_frames(f0, f1)
+                    out[done:done + n].copy_from_device(cache[pos - c0:pos - c0 + n])
                 done += n
                 self.offset = pos + n
             return out

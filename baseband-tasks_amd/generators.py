@@ -120,6 +120,9 @@ class DeviceStream(Base):
     returns zero-copy views, so a task chain on top never touches the host.
     """
     _produces_on_device = True
+    #: any range of the stream is there for the taking: a task that reads straight from it need
+    #: not bound how much it asks for at once (`DeviceTaskMixin.read_device`)
+    _resident = True
 
     def __init__(self, data, start_time, sample_rate, samples_per_frame=None, **kwargs):
         if isinstance(data, np.ndarray):

@@ -335,21 +335,52 @@ class _Pending:
 
 
 class _Allocation:
-    """Owns one block of the device memory pool."""
-    pending = None              # _Pending of the deferred call that last wrote or read here, if any
+    """Owns one block of the device memory pool, and the calls it is still owed: deferred plan
+    calls that are WRITING somewhere in it (`writes`) or READING it (`reads`).  A later reader
+    must come after the writes, a later writer -- or the return of the block to the pool -- after
+    both; calls that only read may share it, and so may calls that write regions the caller knows
+    to be disjoint (`DeviceArray.fresh`: the runs of one big read)."""
+    writes = ()
+    reads = ()
 
     def __init__(self, nbytes):
         self.ptr = C.c_void_p()
         self.nbytes = int(nbytes)
         check(lib().bbt_malloc(C.byref(self.ptr), max(self.nbytes, 1)))
 
-    def settle(self, stream=_NO_STREAM):
-        """Order ``stream`` (default: the package's current stream) after the deferred call that
-        last wrote or read this block; from then on the block is an ordinary one of that stream."""
-        p = self.pending
-        if p is not None:
-            self.pending = None
-            check(lib().bbt_stream_wait_event(_stream if stream is _NO_STREAM else stream, p.done.event))
+    @property
+    def pending(self):
+        return bool(self.writes or self.reads)
+
+    _MAX_OWED = 64
+
+    def owe(self, pending, write):
+        """Note a deferred call that writes (reads) this block.  The lists stay short: beyond
+        _MAX_OWED entries the oldest is waited for on the current stream (it finished long ago:
+        the wait costs nothing) and let go."""
+        owed = (self.writes if write else self.reads) + (pending,)
+        if len(owed) > self._MAX_OWED:
+            old, owed = owed[0], owed[1:]
+            check(lib().bbt_stream_wait_event(_stream, old.done.event))
+            old.done.release()
+        if write:
+            self.writes = owed
+        else:
+            self.reads = owed
+
+    def settle(self, stream=_NO_STREAM, reads=True):
+        """Order ``stream`` (default: the package's current stream) after the deferred calls that
+        still write this block and -- unless ``reads`` is False: the caller only wants to read --
+        after those that still read it."""
+        owed = self.writes + (self.reads if reads else ())
+        if not owed:
+            return
+        self.writes = ()
+        if reads:
+            self.reads = ()
+        target = _stream if stream is _NO_STREAM else stream
+        for p in owed:
+            check(lib().bbt_stream_wait_event(target, p.done.event))
             p.done.release()
 
     def __del__(self):
@@ -385,16 +416,29 @@ class DeviceArray:
         still owes this memory (`_Allocation.pending`), the current stream is first ordered after
         that call -- every binding, copy and interop path goes through here."""
         o = self.owner
-        if o.__class__ is _Allocation and o.pending is not None:
+        if o.__class__ is _Allocation and (o.writes or o.reads):
             o.settle()
         return self._ptr
+
+    def ptr_to_read(self):
+        """The address for a use that only READS the array: ordered after the deferred calls that
+        still write its allocation, not after those that merely read it too."""
+        o = self.owner
+        if o.__class__ is _Allocation and o.writes:
+            o.settle(reads=False)
+        return self._ptr
+
+    #: Set by a caller that hands this view to a plan call as output and KNOWS that no call still
+    #: owed to the allocation touches the view's region (the consecutive runs of one big read fill
+    #: disjoint slices of a fresh array): the call is then not ordered after those calls.
+    fresh = False
 
     @property
     def pending(self):
         """Is a deferred plan call still writing or reading this array's allocation (nobody has
         waited for it yet)?"""
         o = self.owner
-        return o.__class__ is _Allocation and o.pending is not None
+        return o.__class__ is _Allocation and bool(o.writes or o.reads)
 
     @property
     def size(self):
@@ -664,9 +708,13 @@ class OsmPlan(_Plan):
         """One execute entry point of the C ABI on (in_dev, out_dev).  When this package owns the
         output's allocation and the plan has lanes, the call is issued with a deferred join
         (`DEFER_JOIN`): its completion event is left with the output's allocation."""
-        src, dst = in_dev.ptr, out_dev.ptr          # (orders the stream after earlier deferred writers)
         owner = out_dev.owner
-        if not (DEFER_JOIN and self._has_lanes and owner.__class__ is _Allocation):
+        defer = DEFER_JOIN and self._has_lanes and owner.__class__ is _Allocation
+        # the input is read: after the calls that still write it; the output is written: after
+        # every call still owed to its allocation -- unless the caller vouches for the region
+        src = in_dev.ptr_to_read() if defer else in_dev.ptr
+        dst = out_dev._ptr if (defer and out_dev.fresh) else out_dev.ptr
+        if not defer:
             check(fn(self._h, src, dst, *args, _stream))
             return
         ev = _events.take()
@@ -685,9 +733,9 @@ class OsmPlan(_Plan):
         src_owner = in_dev.owner
         shared = src_owner.__class__ is _Allocation and src_owner is not owner
         done = _Done(ev, 2 if shared else 1)
-        owner.pending = _Pending(done, (src_owner, self))
+        owner.owe(_Pending(done, (src_owner, self)), write=True)
         if shared:
-            src_owner.pending = _Pending(done, (self,))
+            src_owner.owe(_Pending(done, (self,)), write=False)
 
     @staticmethod
     def _descriptors(in_off, out_off, valid_start, valid_count):

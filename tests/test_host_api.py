@@ -651,8 +651,9 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     names = [e[0] for e in fake.log]
     assert names.index('bbt_osm_plan_defer') < names.index('bbt_osm_execute')
     ev = [e for e in fake.log if e[0] == 'bbt_osm_plan_defer'][0][2]
-    assert y.pending and x.pending and y.owner.pending.done is x.owner.pending.done
-    assert y.owner.pending.done.refs == 2 and not hip._events._idle
+    assert y.pending and x.pending and y.owner.writes[0].done is x.owner.reads[0].done
+    assert not y.owner.reads and not x.owner.writes                 # (written / read, not the reverse)
+    assert y.owner.writes[0].done.refs == 2 and not hip._events._idle
     # views share the allocation's state; reading the address of one queues the wait, once
     view = y[10:20].reshape(20)
     assert view.pending
@@ -660,12 +661,34 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     assert view.ptr == y._ptr + 10 * 16
     assert fake.log[n0:] == [('bbt_stream_wait_event', None, ev)] and not y.pending and x.pending
     assert y.ptr and len(fake.log) == n0 + 1            # (settled: no second wait)
-    # the next call on the same input: the input's turn to wait, then the event is free again
+    # the next call reads the same input: readers share it -- no wait for the first call -- and
+    # takes a second event; whoever WRITES the input next waits for both readers
     n0 = len(fake.log)
     plan.execute(x, y, *desc)
     after = [e for e in fake.log[n0:] if e[0] in ('bbt_stream_wait_event', 'bbt_osm_plan_defer', 'bbt_osm_execute')]
-    assert after[0] == ('bbt_stream_wait_event', None, ev) and after[1][0] == 'bbt_osm_plan_defer'
-    assert after[1][2] == ev                             # (the pooled event, taken again)
+    assert [e[0] for e in after] == ['bbt_osm_plan_defer', 'bbt_osm_execute'] and after[0][2] != ev
+    assert len(x.owner.reads) == 2
+    n0 = len(fake.log)
+    x.fill_bytes(0)
+    waits = [e for e in fake.log[n0:] if e[0] == 'bbt_stream_wait_event']
+    assert len(waits) == 2 and not x.pending and fake.log[-1][0] == 'bbt_memset'
+    # runs of one big read: disjoint slices of a fresh array, marked `fresh`, do not wait for
+    # each other; the reader of the whole waits for all of them
+    big = hip.DeviceArray((3000, 2), np.complex64)
+    n0 = len(fake.log)
+    for k in range(3):
+        piece = big[1000 * k:1000 * (k + 1)]
+        piece.fresh = True
+        plan.execute(x, piece, *desc)
+    assert 'bbt_stream_wait_event' not in [e[0] for e in fake.log[n0:]] and len(big.owner.writes) == 3
+    n0 = len(fake.log)
+    assert big.ptr and [e[0] for e in fake.log[n0:]] == ['bbt_stream_wait_event'] * 3
+    # ... and without the mark a second writer of the same allocation does wait
+    plan.execute(x, big[:1000], *desc)
+    n0 = len(fake.log)
+    plan.execute(x, big[1000:2000], *desc)
+    assert fake.log[n0][0] == 'bbt_stream_wait_event'
+    del big
     # a block that is freed while a call is owed is ordered first
     n0 = len(fake.log)
     y_ptr = y._ptr
@@ -686,12 +709,73 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
         dtype = np.dtype(np.complex64)
     t = Task()
     a = t._out_buffer(100)
-    a.owner.pending = hip._Pending(hip._Done(hip._events.take(), 1), ())
+    a.owner.owe(hip._Pending(hip._Done(hip._events.take(), 1), ()), write=True)
     b = t._out_buffer(100)
     assert b.owner is not a.owner and t._cache_buffer_b.owner is a.owner
     assert t._out_buffer(100).owner is b.owner           # (nothing owed on b: no switch)
-    b.owner.pending = hip._Pending(hip._Done(hip._events.take(), 1), ())
+    b.owner.owe(hip._Pending(hip._Done(hip._events.take(), 1), ()), write=True)
     c = t._out_buffer(100)
     assert c.owner is a.owner                            # back to the first one ...
     n0 = len(fake.log)
     assert c.ptr and fake.log[n0][0] == 'bbt_stream_wait_event'      # ... after the call before last
+
+
+def test_big_reads_are_cut_into_whole_frame_runs_written_in_place(monkeypatch):
+    """`DeviceTaskMixin.read_device` for more frames than one cache holds (no GPU: a task that logs):
+    whole frames are computed straight into their slice of the result (marked `fresh`: deferred
+    plan calls on disjoint slices do not wait for each other), only a frame the request starts or
+    ends inside goes through the cache and a copy; runs are `max_frames_per_call` long -- or, when
+    the task reads straight from a stream that is resident in HBM, as long as the request."""
+    import baseband_tasks_amd.device_task as dt
+    log = []
+
+    class Arr:
+        fresh = False
+
+        def __init__(self, n, base=0):
+            self.n, self.base = n, base
+
+        def __getitem__(self, sl):
+            return Arr(sl.stop - sl.start, self.base + sl.start)
+
+        def copy_from_device(self, other):
+            log.append(('copy', self.base, self.n, other.base))
+
+    class Source:
+        _resident = False
+
+    class T(dt.DeviceTaskMixin):
+        samples_per_frame, shape, sample_shape, dtype = 10, (95,), (), np.dtype('c8')
+        max_frames_per_call = 3
+
+        def __init__(self, offset):
+            self.offset = offset
+
+        def _prepare_read(self, count, out):
+            return count
+
+        def _compute_frames(self, f0, f1, out):
+            log.append(('direct', f0, f1, out.base, out.n, out.fresh))
+
+        def _ensure_frames(self, f0, f1):
+            log.append(('cache', f0, f1))
+            return Arr(100, f0 * 10), f0 * 10
+
+        def _input_span(self, a, b):
+            return Source, 0, 0
+    monkeypatch.setattr(dt, 'DeviceArray', lambda shape, dtype: Arr(shape[0]))
+    cases = {
+        (False, 0, 95): [('direct', 0, 3, 0, 30, True), ('direct', 3, 6, 30, 30, True), ('direct', 6, 9, 60, 30, True),
+                         ('direct', 9, 10, 90, 5, True)],
+        (False, 3, 80): [('cache', 0, 1), ('copy', 0, 7, 3), ('direct', 1, 4, 7, 30, True), ('direct', 4, 7, 37, 30, True),
+                         ('direct', 7, 8, 67, 10, True), ('cache', 8, 9), ('copy', 77, 3, 80)],
+        (True, 0, 95): [('direct', 0, 10, 0, 95, True)],
+        (True, 25, 66): [('cache', 2, 3), ('copy', 0, 5, 25), ('direct', 3, 9, 5, 60, True), ('cache', 9, 10),
+                         ('copy', 65, 1, 90)],
+    }
+    for (resident, offset, count), want in cases.items():
+        Source._resident = resident
+        log.clear()
+        task = T(offset)
+        task.read_device(count)
+        assert log == want and task.offset == offset + count, (resident, offset, count, log)
