@@ -1444,7 +1444,6 @@ int bbt_osm_execute(bbt_osm_plan* p, const void* in_dev, void* out_dev, int64_t 
     ARG_TRY(p && in_dev && out_dev, "bbt_osm_execute: null argument");
     if (osm_check_blocks(p, "bbt_osm_execute", n_blocks, in_off, out_off, valid_start, valid_count))
         return 1;
-    hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
     PlanCall call(p, take, n_blocks);
     return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, call,
@@ -1475,7 +1474,6 @@ int bbt_osm_execute_flat(bbt_osm_plan* p, const void* in_dev, void* out_dev, int
                     valid_elems[b] >= 0 && valid_elems[b] % 2 == 0 &&
                     (int64_t)valid_start[b] * p->S + first_elem + valid_elems[b] <= p->n * p->S,
                 "%s: block %lld keeps elements outside the block", who, (long long)b);
-    hipStream_t st = (hipStream_t)stream;
     SpecOut so = {};
     PlanCall call(p, take, n_blocks);
     return osm_run_all(p, (const float2*)in_dev, (float2*)out_dev, n_blocks, so, call,
