@@ -1073,18 +1073,29 @@ struct PlanCall {
     hipEvent_t defer;           // the caller's completion event, or null
     bool fork;                  // chunks go to the lane streams
     bool deferred;              // ... and `st` is not joined after them
-    hipStream_t fin;
+    hipStream_t fin;            // where the call ends
+    hipStream_t run;            // where chunks that are not forked run: `st`, or -- a deferred call of a
+                                // plan without lanes (one kernel per chunk) -- the tail stream, so that
+                                // what the caller queues on `st` next (the upstream task's kernels for
+                                // the following run) overlaps it
     PlanCall(bbt_osm_plan* plan, DeferTake& take, int64_t n_blocks)
         : p(plan), st(take.st), lock(plan->mu), defer(take.hand_over()) {
         const int64_t n_chunks = (n_blocks + p->chunk - 1) / p->chunk;
-        const bool lanes_ok = p->lanes > 1 && !(p->timing && p->timing_isolated) && n_chunks > 0;
-        deferred = defer && lanes_ok && p->tail_stream;
+        const bool usual = !(p->timing && p->timing_isolated);
+        const bool lanes_ok = p->lanes > 1 && usual && n_chunks > 0;
+        const bool aside = p->lanes == 1 && usual;
+        deferred = defer && p->tail_stream && (lanes_ok || aside);
         fork = lanes_ok && (n_chunks > 1 || deferred);
         fin = deferred ? p->tail_stream : st;
-        // (two deferred forking calls in a row: nothing of the earlier one is touched outside
-        // the lanes' own order, see above)
+        run = deferred && !fork ? p->tail_stream : st;
+        // (two deferred calls in a row: nothing of the earlier one is touched outside the lanes'
+        // -- the tail stream's -- own order, see above)
         if (p->ev_done_set && !(deferred && p->last_forked_deferred))
             (void)hipStreamWaitEvent(st, p->ev_done, 0);
+        if (run != st) {                   // the tail stream takes over from the caller's
+            (void)hipEventRecord(p->ev_fork, st);
+            (void)hipStreamWaitEvent(run, p->ev_fork, 0);
+        }
     }
     ~PlanCall() {
         if (defer) (void)hipEventRecord(defer, fin);
@@ -1113,7 +1124,7 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
         for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
         const int l = fork ? (int)((l0 + c) % p->lanes) : 0;
         const bool sample = !fork || (c / p->lanes) % p->timing_stride == 0;
-        if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : st, sample))
+        if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : call.run, sample))
             return 1;
     }
     if (fork) {
@@ -1367,6 +1378,14 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         }
     } else {
         p->lanes = 1;
+    }
+    if (p->lanes == 1) {
+        // (no lanes: a deferred call runs on the tail stream, beside what the caller queues next)
+        if (hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking) != hipSuccess ||
+            (!p->ev_fork && hipEventCreateWithFlags(&p->ev_fork, BBT_EV_ORDER) != hipSuccess) ||
+            hipEventCreateWithFlags(&p->ev_tail[0], BBT_EV_ORDER) != hipSuccess ||
+            hipEventCreateWithFlags(&p->ev_tail[1], BBT_EV_ORDER) != hipSuccess)
+            return bail(fail("bbt_osm_plan_create: creating the tail stream failed"));
     }
     if (hipEventCreateWithFlags(&p->ev_done, BBT_EV_ORDER) != hipSuccess)
         return bail(fail("bbt_osm_plan_create: creating the completion event failed"));
@@ -1676,7 +1695,6 @@ int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, 
                     valid_start + hop <= p->n,
                 "bbt_osm_execute_regular: blocks keep [%d, %lld) outside [0, %lld)", valid_start,
                 (long long)(valid_start + hop), (long long)p->n);
-        hipStream_t st = (hipStream_t)stream;
         SpecOut so = {};
         PlanCall call(p, take, 0);         // (one-kernel plans have no lanes)
         const int64_t per_launch = std::min<int64_t>(1 << 20, ((1ll << 31) - 1) / p->npair);
@@ -1689,7 +1707,7 @@ int bbt_osm_execute_regular(bbt_osm_plan* p, const void* in_dev, void* out_dev, 
             ch.b[0].out_off = out_off0 + b0 * hop;
             ch.b[0].valid_start = valid_start;
             ch.b[0].valid_count = (int)hop;
-            if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, nullptr, st)) return 1;
+            if (osm_run_chunk(p, (const float2*)in_dev, (float2*)out_dev, ch, so, nullptr, call.run)) return 1;
         }
         return 0;
     }

@@ -637,8 +637,20 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
     }
     const int npg = (S >> 1) / PP;
     const int pl = threadIdx.x % PP, tau = threadIdx.x / PP;
-    const int sp = (vb % npg) * PP + pl;
-    const OsmBlock blk = osm_block(ch, vb / npg);
+    // Which (block, pair group) a workgroup takes.  Default: consecutive virtual ids = the pair
+    // groups of one block (their 64-byte runs share lines), so an XCD holds a few whole blocks.
+    // With many pair groups (InversePolyphaseFilterBank: one response column per polyphase phase,
+    // 8 MiB in all) an XCD instead takes an eighth of the GROUPS of every block of the launch:
+    // its share of the response (1 MiB) then stays in its L2 from block to block instead of
+    // being fetched again for each -- the response was 11 % of that task's traffic.
+    unsigned grp = vb % npg, bix = vb / npg;
+    if (npg >= 64 && npg % 8 == 0 && gridDim.x % 8 == 0) {
+        const unsigned per = gridDim.x / 8, x = vb / per, l = vb - x * per, gpx = npg / 8;
+        grp = x * gpx + l % gpx;
+        bix = l / gpx;
+    }
+    const int sp = grp * PP + pl;
+    const OsmBlock blk = osm_block(ch, bix);
     const float2* src = in + ((blk.in_off + tau) * S + 2 * sp);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = ld_ext(src + (long long)T * j * S);

@@ -687,7 +687,8 @@ class OsmPlan(_Plan):
             idx = idx_arr.ctypes.data_as(_pi32)
         check(lib().bbt_osm_plan_create(C.byref(self._h), self.n_fft, self.n_stream, n_resp,
                                         resp_ptr, on_dev, idx))
-        # (plans of more than one kernel run chunks of blocks on internal streams, the lanes)
+        # (plans of more than one kernel run chunks of blocks on internal streams, the lanes;
+        # one-kernel plans run a deferred call on a stream of their own beside the caller's)
         self._has_lanes = self.info()['n1'] > 1
 
     def info(self):
@@ -709,7 +710,7 @@ class OsmPlan(_Plan):
         output's allocation and the plan has lanes, the call is issued with a deferred join
         (`DEFER_JOIN`): its completion event is left with the output's allocation."""
         owner = out_dev.owner
-        defer = DEFER_JOIN and self._has_lanes and owner.__class__ is _Allocation
+        defer = DEFER_JOIN and owner.__class__ is _Allocation
         # the input is read: after the calls that still write it; the output is written: after
         # every call still owed to its allocation -- unless the caller vouches for the region
         src = in_dev.ptr_to_read() if defer else in_dev.ptr

@@ -164,8 +164,12 @@ int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* c
  * channelizer): whoever consumes `out_dev` -- or frees or overwrites `in_dev` or `out_dev` --
  * must first wait for `done` (bbt_stream_wait_event, bbt_event_sync).  Consecutive deferred
  * calls on one plan flow into each other: lane order protects the work buffers, the seam
- * buffer has two turns.  Calls that have no lanes to leave behind (one-kernel plans, the
- * isolated timing mode) simply record `done` on `stream` at their end.  done == NULL cancels.
+ * buffer has two turns.  A plan without lanes (one kernel per chunk: n_fft <= 4096, or <= 8192
+ * on the generic path) runs a deferred call on an internal stream of its own, after what was
+ * queued on `stream` before it and beside what is queued there next -- the upstream task's
+ * kernels for the following run (InversePolyphaseFilterBank: Dechannelize of run k + 1 beside the
+ * deconvolution of run k).  The isolated timing mode simply records `done` on `stream`.
+ * done == NULL cancels.
  * The Python host layer uses this for every plan call whose output it owns (hip.py: the event
  * travels with the DeviceArray and is waited for by the next thing that touches it). */
 int bbt_osm_plan_defer(bbt_osm_plan* plan, bbt_event done);

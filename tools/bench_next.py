@@ -170,7 +170,7 @@ def f4_dechan(reps):
 def f4_ipfb(reps):
     n_spec, n_chan = 2**17, 1024
     # block length along the block axis: a parameter of the task (samples_per_frame).  Measured on
-    # MI355X (round 4, complete samples/s): 512 rows 63.7 G, 1024 64.9 G, 2048 56.4 G, 4096 51.4 G --
+    # MI355X (round 4, complete samples/s): 512 rows 64.5 G, 1024 67.6 G, 2048 56.4 G, 4096 54.8 G --
     # shorter blocks waste more on the 67 rows of padding but their transforms take 4 or 8 stream
     # pairs per workgroup (64- / 128-byte runs) at three workgroups per CU
     rows = int(os.environ.get('IPFB_ROWS', '1024'))
