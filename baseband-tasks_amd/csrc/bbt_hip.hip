@@ -666,6 +666,7 @@ struct bbt_osm_plan {
     cf* wn2 = nullptr;          // W_{n2}^k (shared table)
     cf* tlo = nullptr;          // W_N^i, i < 4096        (owned)
     cf* thi = nullptr;          // W_N^{4096 j}           (owned)
+    cf* tws = nullptr;          // W_N^{k1 m r}, [n1][g2.fac[0]], m = n2 / g2.fac[0]   (owned)
     int gen_ct = 1;             // columns per tile of the column passes
     // pair-planar hand-over (bbt_osm_plan_set_layout; OsmChunk::in_plane / out_plane)
     long long in_plane = 0, out_plane = 0;
@@ -959,7 +960,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             if (timed) HIP_TRY(hipEventRecord(e[1], st));
             hipLaunchKernelGGL(k_gen_row, dim3(p->n1, ch.nblk * p->npair), dim3(gen_threads(p->n2)),
                                lds_r, st, work, p->n1, p->resp, p->resp_index, p->npair, p->g2, p->wn2, p->g2r, p->wn2r,
-                               p->tlo, p->thi);
+                               p->tlo, p->thi, p->tws);
             if (timed) HIP_TRY(hipEventRecord(e[2], st));
             hipLaunchKernelGGL((k_gen_col<false>), gcol, bcol, lds_c, st, in, out, work, ch, p->S, p->n2,
                                ct, p->g1, p->wn1);
@@ -1241,6 +1242,15 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if (p->n1 > 1) {
             if (get_gen_table(&p->g1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
                 return bail(1);
+            {   // the uniform factors of the row kernel's four-step twiddles (GenRowSrc)
+                const int r0 = p->g2.fac[0];
+                const long long m = p->n2 / r0;
+                std::vector<cf> t((size_t)p->n1 * r0);
+                for (int k1 = 0; k1 < p->n1; ++k1)
+                    for (int r = 0; r < r0; ++r)
+                        t[(size_t)k1 * r0 + r] = unit_root((long long)k1 * m % n_fft * r, n_fft);
+                if (upload(&p->tws, t)) return bail(1);
+            }
             // columns per tile: a power of two (gen_stage), as many as fit the LDS tile up to 8
             // (128-byte runs of the stream and of the work buffer; measured: 8 columns 18.9, 16
             // columns 18.1, 4 columns 17.3 Gsamples/s for the 1 666 980-sample block)
@@ -1407,6 +1417,7 @@ int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     if (p->twg) hipFree(p->twg);
     if (p->tlo) hipFree(p->tlo);
     if (p->thi) hipFree(p->thi);
+    if (p->tws) hipFree(p->tws);
     for (int l = 0; l < BBT_MAX_LANES; ++l) {
         if (p->lane_stream[l]) {
             hipStreamSynchronize(p->lane_stream[l]);

@@ -159,43 +159,37 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_col(const float2* _
 // Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair).
 //   resp  : [C][N1][N2] = H[c][k1 + N1 k2] / N
 //   g / gr, wn / wnr: stages of the N2-point transform and their reversal;  tlo / thi : W_N^m
-// The four-step twiddles W_N^{k1 i} of a butterfly's elements i = j + r m are a s^r with
-// a = W_N^{k1 j} (one look-up per butterfly) and s = W_N^{k1 m}, the same for the whole
-// workgroup: folded into the source and, conjugated, into the sink.
+// The four-step twiddles W_N^{k1 i} of a butterfly's elements i = j + r m are a s_r with
+// a = W_N^{k1 j} (one look-up per butterfly) and s_r = W_N^{k1 m r}, the same for the whole
+// workgroup: a row of a small table made in double at plan creation (srow[r], r < R: scalar
+// loads; forming them as powers of s_1 cost R - 2 complex products per butterfly and three
+// more roundings).  Folded into the source and, conjugated, into the sink.
 struct GenRowSrc {
     const f4* row;
     const cf* tlo;
     const cf* thi;
+    const cf* srow;
     int k1;
-    long long n_total;
     template <int R>
     __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
         const cf a = big_twiddle(tlo, thi, k1 * j);
-        cf s[R];
-        s[1] = big_twiddle(tlo, thi, (int)(((long long)k1 * m) % n_total));
-#pragma unroll
-        for (int r = 2; r < R; ++r) s[r] = cmul(s[(r + 1) / 2], s[r / 2]);
         v[0] = twmul<-1>(f4_to_c2(row[j]), a);
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = twmul<-1>(f4_to_c2(row[j + r * m]), cmul(a, s[r]));
+        for (int r = 1; r < R; ++r) v[r] = twmul<-1>(f4_to_c2(row[j + r * m]), cmul(a, srow[r]));
     }
 };
 struct GenRowDst {
     f4* row;
     const cf* tlo;
     const cf* thi;
+    const cf* srow;
     int k1;
-    long long n_total;
     template <int R>
     __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
         const cf a = big_twiddle(tlo, thi, k1 * j);
-        cf s[R];
-        s[1] = big_twiddle(tlo, thi, (int)(((long long)k1 * m) % n_total));
-#pragma unroll
-        for (int r = 2; r < R; ++r) s[r] = cmul(s[(r + 1) / 2], s[r / 2]);
         row[j] = c2_to_f4(twmul<+1>(v[0], a));
 #pragma unroll
-        for (int r = 1; r < R; ++r) row[j + r * m] = c2_to_f4(twmul<+1>(v[r], cmul(a, s[r])));
+        for (int r = 1; r < R; ++r) row[j + r * m] = c2_to_f4(twmul<+1>(v[r], cmul(a, srow[r])));
     }
 };
 __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restrict__ work, int N1,
@@ -204,17 +198,19 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restr
                                                   GenGeo g, const cf* __restrict__ wn, GenGeo gr,
                                                   const cf* __restrict__ wnr,
                                                   const cf* __restrict__ tlo,
-                                                  const cf* __restrict__ thi) {
+                                                  const cf* __restrict__ thi,
+                                                  const cf* __restrict__ tws) {
     extern __shared__ f4 gen_lds[];
     const int N2 = g.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int k1 = blockIdx.x, sp = blockIdx.y % npair;
     f4* row = reinterpret_cast<f4*>(work) + ((long long)blockIdx.y * N1 + k1) * N2;
-    const long long n_total = (long long)N1 * N2;
-    GenRowSrc src{row, tlo, thi, k1, n_total};
+    // tws [N1][fac[0]]: the first forward and the last inverse stage have that radix (and m = N2 / fac[0])
+    const cf* srow = tws + (long long)k1 * g.fac[0];
+    GenRowSrc src{row, tlo, thi, srow, k1};
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     GenRespMul mul{resp + ((long long)c0 * N1 + k1) * N2, resp + ((long long)c1 * N1 + k1) * N2, c0 == c1};
-    GenRowDst dst{row, tlo, thi, k1, n_total};
+    GenRowDst dst{row, tlo, thi, srow, k1};
     gen_conv_open(gen_lds, g, gr, 1, wn, wnr, tid, nthr, src, mul, dst);
 }
 
