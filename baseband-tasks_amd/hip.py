@@ -468,8 +468,11 @@ class DeviceArray:
         if step != 1:
             raise ValueError("DeviceArray slices must be contiguous")
         stop = max(stop, start)
-        return DeviceArray((stop - start,) + self.shape[1:], self.dtype,
+        view = DeviceArray((stop - start,) + self.shape[1:], self.dtype,
                            self._ptr + start * self.row_bytes, self.owner)
+        if self.fresh:
+            view.fresh = True              # (part of a region nobody is owed is such a region)
+        return view
 
     def reshape(self, *shape):
         if len(shape) == 1 and not isinstance(shape[0], int):
@@ -484,6 +487,8 @@ class DeviceArray:
         out = DeviceArray(shape, self.dtype, self._ptr, self.owner)
         if out.size != self.size:
             raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
+        if self.fresh:
+            out.fresh = True
         return out
 
     @classmethod
@@ -737,6 +742,7 @@ class OsmPlan(_Plan):
         owner.owe(_Pending(done, (src_owner, self)), write=True)
         if shared:
             src_owner.owe(_Pending(done, (self,)), write=False)
+        out_dev.fresh = False           # (from now on the region IS owed a call)
 
     @staticmethod
     def _descriptors(in_off, out_off, valid_start, valid_count):
