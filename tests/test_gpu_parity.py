@@ -1191,6 +1191,61 @@ def test_many_blocks_in_one_call_match_the_oracle_block_by_block():
     assert np.array_equal(ch2.read(nspec), z)
 
 
+def test_one_call_past_2_32_elements_repeats_with_the_period_of_its_input():
+    """Maximum sizes: ONE `read_device` of the metric pipeline whose input (35 GB) and
+    result (28 GB) each hold more than 2^32 float32 pairs -- 2600 blocks of 2^20, 3.4
+    times the bench's call, every index past 32 bits.  No oracle runs at this size; the
+    property used is periodicity: the input repeats every spf = 836100 samples, so
+    every block transforms the same 2^20 samples and the spectra repeat every
+    lcm(spf, 1024) / 1024 = 209025 spectra (256 blocks) BIT FOR BIT, whichever chunk,
+    lane and seam slot a block falls on; the first period is checked against the
+    oracle where it starts."""
+    n, spf, nblk = 2**20, 836100, 2600
+    period = spf * 256 // 1024                       # spectra
+    rng = np.random.default_rng(11)
+    one = rng.standard_normal((spf, 4), dtype=np.float32).view(np.complex64)
+    length = (nblk - 1) * spf + n
+    hip = bt.hip
+    try:
+        x = hip.DeviceArray((length, 2), np.complex64)
+    except hip.HipError as exc:
+        pytest.skip(f"no room for a {length * 16 / 1e9:.0f} GB stream: {exc}")
+    x[:spf].copy_from_host(one)
+    have = spf
+    while have < length:                             # doubling device-to-device copies
+        m = min(have, length - have)
+        x[have:have + m].copy_from_device(x[:m])
+        have += m
+    ds = bt.DeviceStream(x, T0, 16 * u.MHz, frequency=1000 * u.MHz, sideband=1)
+    dd = bt.Dedisperse(ds, 100.)
+    assert dd._ih_samples_per_frame == n and dd.samples_per_frame == spf
+    ch = bt.Channelize(dd, 1024, 512)
+    nspec = (dd.shape[0] // 1024 // 512) * 512
+    assert nspec * 1024 * 2 > 2**32 and nspec > 10 * period
+    try:
+        z = ch.read_device(nspec)
+    except hip.HipError as exc:
+        pytest.skip(f"no room for the {nspec * 16384 / 1e9:.0f} GB result: {exc}")
+    assert z.shape == (nspec, 1024, 2)
+    first = z[:period].to_host()
+    # the first period against the oracle: the spectra inside block 0, and across the seam 0 | 1
+    g = orc.disperse_geometry(16e6, 1000., 1, -100.)
+    h = orc.chirp(n, 16e6, 1000., 1, -100., g['reference_frequency'])
+    block = np.concatenate([one, one])[:n]
+    y = orc.disperse_block(block, h, g['pad_start'], spf)
+    yy = np.concatenate([y, y])
+    k1 = spf // 1024                                 # the spectrum that straddles blocks 0 | 1
+    assert_parity(first[:64], orc.channelize(yy[:64 * 1024], 1024), 'first spectra')
+    assert_parity(first[k1 - 8:k1 + 8], orc.channelize(yy[(k1 - 8) * 1024:(k1 + 8) * 1024], 1024), 'seam 0 | 1')
+    # every later period, whole, bit for bit
+    step = 8192
+    for j in range(1, nspec // period + 1):
+        lo, hi = j * period, min((j + 1) * period, nspec)
+        for a in range(lo, hi, step):
+            b = min(a + step, hi)
+            assert np.array_equal(z[a:b].to_host(), first[a - lo:b - lo]), (j, a)
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""
