@@ -1246,6 +1246,83 @@ def test_one_call_past_2_32_elements_repeats_with_the_period_of_its_input():
             assert np.array_equal(z[a:b].to_host(), first[a - lo:b - lo]), (j, a)
 
 
+def _periodic_on_device(one, length):
+    """(length,) + one.shape[1:] in HBM, the rows of `one` over and over (doubling device copies);
+    skips the test when the GPU has no room."""
+    hip = bt.hip
+    try:
+        x = hip.DeviceArray((length,) + one.shape[1:], one.dtype)
+    except hip.HipError as exc:
+        pytest.skip(f"no room for a {length * one[0].nbytes / 1e9:.0f} GB stream: {exc}")
+    have = len(one)
+    x[:have].copy_from_host(one)
+    while have < length:
+        m = min(have, length - have)
+        x[have:have + m].copy_from_device(x[:m])
+        have += m
+    return x
+
+
+def _same_as_first_period(z, first, what):
+    period, step = len(first), max(1, (1 << 27) // first[0].nbytes)
+    for lo in range(period, z.shape[0], period):
+        hi = min(lo + period, z.shape[0])
+        for a in range(lo, hi, step):
+            b = min(a + step, hi)
+            assert np.array_equal(z[a:b].to_host(), first[a - lo:b - lo]), (what, a)
+
+
+def test_neighbouring_kernels_past_2_32_elements():
+    """The same maximum-size check for the one-kernel tasks: filter bank, channelizer
+    and sample shifts on streams of more than 2^32 float32 pairs in ONE read each (34-39
+    GB in, as much out).  Periodic input: the first period against the oracle (the
+    shifts: all of it, exactly), every later one bit-identical to the first."""
+    rng = np.random.default_rng(12)
+    # ---- PolyphaseFilterBank 12 x 1024, 2 pol: period 4 x 1013 spectra (whole frames, whole workgroups)
+    resp = bt.sinc_hamming(12, 1024)
+    period = 4 * 1013
+    one = rng.standard_normal((period * 1024, 4), dtype=np.float32).view(np.complex64)
+    nper = 2**32 // (period * 1024 * 2) + 2
+    x = _periodic_on_device(one, nper * period * 1024)
+    ds = bt.DeviceStream(x, T0, 16 * u.MHz, frequency=1000 * u.MHz, sideband=1)
+    pfb = bt.PolyphaseFilterBank(ds, resp)
+    nspec = pfb.shape[0] - pfb.shape[0] % period
+    assert nspec * 1024 * 2 > 2**32
+    try:
+        z = pfb.read_device(nspec)
+    except bt.hip.HipError as exc:
+        pytest.skip(f"no room for the result: {exc}")
+    first = z[:period].to_host()
+    want = orc.channelize(orc.ppf_samples(one[:(64 + 11) * 1024], orc.sinc_hamming(12, 1024)), 1024)
+    assert_parity(first[:64], want, 'filter bank, first spectra')
+    _same_as_first_period(z, first, 'filter bank')
+    del z, first, pfb
+    # ---- Channelize(1024) on the same stream
+    ch = bt.Channelize(ds, 1024, 1024)
+    nspec = ch.shape[0] - ch.shape[0] % period
+    z = ch.read_device(nspec)
+    first = z[:period].to_host()
+    assert_parity(first[:256], orc.channelize(one[:256 * 1024], 1024), 'channelizer, first spectra')
+    _same_as_first_period(z, first, 'channelizer')
+    del z, first, ch, ds, x
+    bt.hip.pool_trim()
+    # ---- ShiftSamples, (n, 8) streams each with its own shift: a pure gather, checked exactly
+    period = 1 << 16
+    one = rng.standard_normal((period, 16), dtype=np.float32).view(np.complex64)
+    shift = np.array([0, 3, 17, 2, 40, 41, 9, 1])
+    n = (2**32 // 8 // period + 2) * period
+    x = _periodic_on_device(one, n)
+    ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=period)
+    sh = bt.ShiftSamples(ds, shift, samples_per_frame=period)
+    count = (sh.shape[0] // period) * period
+    assert count * 8 > 2**32
+    z = sh.read_device(count)
+    off = shift.max() - shift
+    want = one[(np.arange(period)[:, None] + off[None]) % period, np.arange(8)[None]]
+    assert np.array_equal(z[:period].to_host(), want)
+    _same_as_first_period(z, want, 'sample shifts')
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""
