@@ -1405,6 +1405,11 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
 
 int bbt_osm_plan_destroy(bbt_osm_plan* p) {
     if (!p) return 0;
+    // (a deferred call may still be running on the plan's own streams -- its caller has only
+    // QUEUED the wait for it: nothing the kernels read goes before they are done)
+    for (int l = 0; l < BBT_MAX_LANES; ++l)
+        if (p->lane_stream[l]) hipStreamSynchronize(p->lane_stream[l]);
+    if (p->tail_stream) hipStreamSynchronize(p->tail_stream);
     for (auto e : p->ev) hipEventDestroy(e);
     for (auto e : p->ev_free) hipEventDestroy(e);
     if (p->resp) hipFree(p->resp);

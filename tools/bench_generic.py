@@ -1,6 +1,9 @@
 """Throughput of the generic (non power-of-two) overlap-save path next to the
 power-of-two one (dev tool): Dedisperse at 800 / 1000 / 1400 MHz, default block
-(the reference's rule) and `power_of_two=True`."""
+(the reference's rule) and `power_of_two=True`.
+
+    python tools/bench_generic.py [ded:<MHz> ...] [chan:<n> ...]      (no arguments: all rows;
+    with arguments only those, `ded:` without the power-of-two column: for profiling one kernel)"""
 import gc
 import os
 import sys
@@ -39,17 +42,22 @@ def rate(task, reps=5):
     return n * reps / (time.perf_counter() - t0) / 1e6
 
 
-for fc in (800e6, 1000e6, 1400e6, 600e6):
+only = sys.argv[1:]
+centres = [float(a[4:]) * 1e6 for a in only if a.startswith('ded:')] if only else (800e6, 1000e6, 1400e6, 600e6)
+lengths = [int(a[5:]) for a in only if a.startswith('chan:')] if only else (1000, 1536, 3000, 6561, 8192)
+for fc in centres:
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
     dd = bt.Dedisperse(ds, 100.)
     info = dd._get_plan().info()
     line = f"{fc / 1e6:6.0f} MHz default block {dd._ih_samples_per_frame:8d} = {info['n1']} x {info['n2']}: {rate(dd):9.1f} Msamples/s"
-    with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
-        d2 = bt.Dedisperse(ds, 100.)
-    line += f"   | power of two {d2._ih_samples_per_frame:8d}: {rate(d2):9.1f} Msamples/s"
+    d2 = None
+    if not only:
+        with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
+            d2 = bt.Dedisperse(ds, 100.)
+        line += f"   | power of two {d2._ih_samples_per_frame:8d}: {rate(d2):9.1f} Msamples/s"
     print(line, flush=True)
     del dd, d2
-for n in (1000, 1536, 3000, 6561, 8192):
+for n in lengths:
     ds = bt.DeviceStream(x[:16 * 2**20], '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=1000e6, sideband=1)
     ch = bt.Channelize(ds, n, 64)
     print(f"Channelize({n}): {rate(ch) * n:9.1f} Msamples/s", flush=True)
