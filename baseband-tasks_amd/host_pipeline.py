@@ -357,7 +357,12 @@ class HostUploader:
             pending, self._pending = self._pending, None
             got = pending[2].result()                     # (also: the host stream is free again)
             if pending[:2] == key:
-                up = got                                  # (else: a read-ahead nobody came for)
+                up = got
+            else:
+                # a read-ahead nobody came for: its block goes back to the pool, whose reuse is
+                # ordered by the current stream -- which must therefore come after the upload
+                current_stream_wait(got.event)
+                del got
         if up is None:
             up = self._submit(*key).result()
         announced, self._announced = self._announced, None
@@ -370,7 +375,7 @@ class HostUploader:
         pending, self._pending = self._pending, None
         if pending is not None:
             try:
-                pending[2].result()
+                current_stream_wait(pending[2].result().event)     # (see fetch: the block is freed next)
             except Exception:
                 pass
         self._announced = None
