@@ -31,7 +31,7 @@ def _prod(shape):
 
 def _check_n(n, minimum=2):
     """Channel counts the kernels take: for a plain channelizer any
-    2^a 3^b 5^c 7^d up to 8192; with ``minimum`` (the polyphase filter bank's
+    2^a 3^b 5^c 7^d up to 8192, and 16384; with ``minimum`` (the polyphase filter bank's
     fused FIR + FFT kernels) powers of two in [minimum, 4096]."""
     if minimum > 2:
         if n < minimum or n > 4096 or n & (n - 1):
@@ -156,7 +156,7 @@ class Channelize(_RowFFTTask):
     ----------
     ih : stream (complex64)
     n : int
-        Channels: any product of 2, 3, 5, 7 up to 8192 (powers of two up to
+        Channels: any product of 2, 3, 5, 7 up to 8192, and 16384 (powers of two up to
         4096 run on the tuned kernels and, from 256, fuse into an upstream
         overlap-save task).
     samples_per_frame : int

@@ -18,6 +18,7 @@
 #include "../../include/bbt_hip.h"
 #include "bbt_kernels.hpp"
 #include "gen_kernels.hpp"
+#include "fft_big.hpp"
 
 using namespace bbt;
 
@@ -95,6 +96,33 @@ static int get_tables(int n, FftTables* out) {
     if (upload(&ft.tw1, h1)) return 1;
     g_tables[{dev, n}] = ft;
     *out = ft;
+    return 0;
+}
+
+// twiddles of the 8192- / 16384-point transforms (fft_big.hpp: BigGeo<N>::TW_*), cached per device
+static std::map<std::pair<int, int>, cf*> g_big_tables;
+static int get_big_table(int n, cf** out) {
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto it = g_big_tables.find({dev, n});
+    if (it != g_big_tables.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const int t = n / 16, m = t / 16, l = m / 16;
+    std::vector<cf> h;
+    h.reserve(4 * (size_t)(t + m + l));
+    for (int c = 1; c <= 8; c *= 2)
+        for (int i = 0; i < t; ++i) h.push_back(unit_root((long long)i * c, n));
+    for (int c = 1; c <= 8; c *= 2)
+        for (int i = 0; i < m; ++i) h.push_back(unit_root((long long)i * c, t));
+    for (int c = 1; c <= 8; c *= 2)
+        for (int i = 0; i < l; ++i) h.push_back(unit_root((long long)i * c, m));
+    cf* d;
+    if (upload(&d, h)) return 1;
+    g_big_tables[{dev, n}] = d;
+    *out = d;
     return 0;
 }
 
@@ -1781,7 +1809,9 @@ struct bbt_chan_plan {
     bool split_real = false;    // direction -2: one stream z = a + i b, output = half spectra of a and b
     FftTables tab;
     cf* wroot = nullptr;
-    // channel counts that are not powers of two, or 8192 (gen_kernels.hpp)
+    // 8192 / 16384 channels of stream pairs (fft_big.hpp)
+    cf* big = nullptr;
+    // channel counts that are not powers of two (gen_kernels.hpp)
     bool generic = false;
     GenGeo g = {};
     cf* wn = nullptr;
@@ -1859,9 +1889,11 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     ARG_TRY(plan, "bbt_chan_plan_create: null argument");
     *plan = nullptr;
     const bool fast = is_pow2(n_chan) && n_chan >= 2 && n_chan <= 4096;
-    ARG_TRY(fast || (n_chan >= 2 && n_chan <= BBT_GEN_MAX_LEN && is_7smooth(n_chan)),
-            "bbt_chan_plan_create: n_chan=%d must be a power of two in [2, 4096] or a product of "
-            "2, 3, 5, 7 up to 8192", n_chan);
+    // (8192 and 16384 channels: one workgroup of 512 / 1024 threads per transform, stream pairs, plain directions)
+    const bool big = (n_chan == 8192 || n_chan == 16384) && n_stream % 2 == 0 && (direction == -1 || direction == 1);
+    ARG_TRY(fast || big || (n_chan >= 2 && n_chan <= BBT_GEN_MAX_LEN && is_7smooth(n_chan)),
+            "bbt_chan_plan_create: n_chan=%d must be a power of two in [2, 16384] (above 4096: stream "
+            "pairs, directions -1 / +1) or a product of 2, 3, 5, 7 up to 8192", n_chan);
     const bool single = n_stream == 1 && fast && n_chan >= 256;
     ARG_TRY(single || (n_stream >= 2 && n_stream % 2 == 0 && n_stream <= 65535 * 2),
             "bbt_chan_plan_create: n_stream=%d must be even and >= 2 (or 1 for a power-of-two n_chan "
@@ -1880,7 +1912,12 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
     p->npair = n_stream / 2;
     p->dir = direction;
     p->split_real = split_real;
-    if (!fast) {
+    if (big) {
+        if (get_big_table(n_chan, &p->big)) {
+            delete p;
+            return 1;
+        }
+    } else if (!fast) {
         p->generic = true;
         if (!factor_7smooth(n_chan, &p->g) || get_gen_table(&p->g, &p->wn)) {
             if (g_err.empty()) fail("bbt_chan_plan_create: cannot factor n_chan=%d", n_chan);
@@ -1915,6 +1952,30 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
     const int64_t slab = (int64_t)1 << 20;
     const float2* in = (const float2*)in_dev;
     float2* out = (float2*)out_dev;
+    if (p->big) {
+        const float scale = p->dir < 0 ? 1.0f : 1.0f / (float)p->n;
+        const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 30) / p->npair);      // (grid.x < 2^31)
+        for (int64_t s0 = 0; s0 < n_spectra; s0 += per) {
+            const int64_t ns = std::min(per, n_spectra - s0);
+            const int64_t off = s0 * p->n * p->S;
+            const dim3 grid((unsigned)(ns * p->npair));
+#define BBT_BIG_ROWS(N_, SIGN_)                                                                        \
+    do {                                                                                               \
+        constexpr size_t lds = BigGeo<N_>::LDS_ELEMS * sizeof(v2);                                     \
+        if (ensure_dyn_lds((const void*)k_fft_rows_big<N_, SIGN_>, lds)) return 1;                     \
+        hipLaunchKernelGGL((k_fft_rows_big<N_, SIGN_>), grid, dim3(N_ / 16), lds, (hipStream_t)stream, \
+                           in + off, out + off, (long long)ns, p->S, scale, p->big);                   \
+    } while (0)
+            if (p->n == 8192) {
+                if (p->dir < 0) BBT_BIG_ROWS(8192, -1); else BBT_BIG_ROWS(8192, +1);
+            } else {
+                if (p->dir < 0) BBT_BIG_ROWS(16384, -1); else BBT_BIG_ROWS(16384, +1);
+            }
+#undef BBT_BIG_ROWS
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {
         const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
         const int64_t off = s0 * p->n * p->S;

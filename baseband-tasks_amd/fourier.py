@@ -34,9 +34,12 @@ def is_fast_len(n):
 
 
 def check_transform_length(n, what='transform length'):
+    """One-workgroup transforms: n = 2^a 3^b 5^c 7^d up to 8192, and 16384 (csrc/fft_big.hpp)."""
+    if n == 2 * MAX_WG_FFT_LEN:
+        return
     if n < 2 or n > MAX_WG_FFT_LEN or not is_fast_len(n):
         raise ValueError(f"the hip engine handles {what} n = 2^a 3^b 5^c 7^d with 2 <= n <= "
-                         f"{MAX_WG_FFT_LEN}; got {n}.")
+                         f"{MAX_WG_FFT_LEN}, and {2 * MAX_WG_FFT_LEN}; got {n}.")
 
 
 class FFTMakerBase:

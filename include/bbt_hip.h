@@ -266,8 +266,9 @@ int bbt_osm_timing_read_passes(bbt_osm_plan* plan, double ms[3], int64_t launche
  * n_chan consecutive complete samples; in (n_spectra*n_chan, S) ->
  * out (n_spectra, n_chan, S).  direction -1: forward, unnormalised
  * (Channelize); +1: inverse, scaled by 1/n_chan (Dechannelize,
- * channelize.py:164-165).  n_chan a power of two, 2..4096 (fast path), or
- * any 2^a 3^b 5^c 7^d <= 8192.  n_stream even, or 1 for a power-of-two n_chan
+ * channelize.py:164-165).  n_chan a power of two, 2..4096 (fast path), 8192 or
+ * 16384 (one workgroup of 512 / 1024 threads per transform: stream pairs, directions
+ * -1 / +1), or any 2^a 3^b 5^c 7^d <= 8192.  n_stream even, or 1 for a power-of-two n_chan
  * in [256, 4096] (one stream: two consecutive groups are transformed side by
  * side, nothing is padded).  direction -2: every stream is z = a + i b of two
  * real streams and out receives their half spectra, (n_spectra, n_chan/2 + 1,

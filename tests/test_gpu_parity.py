@@ -419,8 +419,11 @@ def test_config5_at_the_references_default_block():
     assert_parity(got, want, 'resample, default block')
 
 
-@pytest.mark.parametrize('n', [3, 5, 6, 7, 12, 100, 360, 1000, 1029, 3000, 6561, 8192])
+@pytest.mark.parametrize('n', [3, 5, 6, 7, 12, 100, 360, 1000, 1029, 3000, 6561, 8192, 16384])
 def test_channel_counts_that_are_not_powers_of_two(n):
+    """Channelize / Dechannelize for any n = 2^a 3^b 5^c 7^d <= 8192 (reference: any n
+    numpy.fft takes, channelize.py:73-74) and for 16384; 8192 and 16384 run on the
+    four-stage one-workgroup transforms of csrc/fft_big.hpp."""
     for shape in ((2,), (3,), (8, 2)):
         nh = noise(5 * n + 3, shape, 1000, seed=23, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
         x = orc.noise_stream(23, 0, 5 * n + 3, 1000, shape)
@@ -2007,6 +2010,8 @@ def test_random_fused_channelizer_geometries():
     (2**21, 512, False),       # 512 x 4096 (512-point column pass)
     (2**22, 2048, False),      # 1024 x 4096 (1024-point column pass)
     (2**23, 512, False),       # three levels, 256 x 16 x 2048
+    (2**23, 64, False),        # ... few channels
+    (2**24, 1024, False),      # 256 x 16 x 4096
 ])
 def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
     """When n_chan exceeds the block's padding, the last n_chan-aligned group of a

@@ -2,7 +2,7 @@
 power-of-two one (dev tool): Dedisperse at 800 / 1000 / 1400 MHz, default block
 (the reference's rule) and `power_of_two=True`.
 
-    python tools/bench_generic.py [ded:<MHz> ...] [chan:<n> ...]      (no arguments: all rows;
+    python tools/bench_generic.py [ded:<MHz> ...] [pow2:<MHz> ...] [chan:<n> ...]      (no arguments: all rows;
     with arguments only those, `ded:` without the power-of-two column: for profiling one kernel)"""
 import gc
 import os
@@ -44,7 +44,17 @@ def rate(task, reps=5):
 
 only = sys.argv[1:]
 centres = [float(a[4:]) * 1e6 for a in only if a.startswith('ded:')] if only else (800e6, 1000e6, 1400e6, 600e6)
-lengths = [int(a[5:]) for a in only if a.startswith('chan:')] if only else (1000, 1536, 3000, 6561, 8192)
+lengths = [int(a[5:]) for a in only if a.startswith('chan:')] if only else (1000, 1536, 3000, 6561, 8192, 16384)
+for fc in [float(a[5:]) * 1e6 for a in only if a.startswith('pow2:')]:          # power-of-two blocks only
+    ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
+    with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
+        d2 = bt.Dedisperse(ds, 100.)
+    info = d2._get_plan().info()
+    print(f"{fc / 1e6:6.0f} MHz power-of-two block {d2._ih_samples_per_frame:8d} = {info['n1']} x {info['n2']}: "
+          f"{rate(d2):9.1f} Msamples/s", flush=True)
+    ch = bt.Channelize(d2, 1024, 512)
+    print(f"{'':10s}... -> Channelize(1024) (fused: {ch._fusable_input() is not None}): {rate(ch) * 1024:9.1f} Msamples/s", flush=True)
+    del d2, ch
 for fc in centres:
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
     dd = bt.Dedisperse(ds, 100.)
