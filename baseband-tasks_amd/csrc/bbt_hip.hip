@@ -642,6 +642,7 @@ struct bbt_osm_plan {
     int n1 = 1, n2 = 0;
     int outer = 1;  // 256 for three-level transforms (N > 2^20): N = outer * n1 * n2
     int chunk = 1;
+    int cap = 1;                // blocks a lane's work buffer holds (>= chunk): regular runs go in launches of up to that many
     cf* resp = nullptr;        // [C][N1][N2], scaled 1/N
     int* resp_index = nullptr;  // [S]
     float2* work = nullptr;     // [chunk][npair][N1][N2] float4 (lane 0)
@@ -1146,15 +1147,57 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
     }
     // (lanes keep alternating across deferred calls; a joined call starts on lane 0 as ever)
     const int l0 = call.deferred ? p->lane_cursor : 0;
+    // regular runs (plain output only: the fused channelizer's blocks each carry a shift and a seam slot)
+    const bool regular_ok = so.n_chan == 0 && !so.det && p->cap > p->chunk;
+    auto follows = [](const OsmBlock& a, const OsmBlock& b, long long d) {
+        return b.in_off - a.in_off == d && b.out_off - a.out_off == d && b.valid_start == a.valid_start &&
+               b.valid_count == a.valid_count && !a.shift && !b.shift && !a.flat && !b.flat;
+    };
     int64_t c = 0;
-    for (int64_t b0 = 0; b0 < n_blocks; b0 += p->chunk, ++c) {
-        OsmChunk ch = {};                  // (fields a caller's fill does not set stay 0)
-        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
-        for (int i = 0; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
+    auto launch = [&](const OsmChunk& ch) {
         const int l = fork ? (int)((l0 + c) % p->lanes) : 0;
         const bool sample = !fork || (c / p->lanes) % p->timing_stride == 0;
-        if (osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : call.run, sample))
-            return 1;
+        ++c;
+        return osm_run_chunk(p, in, out, ch, so, p->lane_work[l], fork ? p->lane_stream[l] : call.run, sample);
+    };
+    for (int64_t b0 = 0; b0 < n_blocks;) {
+        OsmChunk ch = {};                  // (fields a caller's fill does not set stay 0)
+        fill(ch.b[0], b0);
+        int64_t run = 1;                   // blocks from b0 on that step regularly
+        long long hop = 0;
+        if (regular_ok && b0 + p->chunk < n_blocks) {
+            OsmBlock nx = {};
+            fill(nx, b0 + 1);
+            hop = nx.in_off - ch.b[0].in_off;
+            if (hop > 0 && follows(ch.b[0], nx, hop))
+                for (run = 2; b0 + run < n_blocks; ++run) {
+                    fill(nx, b0 + run);
+                    if (!follows(ch.b[0], nx, hop * run)) break;
+                }
+        }
+        if (run > p->chunk) {
+            // launches of equal size, as few as the work buffer allows -- one per lane at least when
+            // each still gets more than a chunk of descriptors would hold
+            int64_t parts = (run + p->cap - 1) / p->cap;
+            if (fork && parts < p->lanes && run >= (int64_t)p->lanes * 2 * p->chunk) parts = p->lanes;
+            const int64_t per = (run + parts - 1) / parts;
+            const OsmBlock first = ch.b[0];
+            for (int64_t r0 = 0; r0 < run; r0 += per) {
+                OsmChunk rc = {};
+                rc.b[0] = first;
+                rc.b[0].in_off += r0 * hop;
+                rc.b[0].out_off += r0 * hop;
+                rc.reg_count = rc.nblk = (int)std::min(per, run - r0);
+                rc.reg_hop = hop;
+                if (launch(rc)) return 1;
+            }
+            b0 += run;
+            continue;
+        }
+        ch.nblk = (int)((n_blocks - b0 < p->chunk) ? (n_blocks - b0) : p->chunk);
+        for (int i = 1; i < ch.nblk; ++i) fill(ch.b[i], b0 + i);
+        if (launch(ch)) return 1;
+        b0 += ch.nblk;
     }
     if (fork) {
         if (call.deferred) p->lane_cursor = (int)((l0 + c) % p->lanes);
@@ -1378,20 +1421,31 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     }
     while (chunk > 1 && (long long)chunk * p->npair > 65535) --chunk;      // grid.y of the row pass
     if ((double)chunk * per_block * lanes > 16.0 * (1u << 30)) lanes = 1;   // (config 4: 2 x 2 GiB)
+    // Short blocks: sixteen descriptors are a small launch (16 x 8192 samples: 32 workgroups per
+    // pass), so runs of REGULAR blocks -- equal steps of input and output, the same kept range:
+    // every block of a padded task but a re-aligned last one -- go as one descriptor and a hop
+    // (OsmChunk::reg_count), as many blocks as the work buffer (the same 192 MiB) holds.
+    int cap = (int)std::min<size_t>((192u << 20) / per_block / lanes, 4096);
+    while (cap > 1 && (long long)cap * p->npair * p->outer > 65535) --cap;
+    if (cap < chunk || getenv("BBT_OSM_CHUNK")) cap = chunk;
     if (single) {
         // `chunk` pairs of blocks fit the work buffer: a chunk of descriptors holds twice as many blocks
         const int pairs = chunk > BBT_MAX_CHUNK / 2 ? BBT_MAX_CHUNK / 2 : chunk;
-        p->work_bytes = per_block * pairs;
+        cap = std::max(cap, pairs);
+        p->work_bytes = per_block * cap;
         chunk = 2 * pairs;
+        cap = 2 * cap;
     } else {
-        p->work_bytes = per_block * chunk;
+        p->work_bytes = per_block * cap;
     }
     if (p->n1 == 1 && !getenv("BBT_OSM_CHUNK")) {
         // one kernel, no work buffer: nothing bounds a launch but the descriptor array
         chunk = BBT_MAX_CHUNK;
         while (chunk > 1 && (long long)chunk * p->npair >= (1ll << 31)) --chunk;
     }
+    if (p->n1 == 1) cap = (int)std::min<long long>(1 << 20, ((1ll << 31) - 1) / p->npair);   // nothing to hold
     p->chunk = chunk;
+    p->cap = cap;
     p->lanes = lanes;
     if (p->n1 == 1) p->work_bytes = 0;        // one kernel, no work buffer
     if (p->n1 > 1) {

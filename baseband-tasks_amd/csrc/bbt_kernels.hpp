@@ -522,9 +522,9 @@ __device__ __forceinline__ void emit_spectrum_single(float2 val, const SpecCurso
 
 struct OsmChunk {
     int nblk;
-    // Regular runs (k_osm_small only): reg_count > 0 blocks that all look like b[0] with input
-    // and output offsets advancing by reg_hop samples per block -- one launch takes any number
-    // of them (the descriptor array holds 16); nblk is then not used.
+    // Regular runs: reg_count > 0 blocks that all look like b[0] with input and output offsets
+    // advancing by reg_hop samples per block -- one launch takes any number of them (the
+    // descriptor array holds 16); kernels read descriptors through osm_block().
     int reg_count;
     long long reg_hop;
     // Pair-planar hand-over between two plans (bbt_osm_plan_set_layout): a stream of S = 2 P
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
         }
         return;
     }
-    const OsmBlock blk = ch.b[b];
+    const OsmBlock blk = osm_block(ch, b);
     if (FIRST) {
         // blk.shift (fused channelizer): the block is read circularly shifted, element
         // e from sample (e + shift) mod N -- a circular convolution commutes with it.
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(FCOL * (N1 / 16)) void k_osm_col256(const float2* _
         }
         return;
     }
-    const OsmBlock blk = ch.b[b];
+    const OsmBlock blk = osm_block(ch, b);
     if (FIRST) {
         // read circularly shifted by blk.shift (see k_osm_col16): the last row can wrap
         // (pair-planar input: this pair's samples are an array of their own, see OsmChunk)

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_osm_small(const flo
     const int npair = S >> 1, n = g.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int sp = blockIdx.x % npair;
-    const OsmBlock blk = ch.b[blockIdx.x / npair];
+    const OsmBlock blk = osm_block(ch, blockIdx.x / npair);
     GenStreamSrc src{in + (blk.in_off * S + 2 * sp), S, true};
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     GenRespMul mul{resp + (long long)c0 * n, resp + (long long)c1 * n, c0 == c1};
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_col(const float2* _
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int sp = blockIdx.x % npair, n2_0 = (blockIdx.x / npair) * ct;
     const int b = blockIdx.y;
-    const OsmBlock blk = ch.b[b];
+    const OsmBlock blk = osm_block(ch, b);
     const int n2 = n2_0 + (tid & (ct - 1));        // (ct is a power of two that divides nthr)
     const bool live = n2 < N2;
     f4* w = reinterpret_cast<f4*>(work) + ((long long)(b * npair + sp) * N1) * N2 + n2;

@@ -45,6 +45,14 @@ def rate(task, reps=5):
 only = sys.argv[1:]
 centres = [float(a[4:]) * 1e6 for a in only if a.startswith('ded:')] if only else (800e6, 1000e6, 1400e6, 600e6)
 lengths = [int(a[5:]) for a in only if a.startswith('chan:')] if only else (1000, 1536, 3000, 6561, 8192, 16384)
+for n_fft in [int(a[4:]) for a in only if a.startswith('blk:')]:               # short power-of-two blocks
+    ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=1400e6, sideband=1)
+    probe = bt.Dedisperse(ds, 1.)
+    pad = probe._pad_start + probe._pad_end
+    dd = bt.Dedisperse(ds, 1., samples_per_frame=n_fft - pad)
+    info = dd._get_plan().info()
+    print(f"block {dd._ih_samples_per_frame:6d} = {info['n1']} x {info['n2']} (padding {pad}): {rate(dd):9.1f} Msamples/s", flush=True)
+    del dd, probe
 for fc in [float(a[5:]) * 1e6 for a in only if a.startswith('pow2:')]:          # power-of-two blocks only
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
     with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
