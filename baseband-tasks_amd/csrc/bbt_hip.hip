@@ -18,7 +18,7 @@
 #include "../../include/bbt_hip.h"
 #include "bbt_kernels.hpp"
 #include "gen_kernels.hpp"
-#include "fft_big.hpp"
+#include "big_kernels.hpp"
 
 using namespace bbt;
 
@@ -686,6 +686,7 @@ struct bbt_osm_plan {
     cf* twa = nullptr;
     cf* twg = nullptr;
     cf* wroot = nullptr;
+    cf* big_tw = nullptr;       // one-kernel plans of 8192 / 16384 samples (big_kernels.hpp): the transform's table (shared)
     // block lengths that are not powers of two (gen_kernels.hpp): N = n1 * n2,
     // n1 == 1 for N <= 8192
     bool generic = false;
@@ -778,6 +779,22 @@ static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const Os
         hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(nblk * p->npair), dim3(N / 16), lds1, st, in, out,
                            ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
     }
+    return 0;
+}
+
+template <int N>
+static int launch_small_big(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch, hipStream_t st) {
+    constexpr size_t lds = BigGeo<N>::LDS_ELEMS * sizeof(v2);
+    const int nblk = ch.reg_count ? ch.reg_count : ch.nblk;
+    if (p->single) {
+        if (ensure_dyn_lds((const void*)k_osm_small_big<N, true>, lds)) return 1;
+        hipLaunchKernelGGL((k_osm_small_big<N, true>), dim3((nblk + 1) / 2), dim3(N / 16), lds, st, in, out, ch,
+                           1, p->resp, p->resp_index, p->big_tw);
+        return 0;
+    }
+    if (ensure_dyn_lds((const void*)k_osm_small_big<N>, lds)) return 1;
+    hipLaunchKernelGGL((k_osm_small_big<N>), dim3(nblk * p->npair), dim3(N / 16), lds, st, in, out, ch, p->S,
+                       p->resp, p->resp_index, p->big_tw);
     return 0;
 }
 
@@ -1002,6 +1019,8 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
             case 1024: rc = launch_small<1024>(p, in, out, ch, st); break;
             case 2048: rc = launch_small<2048>(p, in, out, ch, st); break;
             case 4096: rc = launch_small<4096>(p, in, out, ch, st); break;
+            case 8192: rc = launch_small_big<8192>(p, in, out, ch, st); break;
+            case 16384: rc = launch_small_big<16384>(p, in, out, ch, st); break;
             default: return fail("osm: unsupported n_fft %lld", (long long)p->n);
         }
         if (rc) return rc;
@@ -1147,11 +1166,13 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
     }
     // (lanes keep alternating across deferred calls; a joined call starts on lane 0 as ever)
     const int l0 = call.deferred ? p->lane_cursor : 0;
-    // regular runs (plain output only: the fused channelizer's blocks each carry a shift and a seam slot)
-    const bool regular_ok = so.n_chan == 0 && !so.det && p->cap > p->chunk;
-    auto follows = [](const OsmBlock& a, const OsmBlock& b, long long d) {
+    // regular runs (the fused channelizer's per-block shift and seam slot follow from the hop: osm_block)
+    const bool regular_ok = p->cap > p->chunk;
+    const int mask = so.n_chan ? so.n_chan - 1 : 0;
+    auto follows = [mask](const OsmBlock& a, const OsmBlock& b, long long d) {
         return b.in_off - a.in_off == d && b.out_off - a.out_off == d && b.valid_start == a.valid_start &&
-               b.valid_count == a.valid_count && !a.shift && !b.shift && !a.flat && !b.flat;
+               b.valid_count == a.valid_count && !a.flat && !b.flat &&
+               b.shift == (int)(((long long)a.shift - d) & mask);      // (index: the fills count blocks up)
     };
     int64_t c = 0;
     auto launch = [&](const OsmChunk& ch) {
@@ -1187,8 +1208,11 @@ static int osm_run_all(bbt_osm_plan* p, const float2* in, float2* out, int64_t n
                 rc.b[0] = first;
                 rc.b[0].in_off += r0 * hop;
                 rc.b[0].out_off += r0 * hop;
+                rc.b[0].shift = (int)(((long long)first.shift - r0 * hop) & mask);
+                rc.b[0].index = first.index + (int)r0;
                 rc.reg_count = rc.nblk = (int)std::min(per, run - r0);
                 rc.reg_hop = hop;
+                rc.reg_mask = mask;
                 if (launch(rc)) return 1;
             }
             b0 += run;
@@ -1286,8 +1310,8 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             gn2 = (int)n_fft;
         }
         p->n1 = gn1;
-    } else if (n_fft <= 4096) {
-        p->n1 = 1;
+    } else if (n_fft <= 4096 || ((n_fft == 8192 || n_fft == 16384) && !getenv("BBT_OSM_NO_BIG"))) {
+        p->n1 = 1;               // (8192 / 16384 samples: one workgroup of 512 / 1024 threads, big_kernels.hpp)
     } else if (n_fft <= (1 << 16)) {
         p->n1 = 16;
     } else if (n_fft <= (1 << 20)) {
@@ -1330,7 +1354,11 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             while (p->gen_ct < ct_cap && 2 * p->gen_ct * p->n1 <= BBT_GEN_MAX_LEN) p->gen_ct *= 2;
         }
     } else {
-        if (get_tables(p->n2, &p->tab2)) return bail(1);
+        if (p->n2 > 4096) {
+            if (get_big_table(p->n2, &p->big_tw)) return bail(1);
+        } else if (get_tables(p->n2, &p->tab2)) {
+            return bail(1);
+        }
         if ((p->n1 == 256 || p->outer == 256) && get_tables(256, &p->tab1)) return bail(1);
         if ((p->n1 == 512 || p->n1 == 1024) && get_tables(p->n1, &p->tab1)) return bail(1);
         if (get_wroot(&p->wroot)) return bail(1);

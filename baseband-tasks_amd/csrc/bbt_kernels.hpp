@@ -526,6 +526,7 @@ struct OsmChunk {
     // advancing by reg_hop samples per block -- one launch takes any number of them (the
     // descriptor array holds 16); kernels read descriptors through osm_block().
     int reg_count;
+    int reg_mask;        // fused channelizer: n_chan - 1 (the blocks' circular shifts step with the output offsets), else 0
     long long reg_hop;
     // Pair-planar hand-over between two plans (bbt_osm_plan_set_layout): a stream of S = 2 P
     // streams stored as P arrays of two-stream samples, pair p at [p * plane, (p + 1) * plane)
@@ -541,6 +542,11 @@ __device__ __forceinline__ OsmBlock osm_block(const OsmChunk& ch, int i) {
     OsmBlock blk = ch.b[0];
     blk.in_off += i * ch.reg_hop;
     blk.out_off += i * ch.reg_hop;
+    if (ch.reg_mask) {
+        // shift = (valid_start - out_off) mod n_chan (osm_channelized); seam slots go by the block's index
+        blk.shift = (int)(((long long)blk.shift - i * ch.reg_hop) & ch.reg_mask);
+        blk.index += i;
+    }
     return blk;
 }
 

@@ -76,9 +76,28 @@ class DeviceTaskMixin:
     ``_compute_frames(first, last, out)``: fill DeviceArray ``out`` (flat
     ``(n_samples,) + sample_shape``) with output frames ``first..last-1``.
     """
-    #: upper bound on frames computed by one call (bounds device memory)
-    max_frames_per_call = 32
     _produces_on_device = True
+    _max_frames_per_call = None
+
+    @property
+    def max_frames_per_call(self):
+        """Upper bound on the frames computed by one call (bounds device memory): 32, or with
+        short frames as many as make 64 MiB of output -- a call is a handful of kernel launches
+        whatever it holds, and 32 frames of 8192 samples are 4 MiB.  Assignable."""
+        if self._max_frames_per_call is not None:
+            return self._max_frames_per_call
+        try:
+            row = np.dtype(self._device_dtype).itemsize
+            for d in self.sample_shape:
+                row *= d
+            frame = max(int(self.samples_per_frame) * row, 1)
+        except Exception:
+            return 32
+        return max(32, min((1 << 26) // frame, 1 << 16))
+
+    @max_frames_per_call.setter
+    def max_frames_per_call(self, value):
+        self._max_frames_per_call = None if value is None else int(value)
 
     @property
     def _device_dtype(self):

@@ -87,7 +87,7 @@ def test_config2_dedisperse_and_metric_pipeline(golden):
 def test_fused_channelizer_short_final_frame():
     """The last dedispersion frame keeps fewer samples than one spectrum: that
     call takes the unfused route, everything else stays fused."""
-    n_fft, pad = 2**14, 767 + 771
+    n_fft, pad = 2**15, 767 + 771                  # (16 x 2048: the shortest blocks with a row pass to fuse into)
     spf = n_fft - pad
     n_in = 3 * spf + pad + 100                      # dedispersed length 3 * spf + 100
     nh = noise(n_in, (2,), 5000, seed=31, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
@@ -2000,7 +2000,7 @@ def test_random_fused_channelizer_geometries():
 
 
 @pytest.mark.parametrize('n_fft,n_chan,detect', [
-    (2**14, 1024, False),      # 16 x 1024: one spectrum per row
+    (2**14, 1024, False),      # one kernel (16384-point transform), the channelizer after it
     (2**15, 2048, False),      # 16 x 2048: one spectrum per row
     (2**16, 4096, False),      # 16 x 4096
     (2**18, 128, False),       # few channels (lane exchange)
@@ -2031,7 +2031,7 @@ def test_channel_count_larger_than_the_padding(n_fft, n_chan, detect):
         cv = bt.Convolve(ds, resp, samples_per_frame=spf)
         assert cv._ih_samples_per_frame == n_fft
         plan = cv._get_plan()
-        assert plan.fusable(n_chan)
+        assert plan.fusable(n_chan) == (n_fft > 2**14)      # (8192 / 16384 samples: one kernel, nothing to fuse into)
         ch = bt.Channelize(cv, n_chan, samples_per_frame=3)
         y = np.stack([np.convolve(x[:, k].astype(np.complex128), resp.astype(np.complex128), mode='valid')
                       for k in range(2)], axis=1)
@@ -2264,7 +2264,7 @@ def test_host_threads_with_their_own_streams_and_plans():
     lib = hip.lib()
     rng = np.random.default_rng(4)
     jobs = []
-    for n_fft, n_chan, S in ((2**14, 512, 2), (2**17, 512, 4), (6174, 0, 2), (2**16, 2048, 2)):
+    for n_fft, n_chan, S in ((2**15, 512, 2), (2**17, 512, 4), (6174, 0, 2), (2**16, 2048, 2), (2**14, 0, 2)):
         resp = np.exp(2j * np.pi * rng.uniform(size=(1, n_fft))).astype(np.complex64)
         x = (rng.standard_normal((4 * n_fft, S)) + 1j * rng.standard_normal((4 * n_fft, S))).astype(np.complex64)
         vs, vc = n_fft // 8, n_fft - n_fft // 4
@@ -2703,7 +2703,7 @@ print("one runtime:", maps[0])
         assert done.returncode == 0 and 'one runtime:' in done.stdout, (order, done.stdout[-500:], done.stderr[-1500:])
 
 
-@pytest.mark.parametrize('n_fft,n_chan', [(2**14, 256), (2**15, 2048), (2**16, 4096), (2**18, 1024), (2**20, 512),
+@pytest.mark.parametrize('n_fft,n_chan', [(2**15, 256), (2**15, 2048), (2**16, 4096), (2**18, 1024), (2**20, 512),
                                           (2**21, 256)])
 def test_one_stream_through_the_fused_channelizer(n_fft, n_chan):
     """Channelize(Convolve(one complex stream)): fused, blocks paired, each block with

@@ -281,8 +281,9 @@ def test_channelize_pfb_resample_geometry(golden):
     assert bt.Channelize(nh, 8192).shape == (256, 8192, 2)
     with pytest.raises(ValueError):
         bt.Channelize(nh, 1001)                                        # 7 x 11 x 13
+    assert bt.Channelize(nh, 16384).shape == (128, 16384, 2)           # ... and 16384 (csrc/fft_big.hpp)
     with pytest.raises(ValueError):
-        bt.Channelize(nh, 16384)
+        bt.Channelize(nh, 32768)
     with pytest.raises(TypeError):
         bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f8'), 256)
     real = bt.Channelize(bt.EmptyStreamGenerator((4096,), T0, 1e3, dtype='f4'), 256)

@@ -52,7 +52,9 @@ for n_fft in [int(a[4:]) for a in only if a.startswith('blk:')]:               #
     dd = bt.Dedisperse(ds, 1., samples_per_frame=n_fft - pad)
     info = dd._get_plan().info()
     print(f"block {dd._ih_samples_per_frame:6d} = {info['n1']} x {info['n2']} (padding {pad}): {rate(dd):9.1f} Msamples/s", flush=True)
-    del dd, probe
+    ch = bt.Channelize(dd, 256, 512)
+    print(f"{'':10s}... -> Channelize(256) (fused: {ch._fusable_input() is not None}): {rate(ch) * 256:9.1f} Msamples/s", flush=True)
+    del dd, probe, ch
 for fc in [float(a[5:]) * 1e6 for a in only if a.startswith('pow2:')]:          # power-of-two blocks only
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
     with bt.fft_maker.set(HipFFTMaker(power_of_two=True)):
