@@ -27,7 +27,10 @@ def rate(task, reps=5):
     n = task.shape[0]
 
     def step():
-        task.invalidate_cache()
+        t = task
+        while t is not None and hasattr(t, 'invalidate_cache'):     # (an unfused chain: every task computes)
+            t.invalidate_cache()
+            t = getattr(t, 'ih', None)
         task.seek(0)
         return task.read_device(n)
     for _ in range(2):
