@@ -1326,6 +1326,48 @@ def test_neighbouring_kernels_past_2_32_elements():
     _same_as_first_period(z, want, 'sample shifts')
 
 
+@pytest.mark.parametrize('n_fft,n_chan', [(2**11, 0), (2**13, 0), (2**14, 0), (2**15, 0), (2**15, 256), (2**17, 64),
+                                          (6174, 0), (30000, 0)])
+def test_hundreds_of_short_blocks_in_one_call(n_fft, n_chan):
+    """Short blocks by the hundred in ONE call: runs of regular blocks go to the kernels as one
+    descriptor and a hop (`OsmChunk::reg_count`), launches hold as many blocks as the work
+    buffer does, the fused channelizer's shifts and seam slots follow from the hop, a re-aligned
+    last block ends the run.  Against the oracle, and bit for bit against the same stream read
+    in calls of at most sixteen blocks (the descriptor-per-block route)."""
+    fs, dm = 1e6, (5. if n_fft >= 4096 else 1.2)
+    nh0 = noise(4 * n_fft, (2,), n_fft, seed=3, fs=fs, frequency=300 * u.MHz, sideband=1)
+    pad = (lambda d: d._pad_start + d._pad_end)(bt.Dedisperse(nh0, dm))
+    assert pad < n_fft // 2
+    spf = n_fft - pad
+    nblk = 333
+    length = nblk * spf + pad + spf // 3                    # + a re-aligned last block
+    x = orc.noise_stream(3, 0, length, n_fft, (2,))
+    ds = bt.DeviceStream(x, T0, fs, frequency=300 * u.MHz, sideband=1)
+    want, info = orc.dedisperse(x, fs, 300., 1, dm, samples_per_frame=spf, ih_samples_per_frame=n_fft,
+                                fast_len=HipFFTMaker.next_fast_len)
+    assert info['ih_spf'] == n_fft
+
+    def task(per_call):
+        dd = bt.Dedisperse(ds, dm, samples_per_frame=spf)
+        assert dd._ih_samples_per_frame == n_fft
+        top = bt.Channelize(dd, n_chan, samples_per_frame=7) if n_chan else dd
+        if n_chan and n_fft >= 2**15:
+            assert top._fusable_input() is dd
+        dd.max_frames_per_call = per_call
+        top.max_frames_per_call = 10**6 if per_call > 16 else max(1, per_call * spf // (7 * max(n_chan, 1)))
+        return top
+    whole = task(10**6)
+    assert whole.ih._get_plan().info()['chunk_blocks'] <= 16 if n_chan else True
+    got = whole.read_device(whole.shape[0]).to_host()
+    ref = orc.channelize(want[:got.shape[0] * n_chan], n_chan) if n_chan else want
+    assert got.shape == ref.shape
+    assert_parity(got, ref, f'{nblk} blocks of {n_fft}, {n_chan} channels')
+    pieces = task(16)
+    assert np.array_equal(pieces.read(), got)
+    whole.seek(whole.shape[0] // 2 + 5)
+    assert np.array_equal(whole.read(1000), got[whole.shape[0] // 2 + 5:whole.shape[0] // 2 + 1005])
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""
