@@ -29,8 +29,9 @@ class _PaddedSource(PaddedTaskBase):
 
 
 class _FewChannelPfbPlan:
-    """The filter bank for n < 256 channels (GUPPI's 12 x 64, reference
-    tests/test_pfb.py:33-35), with the interface of `hip.PfbPlan`: seen as
+    """The filter bank for channel counts the fused FIR + FFT kernels do not take -- n < 256
+    (GUPPI's 12 x 64, reference tests/test_pfb.py:33-35), any 2^a 3^b 5^c 7^d that is not a power
+    of two, 8192 and 16384 -- with the interface of `hip.PfbPlan`: seen as
     ``(blocks, n * S)`` the stream is n * S streams of blocks, the polyphase sum
     is an ``n_tap``-tap filter along the block axis with its own taps per phase
     (`hip.FirPlan`, the direct filter kernel), and the channelizer transform
@@ -90,7 +91,8 @@ class PolyphaseFilterBank(_RowFFTTask):
     def __init__(self, ih, response, samples_per_frame=None, frequency=None, sideband=None):
         response = np.asanyarray(response)
         n_tap, n = response.shape
-        _check_n(n, minimum=256 if n >= 256 else 2)      # fewer channels: filter + short transforms
+        self._fused_kernel = 256 <= n <= 4096 and not n & (n - 1)
+        _check_n(n)                                      # (other counts: filter + transform, two kernels)
         if np.dtype(ih.dtype) not in (np.dtype(np.complex64), np.dtype(np.float32)):
             raise TypeError("the accelerated filter bank handles complex64 and float32 streams; "
                             f"got {ih.dtype} (wrap the stream in SinglePrecision(...)).")
@@ -134,7 +136,7 @@ class PolyphaseFilterBank(_RowFFTTask):
         return hip.PfbPlan(self._response, -p)
 
     def _make_plan(self, n_stream_even):
-        if self._n < 256:
+        if not self._fused_kernel:
             return _FewChannelPfbPlan(self._response, n_stream_even)
         return hip.PfbPlan(self._response, n_stream_even)
 

@@ -2130,6 +2130,32 @@ def test_random_windows_of_the_fused_channelizer():
                 _close(it.read(count), power[a:a + count], rtol=2e-5)
 
 
+@pytest.mark.parametrize('n_chan', [6, 96, 100, 1000, 1536, 6000, 8192, 16384])
+def test_filter_bank_with_any_channel_count(n_chan):
+    """PolyphaseFilterBank for channel counts the fused FIR + FFT kernels do not take (the
+    reference takes any n numpy.fft takes, pfb.py:128-154): the polyphase sum as a filter
+    along the block axis, then the channelizer transform -- complex and float32 streams,
+    odd stream counts, against the oracle."""
+    rng = np.random.default_rng(n_chan)
+    for shape, real, n_tap in (((2,), False, 4), ((3,), False, 12), ((2,), True, 8), ((), True, 5)):
+        if real and n_chan % 2:
+            continue
+        ih_spf = n_chan * (n_tap + 9)
+        n_in = ih_spf * 5
+        if real:
+            x = rng.standard_normal((n_in,) + shape).astype(np.float32)
+        else:
+            x = (rng.standard_normal((n_in,) + shape) + 1j * rng.standard_normal((n_in,) + shape)).astype(np.complex64)
+        resp = orc.sinc_hamming(n_tap, n_chan) * 1.7
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=ih_spf)
+        pfb = bt.PolyphaseFilterBank(ds, resp)
+        want, geo = orc.polyphase_filter_bank(x, resp, ih_spf)
+        assert pfb.samples_per_frame == geo['chan_spf']
+        got = pfb.read()
+        assert got.shape == want.shape
+        assert_parity(got, want.astype(np.complex64), f'n {n_chan} taps {n_tap} {shape} real={real}')
+
+
 def test_random_filter_bank_channelizer_and_resampler_geometries():
     """Randomised PolyphaseFilterBank (taps, channels, framing, real and complex
     streams, odd stream counts), Channelize (any 2^a 3^b 5^c 7^d channel count) and
