@@ -29,16 +29,9 @@ def _prod(shape):
     return n
 
 
-def _check_n(n, minimum=2):
-    """Channel counts the kernels take: for a plain channelizer any
-    2^a 3^b 5^c 7^d up to 8192, and 16384; with ``minimum`` (the polyphase filter bank's
-    fused FIR + FFT kernels) powers of two in [minimum, 4096]."""
-    if minimum > 2:
-        if n < minimum or n > 4096 or n & (n - 1):
-            raise ValueError(f"the accelerated filter bank supports power-of-two n in "
-                             f"[{minimum}, 4096]; got {n}.")
-    else:
-        check_transform_length(n, 'channel counts')
+def _check_n(n):
+    """Channel counts the kernels take: any 2^a 3^b 5^c 7^d up to 8192, and 16384."""
+    check_transform_length(n, 'channel counts')
 
 
 class _RowFFTTask(DeviceTaskMixin, TaskBase):
