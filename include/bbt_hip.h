@@ -117,8 +117,9 @@ int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
  * (convolution.py:116-120).
  *
  *   n_fft       block length N (= PaddedTaskBase._ih_samples_per_frame),
- *               a power of two, 256 <= N <= 2^24 (one kernel up to 4096,
- *               two-level four-step up to 2^20, three-level above): the fast
+ *               a power of two, 256 <= N <= 2^24 (one kernel up to 4096 and
+ *               for 8192 and 16384, two-level four-step up to 2^22, three-level
+ *               above): the fast
  *               path; or any N = 2^a 3^b 5^c 7^d -- the lengths the
  *               reference's NumPy engine picks (fourier/numpy.py:99-126,
  *               block rule base.py:750-758) -- that is <= 8192 or splits
@@ -154,8 +155,8 @@ int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* c
                       int* n1, int* n2);
 /* Deferred join for the NEXT bbt_osm_execute* call on `plan` (that one call only, whatever
  * becomes of it).  By default an execute call returns with `stream` ordered after all of its
- * work: anything queued on `stream` afterwards sees the results.  A plan with lanes (block
- * lengths above 4096) runs its kernels on internal streams, so that default costs a drain at
+ * work: anything queued on `stream` afterwards sees the results.  A plan with lanes (more than
+ * one kernel per block: bbt_osm_plan_info reports n1 > 1) runs its kernels on internal streams, so that default costs a drain at
  * every call boundary -- the lanes run empty, `stream` takes over, the next call's lanes start
  * again: 2-4 % of a 768-block call on MI355X.  A reader that takes consecutive frames
  * (base.py:427-436) does not need `stream` ordered after call i to issue call i + 1.  With a
@@ -164,8 +165,8 @@ int bbt_osm_plan_info(const bbt_osm_plan* plan, int64_t* workspace_bytes, int* c
  * channelizer): whoever consumes `out_dev` -- or frees or overwrites `in_dev` or `out_dev` --
  * must first wait for `done` (bbt_stream_wait_event, bbt_event_sync).  Consecutive deferred
  * calls on one plan flow into each other: lane order protects the work buffers, the seam
- * buffer has two turns.  A plan without lanes (one kernel per chunk: n_fft <= 4096, or <= 8192
- * on the generic path) runs a deferred call on an internal stream of its own, after what was
+ * buffer has two turns.  A plan without lanes (one kernel per chunk: n_fft <= 4096, 8192 and 16384,
+ * or <= 8192 on the generic path) runs a deferred call on an internal stream of its own, after what was
  * queued on `stream` before it and beside what is queued there next -- the upstream task's
  * kernels for the following run (InversePolyphaseFilterBank: Dechannelize of run k + 1 beside the
  * deconvolution of run k).  The isolated timing mode simply records `done` on `stream`.
@@ -189,7 +190,7 @@ int bbt_osm_execute(bbt_osm_plan* plan, const void* in_dev, void* out_dev, int64
                     const int32_t* valid_count, bbt_stream stream);
 /* bbt_osm_execute with the kept range given in ELEMENTS of the (row, stream)
  * matrix instead of whole rows, for plans of one kernel (power-of-two n_fft <=
- * 4096, S even): block b keeps valid_elems[b] elements starting at element
+ * 4096, 8192 or 16384; S even): block b keeps valid_elems[b] elements starting at element
  * first_elem (even, < S) of row valid_start[b], written contiguously to out_dev
  * from element out_elem_off[b].  InversePolyphaseFilterBank (pfb.py:255-269) runs
  * its transform along the block axis with one stream per polyphase phase and
@@ -202,7 +203,7 @@ int bbt_osm_execute_flat(bbt_osm_plan* plan, const void* in_dev, void* out_dev, 
  * the intermediate stream, which only the two plans see, is laid out as P arrays of two-stream
  * samples -- pair p at complete two-stream samples [p * plane, (p + 1) * plane) -- so that the
  * consumer's first column pass reads 256-byte runs of one pair instead of 16 bytes out of every
- * 8 S-byte row.  out_plane > 0 (one-kernel plans, n_fft <= 4096): bbt_osm_execute /
+ * 8 S-byte row.  out_plane > 0 (one-kernel plans: n_fft <= 4096, 8192, 16384): bbt_osm_execute /
  * bbt_osm_execute_regular write sample r of pair p at out_dev[(p * out_plane + r) * 2 ...]
  * (complex64 units; offsets in the block descriptors count samples of a plane).  in_plane > 0
  * (two-level plans with 256-point columns, n_fft 2^17 ... 2^20): the executes read their input
@@ -218,7 +219,7 @@ int bbt_osm_plan_set_layout(bbt_osm_plan* plan, int64_t in_plane, int64_t out_pl
  * wanted spectrum straddles them.  n_chan: whatever bbt_osm_plan_fusable
  * accepts (a power of two, 256 <= n_chan <= row length n2 of
  * bbt_osm_plan_info, or 16..128 for blocks with 256 columns or of three
- * levels; power-of-two n_fft > 4096), valid_count >= n_chan; valid_start may be
+ * levels; power-of-two n_fft of more than one kernel: 2^15 and up), valid_count >= n_chan; valid_start may be
  * anything, 0 included.  The dedispersed stream itself never exists in memory. */
 int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
                                 int64_t n_blocks, const int64_t* in_off, const int64_t* out_off,
