@@ -1368,6 +1368,43 @@ def test_hundreds_of_short_blocks_in_one_call(n_fft, n_chan):
     assert np.array_equal(whole.read(1000), got[whole.shape[0] // 2 + 5:whole.shape[0] // 2 + 1005])
 
 
+def test_random_runs_of_many_short_blocks():
+    """Randomised version of the test above (seedable with BBT_TEST_SEED): block length, number of
+    blocks, stream shape (one stream, odd counts, several pairs) and channelizer on top."""
+    rng = np.random.default_rng(909 + int(os.environ.get('BBT_TEST_SEED', '0')))
+    fs = 1e6
+    for case in range(6):
+        n_fft = int(rng.choice([2**11, 2**12, 2**13, 2**14, 2**15, 2**16, 2**17, 3000, 6174, 30000]))
+        shape = [(2,), (), (3,), (2, 2)][case % 4]
+        dm = 5. if n_fft >= 4096 else 1.2
+        g = orc.disperse_geometry(fs, 300., 1, -dm)
+        pad = g['pad_start'] + g['pad_end']
+        spf = n_fft - pad
+        nblk = int(rng.integers(17, 1 + max(18, min(700, (1 << 23) // n_fft))))
+        length = nblk * spf + pad + int(rng.integers(0, spf))
+        x = (rng.standard_normal((length,) + shape) + 1j * rng.standard_normal((length,) + shape)).astype(np.complex64)
+        ds = bt.DeviceStream(x, T0, fs, frequency=300 * u.MHz, sideband=1)
+        n_chan = 0
+        if n_fft >= 2**15 and n_fft & (n_fft - 1) == 0 and case % 2:
+            n_chan = 256
+        want, info = orc.dedisperse(x, fs, 300., 1, dm, samples_per_frame=spf, ih_samples_per_frame=min(length, 4096),
+                                    fast_len=HipFFTMaker.next_fast_len)
+        assert info['ih_spf'] == n_fft
+        res = []
+        for per_call in (10**6, 16):
+            dd = bt.Dedisperse(ds, dm, samples_per_frame=spf)
+            assert dd._ih_samples_per_frame == n_fft
+            top = bt.Channelize(dd, n_chan, samples_per_frame=5) if n_chan else dd
+            dd.max_frames_per_call = per_call
+            top.max_frames_per_call = 10**6 if per_call > 16 else max(1, per_call * spf // (5 * max(n_chan, 1)))
+            res.append(top.read_device(top.shape[0]).to_host())
+        ref = orc.channelize(want[:res[0].shape[0] * n_chan], n_chan) if n_chan else want
+        what = f'case {case}: {nblk} blocks of {n_fft}, shape {shape}, {n_chan} channels'
+        assert res[0].shape == ref.shape, what
+        assert_parity(res[0], ref, what)
+        assert np.array_equal(res[0], res[1]), what
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""
