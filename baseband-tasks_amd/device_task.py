@@ -170,8 +170,12 @@ class DeviceTaskMixin:
         spf = self.samples_per_frame
         first = self.offset // spf
         last = (self.offset + count - 1) // spf + 1
-        if last - first > self.max_frames_per_call:
-            # too much for one cache: assemble piecewise into a fresh array.  `max_frames_per_call`
+        if last - first > self.max_frames_per_call + 2:
+            # too much for one cache: assemble piecewise into a fresh array.  (+ 2: a consumer that
+            # sizes its own runs by the same 64 MiB asks for as many samples as this task's bound holds,
+            # and they straddle a frame at either end -- that request is still ONE run here, not a
+            # piecewise read whose pieces the one-range-ahead uploader cannot follow: a host stream
+            # under Channelize(Dedisperse(...)) read at 1.0 instead of 2.3 Gsamples/s.)  `max_frames_per_call`
             # bounds what a run asks of the upstream task (its cache); when the frames are
             # computed straight into the result from a stream that is resident in HBM anyway,
             # nothing needs bounding and all whole frames go in one run
@@ -229,7 +233,7 @@ class DeviceTaskMixin:
         first, last = start // spf, (start + count - 1) // spf + 1
         if self._cache is not None and self._cache_first <= first and last <= self._cache_last:
             return None
-        if last - first > self.max_frames_per_call:
+        if last - first > self.max_frames_per_call + 2:
             return None
         return self._input_span(first, last)
 
@@ -243,7 +247,15 @@ class DeviceTaskMixin:
         of run m + 1 is read and uploaded by the host stream's worker and the result
         of run m - 1 goes down on a stream of its own, into page-locked memory."""
         spf = self.samples_per_frame
-        per = self.host_frames_per_run or self.max_frames_per_call
+        per = self.host_frames_per_run
+        if not per:
+            # runs of about 128 MiB of output: long enough to move at the bus's rate, short enough
+            # that a read of a gigabyte is many runs whose stages overlap (32 frames of 2^20 samples
+            # are half a gigabyte: two runs, nothing to overlap)
+            row = np.dtype(self._device_dtype).itemsize
+            for d in self.sample_shape:
+                row *= d
+            per = max(1, min(self.max_frames_per_call, -(-(1 << 27) // max(spf * row, 1))))
         runs, pos, done = [], self.offset, 0
         while done < count:
             f0 = pos // spf

@@ -353,11 +353,16 @@ class HostUploader:
     def fetch(self, start, count):
         key = (int(start), int(count))
         up = None
+        skip = 0
         if self._pending is not None:
             pending, self._pending = self._pending, None
             got = pending[2].result()                     # (also: the host stream is free again)
-            if pending[:2] == key:
+            if pending[0] <= key[0] and key[0] + key[1] <= pending[0] + pending[1]:
+                # the range that was announced, or part of it: a task that keeps the frame its last
+                # run ended in (DeviceTaskMixin._ensure_frames) asks for one frame less than its
+                # reader foresaw
                 up = got
+                skip = key[0] - pending[0]
             else:
                 # a read-ahead nobody came for: its block goes back to the pool, whose reuse is
                 # ordered by the current stream -- which must therefore come after the upload
@@ -369,7 +374,7 @@ class HostUploader:
         if announced is not None and announced != key:
             self._pending = announced + (self._submit(*announced),)
         current_stream_wait(up.event)
-        return up.dev
+        return up.dev if (skip == 0 and up.dev.shape[0] == key[1]) else up.dev[skip:skip + key[1]]
 
     def close(self):
         pending, self._pending = self._pending, None
