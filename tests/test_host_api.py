@@ -499,6 +499,12 @@ class _FakeHip:
                 self.id, self.shape = fake.blocks, tuple(shape)
                 self.ptr = 0x1000 * self.id
                 fake.log.append(('take', self.id, threading.get_ident() == fake.main))
+
+            def __getitem__(self, item):                 # (a view: same block)
+                start, stop, _ = item.indices(self.shape[0])
+                view = object.__new__(Dev)
+                view.id, view.ptr, view.shape = self.id, self.ptr, (stop - start,) + self.shape[1:]
+                return view
         self.DeviceArray = Dev
 
     # -- what host_pipeline calls
@@ -596,6 +602,18 @@ def test_host_uploader_takes_the_block_before_the_ordering_event_and_loads_each_
     assert up.fetch(0, 8).shape == (8, 1)              # loads [0, 8), then starts [16, 32)
     assert up.fetch(32, 8).shape == (8, 1)             # the read-ahead is dropped, [32, 40) loaded
     assert up.loads == 3
+    up.close()
+    # a task that keeps the frame its last run ended in asks for less than its reader announced:
+    # the fetch takes the part it wants of the pending load -- no second load
+    up = hp.HostUploader(src)
+    up.prefetch(16, 24)
+    up.fetch(0, 16)
+    part = up.fetch(20, 20)                            # [20, 40) of the announced [16, 40)
+    assert part.shape == (20, 1) and up.loads == 2
+    up.prefetch(40, 8)
+    up.fetch(30, 4)                                    # not announced: loaded; then [40, 48) starts
+    assert up.fetch(41, 8).shape == (8, 1)             # reaches past the pending load: loaded anew
+    assert up.loads == 5
     up.close()
 
 
