@@ -81,9 +81,11 @@ class DeviceTaskMixin:
 
     @property
     def max_frames_per_call(self):
-        """Upper bound on the frames computed by one call (bounds device memory): 32, or with
-        short frames as many as make 64 MiB of output -- a call is a handful of kernel launches
-        whatever it holds, and 32 frames of 8192 samples are 4 MiB.  Assignable."""
+        """Upper bound on the frames computed by one call (bounds device memory): as many as make
+        512 MiB of output, 32 at least -- a call is a handful of kernel launches whatever it holds
+        (32 frames of 8192 samples are 4 MiB), a plan with lanes wants a dozen blocks of 2^20 samples
+        per call to keep them busy, and every task of a chain holds two such buffers of 288 GB.
+        Assignable."""
         if self._max_frames_per_call is not None:
             return self._max_frames_per_call
         try:
@@ -93,7 +95,7 @@ class DeviceTaskMixin:
             frame = max(int(self.samples_per_frame) * row, 1)
         except Exception:
             return 32
-        return max(32, min((1 << 26) // frame, 1 << 16))
+        return max(32, min((1 << 29) // frame, 1 << 18))
 
     @max_frames_per_call.setter
     def max_frames_per_call(self, value):
@@ -172,7 +174,7 @@ class DeviceTaskMixin:
         last = (self.offset + count - 1) // spf + 1
         if last - first > self.max_frames_per_call + 2:
             # too much for one cache: assemble piecewise into a fresh array.  (+ 2: a consumer that
-            # sizes its own runs by the same 64 MiB asks for as many samples as this task's bound holds,
+            # sizes its own runs by the same bound asks for as many samples as this task's bound holds,
             # and they straddle a frame at either end -- that request is still ONE run here, not a
             # piecewise read whose pieces the one-range-ahead uploader cannot follow: a host stream
             # under Channelize(Dedisperse(...)) read at 1.0 instead of 2.3 Gsamples/s.)  `max_frames_per_call`
