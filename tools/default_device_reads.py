@@ -2,7 +2,7 @@
 stream with nothing tuned -- frames of one spectrum, the defaults' block lengths, chains of
 several tasks.     python tools/default_device_reads.py"""
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import baseband_tasks_amd as bt
 dev = torch.device('cuda', 0)
@@ -36,6 +36,8 @@ timeit(lambda: bt.Channelize(bt.Dedisperse(ds(), 100.), 1024), 'Channelize(Dedis
 timeit(lambda: bt.Power(bt.Channelize(bt.Dedisperse(ds(), 100.), 1024)), 'Power(Channelize(Dedisperse))', 1024)
 timeit(lambda: bt.Integrate(bt.Power(bt.Channelize(bt.Dedisperse(ds(), 100.), 1024)), 16), 'Integrate(Power(Channelize(Dedisperse)), 16)', 1024 * 16)
 timeit(lambda: bt.PolyphaseFilterBank(ds(), bt.sinc_hamming(12, 1024)), 'PolyphaseFilterBank 12 x 1024', 1024)
+timeit(lambda: bt.Resample(ds(), 0.25), 'Resample(0.25)')
+timeit(lambda: bt.Dedisperse(ds(), 100.), 'Dedisperse(DM 100)')
 timeit(lambda: bt.Dedisperse(bt.Resample(ds(), 0.25), 100.), 'Dedisperse(Resample(0.25), DM 100)')
 timeit(lambda: bt.Square(bt.Channelize(ds(), 64)), 'Square(Channelize(64))', 64)
 timeit(lambda: bt.Dedisperse(ds(1400e6, 20000), 10.), 'Dedisperse(DM 10) on 20000-sample input frames')

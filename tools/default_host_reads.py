@@ -2,7 +2,7 @@
 `read()`, for the frame sizes the defaults give -- the cases that showed the run-size and
 read-ahead cliffs of round 4.     python tools/default_host_reads.py"""
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import baseband_tasks_amd as bt
 from baseband_tasks_amd import host_pipeline as hp
