@@ -22,7 +22,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 140
+#define BBT_VERSION 141
 
 // ---------------------------------------------------------------------------
 // errors
@@ -2472,6 +2472,29 @@ extern "C" int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_
 
 // ---------------------------------------------------------------------------
 // per-stream complex factor
+extern "C" int bbt_chirp(void* out_dev, int64_t n, int n_col, const double* freq_hz, const double* sideband,
+                         const double* ref_hz, double rate_hz, double d_dm, double offset_s, bbt_stream stream) {
+    ARG_TRY(out_dev && freq_hz && sideband && ref_hz, "bbt_chirp: null argument");
+    ARG_TRY(n >= 1 && n_col >= 1 && n_col <= 65535 && rate_hz > 0, "bbt_chirp: bad sizes");
+    std::vector<double4> h(n_col);
+    for (int c = 0; c < n_col; ++c) {
+        ARG_TRY(ref_hz[c] > 0, "bbt_chirp: reference frequency %g of column %d is not positive", ref_hz[c], c);
+        h[c] = make_double4(freq_hz[c], sideband[c], ref_hz[c], 0.);
+    }
+    double4* col = nullptr;
+    HIP_TRY(hipMalloc((void**)&col, sizeof(double4) * n_col));
+    hipError_t e = hipMemcpyAsync(col, h.data(), sizeof(double4) * n_col, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_chirp, dim3((unsigned)((n + 255) / 256), n_col), dim3(256), 0, (hipStream_t)stream,
+                           (float2*)out_dev, (long long)n, col, rate_hz, d_dm, offset_s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);     // (the host copy of `col` goes with this frame)
+    hipFree(col);
+    if (e != hipSuccess) return fail("bbt_chirp: %s", hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" int bbt_scale_streams(const void* in_dev, void* out_dev, int64_t n_samples, int n_elem,
                                  const void* factor_dev, bbt_stream stream) {
     ARG_TRY(in_dev && out_dev && factor_dev, "bbt_scale_streams: null argument");

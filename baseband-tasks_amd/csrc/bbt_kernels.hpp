@@ -1852,6 +1852,30 @@ __global__ __launch_bounds__(256) void k_real_ops(const void* __restrict__ in_,
     }
 }
 
+// The dispersion chirp, Disperse.phase_factor (reference dispersion.py:115-129, dm.py:78-105), in
+// float64 on the GPU, cast to complex64 as the reference casts it:
+//   f = freq_c + s_c fftfreq(n, 1/rate)[k]   (Hz)
+//   phase = s_c d f_MHz (1/fref_MHz - 1/f_MHz)^2 1e6 + offset fftfreq[k]   (cycles; d = D DM)
+//   out[c][k] = exp(2 pi i phase)
+// col[c] = (freq_hz, sideband, ref_hz, unused).  The phase runs to 1e6 cycles and more (config 4):
+// its fractional part is taken in float64 before the sine and cosine.
+__global__ __launch_bounds__(256) void k_chirp(float2* __restrict__ out, long long n, const double4* __restrict__ col,
+                                               double rate_hz, double d, double offset) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int c = blockIdx.y;
+    const double4 p = col[c];
+    const double fft_freq = (double)(k < (n + 1) / 2 ? k : k - n) * rate_hz / (double)n;      // numpy.fft.fftfreq
+    const double f = (p.x + fft_freq * p.y) / 1e6, fr = p.z / 1e6;
+    const double t = 1. / fr - 1. / f;
+    double phase = d * f * (t * t) * 1e6 * p.y;
+    phase += offset * fft_freq;
+    const double frac = phase - floor(phase);
+    double sn, cs;
+    sincospi(2. * frac, &sn, &cs);
+    out[(long long)c * n + k] = make_float2((float)cs, (float)sn);
+}
+
 // Per-stream complex factor (reference sampling.py:374-377, TimeDelay.task:
 // data *= phase_factor): out[i, e] = in[i, e] * factor[e].
 __global__ __launch_bounds__(256) void k_scale_streams(const float2* __restrict__ in,

@@ -97,6 +97,8 @@ SIGNATURES = {
     'bbt_fir_plan_destroy': [_vp],
     'bbt_fir_execute': [_vp, _vp, _vp, _i64, _vp],
     'bbt_real_op': [_vp, _vp, _int, _i64, _int, _int, _vp],
+    'bbt_chirp': [_vp, _i64, _int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                  C.c_double, C.c_double, C.c_double, _vp],
     'bbt_scale_streams': [_vp, _vp, _i64, _int, _vp, _vp],
     'bbt_unpack': [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp],
     'bbt_unpack_masked': [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp],
@@ -108,7 +110,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 140
+MIN_LIB_VERSION = 141
 
 _lib = None
 _lock = threading.Lock()
@@ -669,6 +671,20 @@ class _Plan:
             self.close()
         except Exception:
             pass
+
+
+def chirp(n, frequency_hz, sideband, reference_hz, rate_hz, d_dm, offset_s=0.):
+    """(n_col, n) complex64 dispersion chirps made on the GPU in float64 (bbt_chirp): one
+    column per entry of the equal-length 1-d arrays ``frequency_hz, sideband, reference_hz``."""
+    f = np.ascontiguousarray(frequency_hz, dtype=np.float64).ravel()
+    sb = np.ascontiguousarray(sideband, dtype=np.float64).ravel()
+    fr = np.ascontiguousarray(reference_hz, dtype=np.float64).ravel()
+    assert f.shape == sb.shape == fr.shape
+    out = DeviceArray((f.shape[0], int(n)), np.complex64)
+    pd = C.POINTER(C.c_double)
+    check(lib().bbt_chirp(out.ptr, int(n), f.shape[0], f.ctypes.data_as(pd), sb.ctypes.data_as(pd),
+                          fr.ctypes.data_as(pd), float(rate_hz), float(d_dm), float(offset_s), _stream))
+    return out
 
 
 class OsmPlan(_Plan):

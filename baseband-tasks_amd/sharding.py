@@ -55,6 +55,7 @@ def share_response(task, torch, dist, device, src=0, comm=None):
     n = task._ih_samples_per_frame
     rank = dist.get_rank()
     if rank == src:
+        task.DEVICE_CHIRP = False          # (evaluated once, on the host, and broadcast: also without a GPU)
         columns, index, n_plan = task._plan_layout()
         shape = torch.tensor(list(columns.shape) + [n_plan, int(bool(task._paired))],
                              dtype=torch.int64, device=device)

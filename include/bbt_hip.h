@@ -345,6 +345,19 @@ int bbt_shift_execute(bbt_shift_plan* plan, const void* in_dev, void* out_dev, i
 int bbt_real_op(const void* in_dev, void* out_dev, int op, int64_t n_total, int n_chan,
                 int n_stream, bbt_stream stream);
 
+/* The dispersion chirp on the GPU: Disperse.phase_factor (dispersion.py:115-129) with
+ * DispersionMeasure.phase_delay (dm.py:78-105), float64 arithmetic cast to complex64 as
+ * the reference casts it.  For column c and FFT bin k of n (numpy.fft.fftfreq order):
+ *   f = freq_hz[c] + sideband[c] * fftfreq(n, 1 / rate_hz)[k]
+ *   phase = sideband[c] * d_dm * f_MHz * (1 / ref_MHz[c] - 1 / f_MHz)^2 * 1e6 + offset_s * fftfreq[k]   (cycles)
+ *   out_dev[c * n + k] = exp(2 pi i phase)
+ * d_dm = dispersion constant (1 / 2.41e-4 s MHz^2 cm^3 / pc) times DM, negative to dedisperse;
+ * offset_s = sample_offset / rate (reference frequency outside the band, dispersion.py:123-125).
+ * out_dev: (n_col, n) complex64, what bbt_osm_plan_create takes as a device-resident response.
+ * The host arrays hold n_col doubles each.  Synchronises `stream`. */
+int bbt_chirp(void* out_dev, int64_t n, int n_col, const double* freq_hz, const double* sideband,
+              const double* ref_hz, double rate_hz, double d_dm, double offset_s, bbt_stream stream);
+
 /* Per-stream complex factor: out[i, e] = in[i, e] * factor_dev[e] for the n_elem
  * complex64 elements of a complete sample (TimeDelay.task, sampling.py:374-377).
  * In-place (out_dev == in_dev) is allowed. */

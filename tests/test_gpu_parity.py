@@ -1405,6 +1405,43 @@ def test_random_runs_of_many_short_blocks():
         assert np.array_equal(res[0], res[1]), what
 
 
+def test_chirp_made_on_the_gpu_equals_the_reference_attribute():
+    """The plan's chirp is made on the GPU in float64 (`bbt_chirp`) instead of being evaluated on
+    the host and uploaded; `phase_factor` stays the reference's attribute (dispersion.py:115-129).
+    Both are float64 results rounded to complex64: they agree to a rounding of the last bit (the
+    phase itself, up to 10^6 cycles for config 4, to 1e-9 cycle) -- scalar and per-stream
+    frequencies and sidebands, a reference frequency outside the band (sample offset), odd and
+    even block lengths, both signs of DM."""
+    cases = [
+        dict(n=2**20, fs=16e6, f=1000e6, sb=1, dm=100., ref=None, shape=(2,)),
+        dict(n=2**20, fs=16e6, f=1000e6, sb=np.array([1, -1]), dm=100., ref=None, shape=(2,)),
+        dict(n=6561, fs=1e6, f=np.array([[300e6], [301e6]]), sb=np.array([[1], [-1]]), dm=5., ref=300.7e6, shape=(2, 2)),
+        dict(n=30000, fs=1e6, f=300e6, sb=-1, dm=5., ref=299.2e6, shape=(3,)),
+        dict(n=2**20, fs=6.25e6, f=(403.125e6 + 6.25e6 * np.arange(8)).reshape(8, 1), sb=1, dm=30.,
+             ref=(403.125e6 + 6.25e6 * np.arange(8)).reshape(8, 1), shape=(8, 2)),
+        dict(n=2**24, fs=6.25e6, f=403.125e6, sb=1, dm=557., ref=None, shape=(2,)),      # config 4's worst sub-band
+    ]
+    for case in cases:
+        for cls in (bt.Dedisperse, bt.Disperse):
+            nh = bt.EmptyStreamGenerator((2**27,) + case['shape'], T0, case['fs'], samples_per_frame=case['n'],
+                                         frequency=case['f'], sideband=case['sb'], dtype=np.complex64)
+            kw = {} if case['ref'] is None else dict(reference_frequency=case['ref'])
+            probe = cls(nh, case['dm'], **kw)
+            spf = case['n'] - probe._pad_start - probe._pad_end
+            host = cls(nh, case['dm'], samples_per_frame=spf, **kw)
+            host.DEVICE_CHIRP = False
+            want, want_index = host._response_columns()
+            dev = cls(nh, case['dm'], samples_per_frame=spf, **kw)
+            assert dev._ih_samples_per_frame == case['n'] and dev.DEVICE_CHIRP
+            got, got_index = dev._response_columns()
+            assert isinstance(got, bt.hip.DeviceArray) and dev._phase_factor is None
+            got = got.to_host()
+            assert got.shape == want.shape and np.array_equal(got_index, want_index)
+            err = np.abs(got.astype(np.complex128) - want.astype(np.complex128)).max()
+            assert err < 2.5e-7, (cls.__name__, case['n'], err)
+            assert np.mean(got == want) > 0.9, (cls.__name__, case['n'], np.mean(got == want))
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""

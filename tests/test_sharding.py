@@ -77,7 +77,9 @@ def test_share_response_and_gather_gloo(tmp_path):
     from baseband_tasks_amd import units as u
     nh = bt.EmptyStreamGenerator((16 * 4096, 2), '2020-01-01T00:00:00', 1 * u.MHz, samples_per_frame=4096,
                                  frequency=300 * u.MHz, sideband=np.array([1, -1]))
-    want, idx = bt.Dedisperse(nh, 5., samples_per_frame=4096 - 1538)._response_columns()
+    dd = bt.Dedisperse(nh, 5., samples_per_frame=4096 - 1538)
+    dd.DEVICE_CHIRP = False                     # (the host evaluation: what rank 0 broadcasts)
+    want, idx = dd._response_columns()
     assert np.array_equal(r1['resp'], want) and list(idx) == [0, 1]
     # spans tile the frames; gather is in rank order
     assert r0['span'][0] == 0 and r0['span'][1] == r1['span'][0]
