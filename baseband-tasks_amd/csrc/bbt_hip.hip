@@ -1905,6 +1905,16 @@ static void launch_short(const bbt_chan_plan* p, const float2* in, float2* out, 
                          float scale, hipStream_t st) {
     constexpr int R = (N <= 16) ? 1 : N / 16;
     constexpr int FPW = 256 / R;
+    if constexpr (N <= 16) {
+        if (p->S == 2) {                  // one pair: whole lines in and out, the transposition in LDS
+            constexpr size_t lds = 256 * (N + 1) * 16;
+            if (ensure_dyn_lds((const void*)k_fft_tiny<N, SIGN>, lds) == 0) {
+                hipLaunchKernelGGL((k_fft_tiny<N, SIGN>), dim3((unsigned)((n_fft + 255) / 256)), dim3(256), lds, st,
+                                   in, out, (long long)n_fft, scale);
+                return;
+            }
+        }
+    }
 #define BBT_SHORT(PP_)                                                                         \
     {                                                                                          \
         constexpr int FPB = FPW / PP_;                                                         \

@@ -338,6 +338,49 @@ __global__ __launch_bounds__(256) void k_fft_short(const float2* __restrict__ in
     }
 }
 
+// The same for N <= 16 on ONE stream pair (S == 2), where a thread's N samples are 16 N contiguous
+// bytes and the lanes of a load sit 16 N bytes apart -- 64 cache lines per wave instruction for
+// 16 bytes each.  Here the workgroup's 256 transforms (4096 N contiguous bytes) come in and go out
+// in whole lines and change hands in LDS: element e at e + e / N (16-byte slots, one pad per
+// transform: a thread's N slots are then (N + 1) 16 bytes apart from its neighbour's, free of
+// bank conflicts for N = 2 .. 16); a thread reads and rewrites only its own slots, so one barrier
+// each way.  256 (N + 1) 16 bytes of dynamic LDS.
+template <int N, int SIGN>
+__global__ __launch_bounds__(256) void k_fft_tiny(const float2* __restrict__ in, float2* __restrict__ out,
+                                                  long long n_fft, float scale) {
+    extern __shared__ f4v tiny_lds[];
+    const int t = threadIdx.x;
+    const long long first = (long long)blockIdx.x * 256 * N;         // first complete sample of this workgroup
+    const long long total = n_fft * N;
+    const f4v* src = reinterpret_cast<const f4v*>(in) + first;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int e = t + 256 * k;
+        if (first + e < total) tiny_lds[e + e / N] = __builtin_nontemporal_load(src + e);
+    }
+    __syncthreads();
+    const bool active = (long long)blockIdx.x * 256 + t < n_fft;
+    if (active) {
+        c2 v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const f4v x = tiny_lds[t * (N + 1) + j];
+            v[j] = c2{v2{x.x, x.z}, v2{x.y, x.w}};
+        }
+        radixR<SIGN, N>(v);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            tiny_lds[t * (N + 1) + j] = f4v{v[j].re.x * scale, v[j].im.x * scale, v[j].re.y * scale, v[j].im.y * scale};
+    }
+    __syncthreads();
+    f4v* dst = reinterpret_cast<f4v*>(out) + first;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int e = t + 256 * k;
+        if (first + e < total) __builtin_nontemporal_store(tiny_lds[e + e / N], dst + e);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Overlap-save block descriptors (one launch handles <= BBT_MAX_CHUNK blocks).
 #define BBT_MAX_CHUNK 16

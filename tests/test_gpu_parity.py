@@ -419,7 +419,7 @@ def test_config5_at_the_references_default_block():
     assert_parity(got, want, 'resample, default block')
 
 
-@pytest.mark.parametrize('n', [3, 5, 6, 7, 12, 100, 360, 1000, 1029, 3000, 6561, 8192, 16384])
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6, 7, 8, 12, 16, 100, 360, 1000, 1029, 3000, 6561, 8192, 16384])
 def test_channel_counts_that_are_not_powers_of_two(n):
     """Channelize / Dechannelize for any n = 2^a 3^b 5^c 7^d <= 8192 (reference: any n
     numpy.fft takes, channelize.py:73-74) and for 16384; 8192 and 16384 run on the
@@ -432,6 +432,14 @@ def test_channel_counts_that_are_not_powers_of_two(n):
         assert_parity(z, orc.channelize(x[:z.shape[0] * n], n), f'n={n} streams {shape}')
         back = bt.Dechannelize(ch).read()
         assert_parity(back, x[:back.shape[0]], f'round trip n={n} streams {shape}')
+    if n <= 16:
+        # many transforms of one stream pair: whole workgroups and a ragged last one (k_fft_tiny)
+        count = 256 * 7 + 19
+        x = orc.noise_stream(29, 0, count * n, 1000, (2,))
+        ds = bt.DeviceStream(x, T0, 1 * u.MHz)
+        z = bt.Channelize(ds, n, samples_per_frame=count).read()
+        assert z.shape[0] == count
+        assert_parity(z, orc.channelize(x, n), f'n={n}, {count} transforms')
 
 
 @pytest.mark.parametrize('ref_mhz', [None, 300.4, 300.7, 299.2])
