@@ -1907,9 +1907,10 @@ static void launch_short(const bbt_chan_plan* p, const float2* in, float2* out, 
     constexpr int FPW = 256 / R;
     if constexpr (N <= 16) {
         if (p->S == 2) {                  // one pair: whole lines in and out, the transposition in LDS
-            constexpr size_t lds = 256 * (N + 1) * 16;
-            if (ensure_dyn_lds((const void*)k_fft_tiny<N, SIGN>, lds) == 0) {
-                hipLaunchKernelGGL((k_fft_tiny<N, SIGN>), dim3((unsigned)((n_fft + 255) / 256)), dim3(256), lds, st,
+            constexpr int T = 256;          // (128 for N = 16 -- four workgroups per CU instead of two -- measured no faster)
+            constexpr size_t lds = T * (N + 1) * 16;
+            if (ensure_dyn_lds((const void*)k_fft_tiny<N, SIGN, T>, lds) == 0) {
+                hipLaunchKernelGGL((k_fft_tiny<N, SIGN, T>), dim3((unsigned)((n_fft + T - 1) / T)), dim3(T), lds, st,
                                    in, out, (long long)n_fft, scale);
                 return;
             }

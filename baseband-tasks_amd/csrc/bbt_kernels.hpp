@@ -344,22 +344,22 @@ __global__ __launch_bounds__(256) void k_fft_short(const float2* __restrict__ in
 // in whole lines and change hands in LDS: element e at e + e / N (16-byte slots, one pad per
 // transform: a thread's N slots are then (N + 1) 16 bytes apart from its neighbour's, free of
 // bank conflicts for N = 2 .. 16); a thread reads and rewrites only its own slots, so one barrier
-// each way.  256 (N + 1) 16 bytes of dynamic LDS.
-template <int N, int SIGN>
-__global__ __launch_bounds__(256) void k_fft_tiny(const float2* __restrict__ in, float2* __restrict__ out,
+// each way.  T transforms per workgroup: T (N + 1) 16 bytes of dynamic LDS.
+template <int N, int SIGN, int T>
+__global__ __launch_bounds__(T) void k_fft_tiny(const float2* __restrict__ in, float2* __restrict__ out,
                                                   long long n_fft, float scale) {
     extern __shared__ f4v tiny_lds[];
     const int t = threadIdx.x;
-    const long long first = (long long)blockIdx.x * 256 * N;         // first complete sample of this workgroup
+    const long long first = (long long)blockIdx.x * T * N;         // first complete sample of this workgroup
     const long long total = n_fft * N;
     const f4v* src = reinterpret_cast<const f4v*>(in) + first;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const int e = t + 256 * k;
+        const int e = t + T * k;
         if (first + e < total) tiny_lds[e + e / N] = __builtin_nontemporal_load(src + e);
     }
     __syncthreads();
-    const bool active = (long long)blockIdx.x * 256 + t < n_fft;
+    const bool active = (long long)blockIdx.x * T + t < n_fft;
     if (active) {
         c2 v[N];
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_fft_tiny(const float2* __restrict__ in,
     f4v* dst = reinterpret_cast<f4v*>(out) + first;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const int e = t + 256 * k;
+        const int e = t + T * k;
         if (first + e < total) __builtin_nontemporal_store(tiny_lds[e + e / N], dst + e);
     }
 }

@@ -221,6 +221,18 @@ def chan_8192(reps):
     return _channelize_row(8192, reps)
 
 
+def chan_16(reps):
+    return _channelize_row(16, reps)
+
+
+def chan_32(reps):
+    return _channelize_row(32, reps)
+
+
+def chan_128(reps):
+    return _channelize_row(128, reps)
+
+
 def chan_16384(reps):
     return _channelize_row(16384, reps)
 
@@ -359,7 +371,7 @@ def chan_single_1024(reps):
                 note='Channelize(1024) of ONE complex64 stream (padded to a pair inside)')
 
 
-ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_6000, chan_8192=chan_8192, chan_16384=chan_16384,
+ROWS = dict(chan_64=chan_64, chan_8=chan_8, chan_1000=chan_1000, chan_6000=chan_6000, chan_8192=chan_8192, chan_16384=chan_16384, chan_16=chan_16, chan_32=chan_32, chan_128=chan_128,
             chan_real_1024=chan_real_1024, chan_real4_1024=chan_real4_1024, pfb_4x1024=pfb_4x1024, pfb_8x2048=pfb_8x2048, pfb_16x4096=pfb_16x4096,
             pfb_12x256=pfb_12x256, pfb_real_12x1024=pfb_real_12x1024, dedisperse_real=dedisperse_real,
             dedisperse_single=dedisperse_single, dedisperse_default=dedisperse_default, chan_single_1024=chan_single_1024,
