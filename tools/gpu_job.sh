@@ -5,7 +5,7 @@
 #
 #   suite                     whole GPU test suite (-x), then the default bench.py
 #   tests   K=<expr> [F=<files>] [T=<s>]     selected tests (pytest -k) of test_gpu_parity.py or files F
-#   stress  SEEDS="0 1 .."    the randomised tests under many BBT_TEST_SEEDs + the padding regression
+#   stress  SEEDS="0 1 .."    the randomised tests under many BBT_TEST_SEEDs + the padding regression + tools/soak_reads.py
 #   ab      A=<lib> B=<lib> [ARGS=..] [N=3]  alternating headline runs of two library builds
 #   envab   ENV_A=".." ENV_B=".." [ARGS=..] [N=3]   the same for two environment settings
 #   one     CONFIGS="config2 config5" [ENVS="A=1|B=2"]   tools/bench_one.py rows (optionally per env)
@@ -72,7 +72,8 @@ stress)
     for s in ${SEEDS:-0 1 2 3 4 5 6 7 8}; do
         BBT_TEST_SEED=$s timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -k "random_" > $OUT/seed$s.txt 2>&1 || { say "seed $s failed"; tail -5 $OUT/seed$s.txt; exit 1; }
         tail -1 $OUT/seed$s.txt
-    done ;;
+    done
+    timeout -k 10 600 python3 tools/soak_reads.py > $OUT/soak.txt 2>&1; say "soak rc=$?"; tail -1 $OUT/soak.txt ;;
 ab|envab)
     for r in $(seq 1 ${N:-3}); do
         for v in A B; do
