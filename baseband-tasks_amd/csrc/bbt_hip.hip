@@ -923,11 +923,15 @@ static int osm_launch_pass(bbt_osm_plan* p, int pass, const float2* in, float2* 
         pairs_view.nblk = (ch.nblk + 1) / 2;
     }
     const OsmChunk& chw = p->single ? pairs_view : ch;       // what the row pass counts
-    const dim3 g16(p->n2 / 256 * p->npair, chw.nblk);
+    const dim3 g16(p->n2 / 256 * p->npair, chw.nblk);        // (the same count with 8 pairs x 32 columns per workgroup)
+    const bool pp8 = p->n1 == 16 && !p->single && p->npair % 8 == 0;
     if (pass == 0) {
         if (p->n1 == 16 && p->single)
             hipLaunchKernelGGL((k_osm_col16<true, false, true>), g16, dim3(256), 0, st, in, out, work, ch,
                                1, p->n2, so);
+        else if (pp8)
+            hipLaunchKernelGGL((k_osm_col16<true, false, false, 8>), g16, dim3(256), 0, st, in, out, work, ch,
+                               p->S, p->n2, so);
         else if (p->n1 == 16)
             hipLaunchKernelGGL((k_osm_col16<true, false>), g16, dim3(256), 0, st, in, out, work, ch,
                                p->S, p->n2, so);
@@ -942,6 +946,12 @@ static int osm_launch_pass(bbt_osm_plan* p, int pass, const float2* in, float2* 
         else if (p->single)
             hipLaunchKernelGGL((k_osm_col16<false, false, true>), g16, dim3(256), 0, st, in, out,
                                work, ch, 1, p->n2, so);
+        else if (nch && pp8)
+            hipLaunchKernelGGL((k_osm_col16<false, true, false, 8>), g16, dim3(256), 0, st, in, out,
+                               work, ch, p->S, p->n2, so);
+        else if (pp8)
+            hipLaunchKernelGGL((k_osm_col16<false, false, false, 8>), g16, dim3(256), 0, st, in, out,
+                               work, ch, p->S, p->n2, so);
         else if (nch)
             hipLaunchKernelGGL((k_osm_col16<false, true>), g16, dim3(256), 0, st, in, out,
                                work, ch, p->S, p->n2, so);

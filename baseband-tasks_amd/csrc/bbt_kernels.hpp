@@ -735,15 +735,22 @@ __global__ __launch_bounds__(PP* N / 16) void k_osm_small(const float2* __restri
 
 // Column pass, N1 == 16: one thread per 2-stream column, radix-16 in registers.
 //   FIRST: stream -> work (forward).  !FIRST: work -> valid output (inverse).
-template <bool FIRST, bool SPEC = false, bool SINGLE = false>
+// PP > 1 (many streams): the lanes run over PP stream pairs first, then over 256 / PP columns --
+// PP * 16 contiguous bytes of every complete sample on the stream side (a whole line for 8
+// pairs, where one pair per workgroup takes 16 bytes out of every S * 8-byte row) and
+// 256 / PP * 16-byte runs of the work buffer (1024 sub-bands x 2 pol on 2^16-sample blocks,
+// the CHIME-native form of config 4: Dedisperse 49.9 G stream-samples/s with PP = 1).
+template <bool FIRST, bool SPEC = false, bool SINGLE = false, int PP = 1>
 __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in,
                                                    float2* __restrict__ out,
                                                    float2* __restrict__ work, OsmChunk ch, int S,
                                                    int N2, SpecOut so) {
     const int npair = SINGLE ? 1 : S >> 1;
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int n2 = (vb / npair) * 256 + threadIdx.x;
-    const int b = blockIdx.y, sp = vb % npair;
+    constexpr int COLS = 256 / PP;
+    const int npg = npair / PP;                   // groups of PP pairs (npair % PP == 0)
+    const int n2 = (vb / npg) * COLS + threadIdx.x / PP;
+    const int b = blockIdx.y, sp = (vb % npg) * PP + threadIdx.x % PP;
     float2* w = work + ((long long)(b * npair + sp) * 16) * N2 * 2 + (long long)n2 * 2;
     c2 v[16];
     if constexpr (SINGLE) {                       // b = pair of blocks of the one stream

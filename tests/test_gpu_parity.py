@@ -1456,6 +1456,32 @@ def test_chirp_made_on_the_gpu_equals_the_reference_attribute():
             assert np.mean(got == want) > 0.9, (cls.__name__, case['n'], np.mean(got == want))
 
 
+@pytest.mark.parametrize('n_fft', [2**15, 2**16])
+def test_sixteen_streams_on_blocks_with_16_point_columns(n_fft):
+    """16 x N2 blocks with many streams: the column passes' lanes run over 8 stream pairs first
+    (whole lines of every complete sample; `k_osm_col16<..., PP = 8>`) -- per-sub-band
+    frequencies and reference frequencies (the CHIME-native form of config 4), plain
+    output and the fused channelizer, against the oracle."""
+    freq = (400. + 0.39 * np.arange(8)).reshape(8, 1) * u.MHz
+    fs, dm = 0.39 * u.MHz, 60.
+    nh0 = noise(8 * n_fft, (8, 2), n_fft, seed=5, fs=fs, frequency=freq, sideband=1)
+    pad = (lambda d: d._pad_start + d._pad_end)(bt.Dedisperse(nh0, dm, reference_frequency=freq))
+    assert pad < n_fft // 2
+    spf = n_fft - pad
+    length = 3 * spf + pad + 555
+    x = orc.noise_stream(5, 0, length, n_fft, (8, 2))
+    ds = bt.DeviceStream(x, T0, fs, frequency=freq, sideband=1)
+    want, info = orc.dedisperse(x, 0.39e6, np.asarray(freq) / 1e6, 1, dm, reference_frequency_mhz=np.asarray(freq) / 1e6,
+                                samples_per_frame=spf, ih_samples_per_frame=n_fft)
+    dd = bt.Dedisperse(ds, dm, reference_frequency=freq, samples_per_frame=spf)
+    assert dd._ih_samples_per_frame == n_fft and dd._get_plan().info()['n1'] == 16
+    assert_parity(dd.read(), want, f'16 streams, blocks of {n_fft}')
+    ch = bt.Channelize(bt.Dedisperse(ds, dm, reference_frequency=freq, samples_per_frame=spf), 256, 5)
+    assert ch._fusable_input() is not None
+    z = ch.read()
+    assert_parity(z, orc.channelize(want[:z.shape[0] * 256], 256), f'fused channelizer, 16 streams, blocks of {n_fft}')
+
+
 def test_device_memory_pool_reuses_blocks():
     """bbt_malloc/bbt_free cache blocks (the per-call output arrays of a reader
     must not cost a hipMalloc + synchronising hipFree each)."""
