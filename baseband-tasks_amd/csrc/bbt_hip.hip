@@ -1320,8 +1320,13 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
             gn2 = (int)n_fft;
         }
         p->n1 = gn1;
-    } else if (n_fft <= 4096 || ((n_fft == 8192 || n_fft == 16384) && !getenv("BBT_OSM_NO_BIG"))) {
-        p->n1 = 1;               // (8192 / 16384 samples: one workgroup of 512 / 1024 threads, big_kernels.hpp)
+    } else if (n_fft <= 4096 ||
+               ((n_fft == 8192 || n_fft == 16384) && (single || (n_stream / 2) % 8 != 0) && !getenv("BBT_OSM_NO_BIG"))) {
+        // (8192 / 16384 samples: one workgroup of 512 / 1024 threads, big_kernels.hpp -- one stream pair
+        // per workgroup, 16 bytes of every complete sample: with pairs in eights the two-level plan, whose
+        // 16-point column passes then move whole lines, is as fast at 8192 and faster at 16384 samples:
+        // 16 / 128 / 2048 streams 113 / 109 / 84 against 84 / 88 / 58 G stream-samples/s)
+        p->n1 = 1;
     } else if (n_fft <= (1 << 16)) {
         p->n1 = 16;
     } else if (n_fft <= (1 << 20)) {
