@@ -1336,7 +1336,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         // (A 512-point column pass holds 8 columns in 48 KiB of exchange area, three workgroups
         // per CU; the row pass is the 4096-point one of the 2^20 blocks.)
         p->n1 = 512;
-    } else if (n_fft == (1 << 22)) {
+    } else if (n_fft == (1 << 22) && (single || (n_stream / 2) % 8 != 0)) {
+        // (stream pairs in eights: three levels, whose 256-point column passes take 8 pairs per workgroup --
+        // 16 / 128 streams 59.9 / 66.4 against 54.3 / 59.7 G stream-samples/s; at 2^21 two levels stay ahead)
         p->n1 = 1024;            // 1024 x 4096, likewise (8 columns: 80 KiB, two workgroups per CU)
     } else {
         p->outer = 256;          // three levels, 256 x 16 x N2

@@ -1841,14 +1841,15 @@ def test_convolve_on_short_blocks_matches_numpy_and_direct_filter(shape):
         assert np.array_equal(cv.read(40000), got[5000:45000])
 
 
-def test_blocks_longer_than_2_20_with_sixteen_streams():
-    """2^21-sample blocks x 16 streams: plain and fused-channelizer outputs (256,
-    64 and 16 channels); two levels, 512 x 4096 (the 512-point column pass)."""
-    n_fft = 2**21
+@pytest.mark.parametrize('n_fft,n1', [(2**21, 512), (2**22, 16)])
+def test_blocks_longer_than_2_20_with_sixteen_streams(n_fft, n1):
+    """2^21- / 2^22-sample blocks x 16 streams: plain and fused-channelizer outputs (256,
+    64 and 16 channels); 2^21 on two levels, 512 x 4096 (the 512-point column pass), 2^22 with
+    stream pairs in eights on three (256 x 16 x 1024: its column passes take 8 pairs at once)."""
     freq = (400. + 6.25 * np.arange(8)).reshape(8, 1) * u.MHz
     nh = noise(n_fft + 300000, (8, 2), 2**19, seed=63, fs=6.25 * u.MHz, frequency=freq, sideband=1)
     x = nh.read()
-    dm = 60.
+    dm = 60. if n_fft == 2**21 else 120.          # (padding 2^19 .. 2^20 quarter-blocks: the power-of-two rule gives 2^22)
     pow2 = HipFFTMaker(power_of_two=True)
     want, info = orc.dedisperse(x, 6.25e6, np.asarray(freq) / 1e6, 1, dm,
                                 reference_frequency_mhz=np.asarray(freq) / 1e6,
@@ -1856,7 +1857,7 @@ def test_blocks_longer_than_2_20_with_sixteen_streams():
     with bt.fft_maker.set(pow2):
         dd = bt.Dedisperse(nh, dm, reference_frequency=freq)
         assert dd._ih_samples_per_frame == info['ih_spf'] == n_fft
-        assert dd._get_plan().info()['n1'] == 512
+        assert dd._get_plan().info()['n1'] == n1
         assert_parity(dd.read(), want, 'dedisperse, 16 streams')
         ds = bt.DeviceStream(x, T0, 6.25 * u.MHz, frequency=freq, sideband=1)     # (re-reading the noise
         for n in (256, 64, 16):                                                      # generator per call is slow)
