@@ -1962,6 +1962,26 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
                            (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
         return;
     }
+    // several pairs: the lanes over PP pairs first (k_fft_rows_pp) -- the largest of 8, 4, 2 that the
+    // exchange area allows (as k_osm_small: 8 up to 512 points, 4 up to 2048, 2 at 4096) and that divides
+    // the number of pairs.  Measured, Channelize(256 / 1024 / 4096) in G stream-samples/s: 16 streams
+    // 174 / 150 / 165 -> 361 / 294 / 252, 2048 streams 87 / 114 / 124 -> 355 / 274 / 168 (two streams: 383 / 374 / 318).
+    constexpr int CAP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
+#define BBT_ROWS_PP(PP_)                                                                                         \
+    if (PP_ <= CAP && p->npair % PP_ == 0 && n_fft * (p->npair / PP_) < (1ll << 31)) {                          \
+        constexpr int Q = PP_ <= CAP ? PP_ : 1;                                                                  \
+        constexpr size_t lds = FftGeo<N>::LDS_ELEMS * sizeof(v2) * Q;                                            \
+        if (ensure_dyn_lds((const void*)k_fft_rows_pp<N, SIGN, Q>, lds) == 0) {                                  \
+            hipLaunchKernelGGL((k_fft_rows_pp<N, SIGN, Q>), dim3((unsigned)(n_fft * (p->npair / Q))),            \
+                               dim3(Q * N / 16), lds, st, in, out, (long long)n_fft, p->S, scale, p->tab.tw0,    \
+                               p->tab.tw1);                                                                      \
+            return;                                                                                              \
+        }                                                                                                        \
+    }
+    if (!p->split_real && p->S > 2 && !getenv("BBT_ROWS_NO_PP")) {
+        BBT_ROWS_PP(8) BBT_ROWS_PP(4) BBT_ROWS_PP(2)
+    }
+#undef BBT_ROWS_PP
     const unsigned gx = (unsigned)((n_fft + FPW - 1) / FPW);
     if (p->split_real) {            // every stream z = a + i b of two real streams: half spectra out / in
         hipLaunchKernelGGL((k_fft_rows<N, SIGN, FPW, false, true>), dim3(gx * p->npair), dim3(FPW * N / 16), 0,

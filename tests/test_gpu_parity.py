@@ -423,11 +423,13 @@ def test_config5_at_the_references_default_block():
     assert_parity(got, want, 'resample, default block')
 
 
-@pytest.mark.parametrize('n', [2, 3, 4, 5, 6, 7, 8, 12, 16, 100, 360, 1000, 1029, 3000, 6561, 8192, 16384])
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6, 7, 8, 12, 16, 100, 256, 360, 512, 1000, 1024, 1029, 2048, 3000, 4096, 6561,
+                               8192, 16384])
 def test_channel_counts_that_are_not_powers_of_two(n):
     """Channelize / Dechannelize for any n = 2^a 3^b 5^c 7^d <= 8192 (reference: any n
     numpy.fft takes, channelize.py:73-74) and for 16384; 8192 and 16384 run on the
-    four-stage one-workgroup transforms of csrc/fft_big.hpp."""
+    four-stage one-workgroup transforms of csrc/fft_big.hpp; 2, 4 and 16 streams: powers of two
+    from 256 on take several stream pairs per workgroup (k_fft_rows_pp: 2, 4 or 8 by n)."""
     for shape in ((2,), (3,), (8, 2)):
         nh = noise(5 * n + 3, shape, 1000, seed=23, fs=1 * u.MHz, frequency=300 * u.MHz, sideband=1)
         x = orc.noise_stream(23, 0, 5 * n + 3, 1000, shape)

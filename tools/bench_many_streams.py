@@ -1,0 +1,24 @@
+"""Channelize with 256 / 1024 / 4096 channels on 4 ... 2048 streams (dev tool, GPU box): the case where
+one stream pair per workgroup reads 16 bytes of every complete sample (BBT_ROWS_NO_PP=1: that route).
+    python tools/bench_many_streams.py"""
+import sys, time, os, gc
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import baseband_tasks_amd as bt
+dev = torch.device('cuda', 0)
+bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
+gc.disable()
+for S in (4, 8, 16, 128, 2048):
+    n = (2**28) // S
+    x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
+    ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 1e6, samples_per_frame=2**16, frequency=300e6, sideband=1)
+    for nc in (256, 1024, 4096):
+        t = bt.Channelize(ds, nc)
+        def step():
+            t.invalidate_cache(); t.seek(0); return t.read_device(t.shape[0])
+        for _ in range(3): step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(4): y = step()
+        _ = y.ptr; torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+        print(f"S={S:5d} Channelize({nc:4d}): {t.shape[0] * nc * S / dt / 1e9:7.1f} G stream-samples/s", flush=True)
+    del ds, x
