@@ -270,6 +270,14 @@ class DeviceTaskMixin:
         # two result buffers in turn: run m + 2 is computed into the buffer run m came from, once
         # that run has gone down
         buffers = [self._cache_buffer, self._cache_buffer_b]
+        for buf in buffers:
+            # A buffer may still be owed a deferred call from before this read (a `read_device`
+            # result nobody touched, or one only a downstream deferred plan read): `_out_buffer`
+            # would then swap the two behind this loop's back and two consecutive runs would share
+            # one buffer, the second computing into it while the first is still going down.
+            # Settled here, and again by `piece.ptr` after every run, no swap happens inside.
+            if buf is not None:
+                buf.ptr
         gone = [None, None]
         computed = host_pipeline.StreamEvent()
         for i, (f0, f1, pos, done, n) in enumerate(runs):
@@ -281,6 +289,12 @@ class DeviceTaskMixin:
             self._cache_buffer = buffers[b]
             if gone[b] is not None:
                 host_pipeline.current_stream_wait(gone[b])
+            other = buffers[1 - b]
+            if (gone[1 - b] is not None and other is not None and buffers[b] is not None
+                    and other.owner is buffers[b].owner):
+                # (both turns on one allocation -- cannot happen after the settling above; if it
+                # ever does, the run waits for the other turn's download as well)
+                host_pipeline.current_stream_wait(gone[1 - b])
             cache, c0 = self._ensure_frames(f0, f1)
             buffers[b] = self._cache_buffer
             piece = cache[pos - c0:pos - c0 + n]

@@ -739,6 +739,58 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     assert c.ptr and fake.log[n0][0] == 'bbt_stream_wait_event'      # ... after the call before last
 
 
+def test_pipelined_read_after_an_unconsumed_device_read_keeps_two_buffers(monkeypatch):
+    """`read_device` whose result nobody touched leaves the cache buffer owed a deferred
+    call; a pipelined `read` entered in that state must still alternate between TWO allocations
+    (`_out_buffer`'s own swap had made runs 0 and 1 share one, run 1 computing into it while run 0
+    was still going down).  No GPU: the logging stand-in for the library.  Reference: a reader that
+    seeks and reads again, base.py:389-438."""
+    from baseband_tasks_amd import hip, host_pipeline as hp
+    from baseband_tasks_amd.device_task import DeviceTaskMixin
+    fake = _FakeLib()
+    monkeypatch.setattr(hip, '_lib', fake)
+    monkeypatch.setattr(hip, '_events', hip._EventPool())
+    monkeypatch.setattr(hp, '_copy_pair', (hp.Stream(), hp.Stream()))
+    spf = 64
+    computed = []
+
+    class Task(DeviceTaskMixin):
+        sample_shape = (2,)
+        dtype = np.dtype(np.complex64)
+        samples_per_frame = spf
+        shape = (spf * 8, 2)
+        offset = 0
+        host_frames_per_run = 2
+
+        def _compute_frames(self, first, last, out):
+            # a deferred plan call: the output's allocation is owed its completion event
+            out.owner.owe(hip._Pending(hip._Done(hip._events.take(), 1), ()), write=True)
+            computed.append((first, last, out.owner))
+
+        def _input_span(self, first, last):
+            return None
+    t = Task()
+    # state on entry: buffer A owed (an untouched read_device), buffer B present and idle
+    t._cache_buffer_b = hip.DeviceArray((spf * 2 * 2,), np.complex64)
+    b_alloc = t._cache_buffer_b.owner
+    t._ensure_frames(0, 2)
+    a_alloc = t._cache_buffer.owner
+    assert a_alloc is not b_alloc and t._cache_buffer.pending and not t._cache_buffer_b.pending
+    t.invalidate_cache()
+    del computed[:]
+    out = np.empty((spf * 8, 2), np.complex64)
+    t._read_pipelined(spf * 8, out)
+    owners = [o for _, _, o in computed]
+    assert [c[:2] for c in computed] == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    for k in range(3):
+        assert owners[k] is not owners[k + 1], 'consecutive runs share a buffer'
+    assert owners[0] is owners[2] and owners[1] is owners[3]
+    assert {id(o) for o in owners} == {id(a_alloc), id(b_alloc)}
+    # every download is queued after the run's own compute and before the buffer's next turn
+    names = [e[0] for e in fake.log]
+    assert names.count('bbt_memcpy_d2h') == 4
+
+
 def test_big_reads_are_cut_into_whole_frame_runs_written_in_place(monkeypatch):
     """`DeviceTaskMixin.read_device` for more frames than one cache holds (no GPU: a task that logs):
     whole frames are computed straight into their slice of the result (marked `fresh`: deferred
