@@ -134,8 +134,13 @@ class Disperse(SpectralMultiplyTask):
             return super()._response_columns()
         cols = [np.broadcast_to(a, bshape).ravel() for a in (freq, side, ref)]
         d_dm = self._dm.dispersion_delay_constant * float(self._dm)
-        columns = hip.chirp(self._ih_samples_per_frame, cols[0], cols[1], cols[2], self.sample_rate, d_dm,
-                            self._sample_offset / self.sample_rate)
+        try:
+            columns = hip.chirp(self._ih_samples_per_frame, cols[0], cols[1], cols[2], self.sample_rate, d_dm,
+                                self._sample_offset / self.sample_rate)
+        except hip.HipError:
+            # (geometries `bbt_chirp` refuses -- more than 65535 distinct columns, a reference
+            # frequency that is not positive: the host attribute handles every case the reference does)
+            return super()._response_columns()
         ncol = cols[0].shape[0]
         index = np.broadcast_to(np.arange(ncol).reshape(bshape), self.sample_shape).ravel().astype(np.int32)
         if self._n_stream_even != self._n_stream:

@@ -7,6 +7,7 @@ import importlib.util
 import os
 import sys
 import threading
+import weakref
 
 import numpy as np
 
@@ -397,6 +398,61 @@ class _Allocation:
             pass
 
 
+# Deferred plan calls that still READ memory this package does not own (a torch tensor handed in
+# as a stream's samples): id(owner) -> (weak reference to the owner, [_Pending, ...]).  The owner
+# has no `_Allocation` to carry the events, so whoever is about to OVERWRITE such memory in place
+# asks `wait_for_readers` first (include/bbt_hip.h: a deferred call's input stays untouched until
+# its completion event).
+_foreign_reads = {}
+_FOREIGN_MAX = 64
+
+
+def _owe_foreign_read(owner, pending):
+    key = id(owner)
+    entry = _foreign_reads.get(key)
+    if entry is None or entry[0]() is not owner:
+        try:
+            ref = weakref.ref(owner, lambda _r, k=key: _drop_foreign(k))
+        except TypeError:
+            return False
+        entry = _foreign_reads[key] = (ref, [])
+    entry[1].append(pending)
+    if len(entry[1]) > _FOREIGN_MAX:
+        old = entry[1].pop(0)
+        check(lib().bbt_stream_wait_event(_stream, old.done.event))
+        old.done.release()
+    return True
+
+
+def _drop_foreign(key):
+    entry = _foreign_reads.pop(key, None)
+    if entry is not None:
+        for p in entry[1]:
+            try:
+                p.done.release()
+            except Exception:
+                pass
+
+
+def wait_for_readers(array, stream=_NO_STREAM):
+    """Order ``stream`` (default: the package's current stream) after every deferred plan call
+    that still reads ``array`` -- a `DeviceArray`, or the foreign object (a torch tensor) that was
+    handed to `DeviceStream` / `as_device_array`.  Call it before refilling such an input in
+    place on that stream; memory of this package needs no call (`DeviceArray.ptr` waits)."""
+    owner = array.owner if isinstance(array, DeviceArray) else array
+    if owner.__class__ is _Allocation:
+        owner.settle(stream)
+        return
+    entry = _foreign_reads.get(id(owner))
+    if entry is None or entry[0]() is not owner:
+        return
+    target = _stream if stream is _NO_STREAM else stream
+    owed, entry[1][:] = list(entry[1]), []
+    for p in owed:
+        check(lib().bbt_stream_wait_event(target, p.done.event))
+        p.done.release()
+
+
 class DeviceArray:
     """C-contiguous array in HBM: (ptr, shape, dtype); leading-axis slices are
     zero-copy views.  ``owner`` keeps the allocation (or a foreign object such
@@ -728,7 +784,8 @@ class OsmPlan(_Plan):
 
     def _call(self, fn, in_dev, out_dev, *args):
         """One execute entry point of the C ABI on (in_dev, out_dev).  When this package owns the
-        output's allocation and the plan has lanes, the call is issued with a deferred join
+        output's allocation the call is issued with a deferred join (plans with lanes leave the
+        lanes running; one-kernel plans run on a stream of their own beside the caller's)
         (`DEFER_JOIN`): its completion event is left with the output's allocation."""
         owner = out_dev.owner
         defer = DEFER_JOIN and owner.__class__ is _Allocation
@@ -754,10 +811,13 @@ class OsmPlan(_Plan):
         # caller's to keep untouched, as include/bbt_hip.h says.
         src_owner = in_dev.owner
         shared = src_owner.__class__ is _Allocation and src_owner is not owner
-        done = _Done(ev, 2 if shared else 1)
+        foreign = src_owner is not None and src_owner.__class__ is not _Allocation
+        done = _Done(ev, 2 if (shared or foreign) else 1)
         owner.owe(_Pending(done, (src_owner, self)), write=True)
         if shared:
             src_owner.owe(_Pending(done, (self,)), write=False)
+        elif foreign and not _owe_foreign_read(src_owner, _Pending(done, (self,))):
+            done.release()              # (an owner that cannot be weakly referenced: not tracked)
         out_dev.fresh = False           # (from now on the region IS owed a call)
 
     @staticmethod

@@ -722,6 +722,25 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     plan.execute(x, z, *desc)
     assert 'bbt_osm_plan_defer' not in [e[0] for e in fake.log[n0:]] and not z.pending
 
+    # a foreign INPUT (a torch tensor): the call is deferred, and the event is kept for
+    # `hip.wait_for_readers`, which whoever refills the tensor in place calls first
+    xin = hip.DeviceArray((2**20, 2), np.complex64, ptr=0x9000000, owner=Foreign())
+    y2 = hip.DeviceArray((1000, 2), np.complex64)
+    n0 = len(fake.log)
+    plan.execute(xin, y2, *desc)
+    ev2 = [e for e in fake.log[n0:] if e[0] == 'bbt_osm_plan_defer'][0][2]
+    assert y2.owner.writes[0].done.refs == 2
+    n0 = len(fake.log)
+    hip.wait_for_readers(xin.owner)
+    assert fake.log[n0:] == [('bbt_stream_wait_event', None, ev2)]
+    hip.wait_for_readers(xin)                            # (settled: nothing more to wait for)
+    assert len(fake.log) == n0 + 1 and y2.owner.writes[0].done.refs == 1
+    key = id(xin.owner)
+    del xin
+    assert key in hip._foreign_reads                     # (the owed output keeps its input alive)
+    del y2
+    assert key not in hip._foreign_reads                 # (the registry does not outlive the tensor)
+
     # a task's cache alternates while the previous run is owed, and stays put once it is not
     class Task(DeviceTaskMixin):
         sample_shape = (2,)
