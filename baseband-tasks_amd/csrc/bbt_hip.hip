@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,10 +20,12 @@
 #include "bbt_kernels.hpp"
 #include "gen_kernels.hpp"
 #include "big_kernels.hpp"
+#include "gen2_host.hpp"
+#include "rtc.hpp"
 
 using namespace bbt;
 
-#define BBT_VERSION 141
+#define BBT_VERSION 150
 
 // ---------------------------------------------------------------------------
 // errors
@@ -193,6 +196,13 @@ static bool factor_7smooth(int64_t n, GenGeo* g) {
     for (int r : fac) g->fac[g->nfac++] = r;
     return true;
 }
+static int rtc_mode() {                     // 0 off, 1 on, 2 required
+    const char* e = getenv("BBT_RTC");
+    if (!e || !*e) return 1;
+    if (!strcmp(e, "0")) return 0;
+    if (!strcmp(e, "require")) return 2;
+    return 1;
+}
 static bool is_7smooth(int64_t n) {
     if (n < 1) return false;
     for (int r : {2, 3, 5, 7})
@@ -202,6 +212,17 @@ static bool is_7smooth(int64_t n) {
 // N = N1 * N2 with N1 <= N2 <= BBT_GEN_MAX_LEN: the largest N1 up to 512 (the column passes
 // then hold 8 columns of N1 points in their LDS tile: 128-byte runs), else as balanced as possible.
 static bool split_7smooth(int64_t n, int* n1, int* n2) {
+    if (const char* env = getenv("BBT_GEN_N1")) {            // (dev: force the split)
+        const int64_t d = atoll(env);
+        if (d > 1 && n % d == 0 && n / d <= BBT_GEN_MAX_LEN && d <= BBT_GEN_MAX_LEN) {
+            *n1 = (int)d;
+            *n2 = (int)(n / d);
+            return true;
+        }
+    }
+    // (plans on the run-time specialised kernels: the split rule measured for them; the column
+    // tile of the general kernels holds n1 * 8 <= 8192 elements, so n1 <= 1024 keeps the fall-back)
+    if (rtc_mode() && g2_choose_split(n, 8, 1024, BBT_GEN_MAX_LEN, n1, n2)) return true;
     const int64_t prefer = 512;
     int64_t best = 0, wide = 0;
     for (int64_t d = 1; d * d <= n; ++d)
@@ -292,6 +313,67 @@ static int make_big_twiddle(int64_t n, cf** lo, cf** hi) {
     return 0;
 }
 
+// ---- the register-resident engine for those lengths, specialised at plan time ---------------
+// (fft_gen2.hpp, gen2_kernels.hpp; compiled by rtc.hpp).  BBT_RTC=0: the LDS Stockham engine
+// above runs every such length (as in rounds 2-4); BBT_RTC=require: a failing compilation is an
+// error instead of a warning and a fall back to it.
+static std::mutex g_g2_mutex;
+static std::map<std::pair<int, std::string>, cf*> g_g2_tables;    // (device, stage list) -> tables
+static int64_t g_rtc_modules = 0;
+static double g_rtc_seconds = 0;
+static int get_g2_table(const G2Plan& g, cf** out) {
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    std::string key = std::to_string(g.n);
+    for (int s = 0; s < g.nfac; ++s) key += "," + std::to_string(g.fac[s]);
+    std::lock_guard<std::mutex> lock(g_g2_mutex);
+    auto it = g_g2_tables.find({dev, key});
+    if (it != g_g2_tables.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const std::vector<float> t = g2_tables(g);
+    cf* d;
+    HIP_TRY(hipMalloc((void**)&d, t.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    g_g2_tables[{dev, key}] = d;
+    *out = d;
+    return 0;
+}
+// source -> entry points.  0 = ok; 1 = not available (the caller falls back), with the reason in
+// g_err; in `require` mode that is the error of the call.
+static int g2_build(const std::string& source, const std::vector<const char*>& names, hipFunction_t* fns) {
+    RtcModule* m;
+    std::string log;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (rtc_module(source, &m, &log)) return fail("run-time compilation of a generic-length kernel failed: %s", log.c_str());
+    for (size_t i = 0; i < names.size(); ++i)
+        if (rtc_function(m, names[i], &fns[i], &log)) return fail("%s", log.c_str());
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+        std::lock_guard<std::mutex> lock(g_g2_mutex);
+        if (dt > 0.02) {                    // (a module that was compiled, not found in the process's cache)
+            g_rtc_modules += 1;
+            g_rtc_seconds += dt;
+        }
+    }
+    if (getenv("BBT_RTC_VERBOSE")) fprintf(stderr, "bbt: rtc %.2f s\n%s", dt, source.c_str());
+    return 0;
+}
+static void g2_warn_once(const char* what) {
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        fprintf(stderr, "baseband_tasks_amd: %s -- %s; lengths that are not powers of two run on the slower "
+                        "general kernels (BBT_RTC=require makes this an error)\n", what, g_err.c_str());
+    });
+}
+template <class... A>
+static int g2_launch(hipFunction_t f, dim3 grid, dim3 block, hipStream_t st, A... a) {
+    void* args[] = {(void*)&a...};
+    HIP_TRY(hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, st, args, nullptr));
+    return 0;
+}
+
 struct DevicePool {
     std::mutex mu;
     struct Idle {
@@ -325,6 +407,13 @@ extern "C" {
 
 const char* bbt_last_error(void) { return g_err.c_str(); }
 int bbt_version(void) { return BBT_VERSION; }
+int bbt_rtc_info(int* mode, int64_t* modules, double* seconds) {
+    std::lock_guard<std::mutex> lock(g_g2_mutex);
+    if (mode) *mode = rtc_mode();
+    if (modules) *modules = g_rtc_modules;
+    if (seconds) *seconds = g_rtc_seconds;
+    return 0;
+}
 
 int bbt_device_count(int* count) {
     ARG_TRY(count, "bbt_device_count: null argument");
@@ -698,6 +787,14 @@ struct bbt_osm_plan {
     cf* thi = nullptr;          // W_N^{4096 j}           (owned)
     cf* tws = nullptr;          // W_N^{k1 m r}, [n1][g2.fac[0]], m = n2 / g2.fac[0]   (owned)
     int gen_ct = 1;             // columns per tile of the column passes
+    // the same plan on the run-time specialised engine (gen2_kernels.hpp; null functions: not in use)
+    bool rtc = false;
+    G2Plan q1, q2, q2r;         // column transform (ct columns), row transform and its reversal
+    cf* qw1 = nullptr;          // their stage tables (shared)
+    cf* qw2 = nullptr;
+    cf* qw2r = nullptr;
+    hipFunction_t k2_small = nullptr, k2_first = nullptr, k2_row = nullptr, k2_last = nullptr;
+    int n2p = 0;                // pitch of a row of the work buffer: n2 rounded up to whole 128-byte lines
     // pair-planar hand-over (bbt_osm_plan_set_layout; OsmChunk::in_plane / out_plane)
     long long in_plane = 0, out_plane = 0;
     // fused channelizer
@@ -992,7 +1089,33 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
         pairs_view.nblk = (ch.nblk + 1) / 2;
     }
     const OsmChunk& chw = p->single ? pairs_view : ch;       // what the row / middle passes count
-    if (p->generic) {
+    if (p->generic && p->rtc) {
+        if (nch) return fail("osm: the fused channelizer needs a power-of-two block length");
+        if (p->n1 == 1) {
+            if (g2_launch(p->k2_small, dim3(ch.nblk * p->npair), dim3(p->q2.threads()), st, (const float2*)in, out, ch,
+                          p->S, (const cf*)p->resp, (const int*)p->resp_index, (const cf*)p->qw2, (const cf*)p->qw2r))
+                return 1;
+            if (timed) {
+                HIP_TRY(hipEventRecord(e[1], st));
+                HIP_TRY(hipEventRecord(e[2], st));
+            }
+        } else {
+            const int ct = p->gen_ct, tiles = (p->n2 + ct - 1) / ct;
+            const dim3 gcol((unsigned)tiles * p->npair * ch.nblk), bcol(p->q1.threads());
+            if (g2_launch(p->k2_first, gcol, bcol, st, (const float2*)in, out, work, ch, p->S, p->n2, p->n2p,
+                          (const cf*)p->qw1))
+                return 1;
+            if (timed) HIP_TRY(hipEventRecord(e[1], st));
+            if (g2_launch(p->k2_row, dim3(p->n1, ch.nblk * p->npair), dim3(p->q2.threads()), st, work, p->n1, p->n2p,
+                          (const cf*)p->resp, (const int*)p->resp_index, p->npair, (const cf*)p->qw2,
+                          (const cf*)p->qw2r, (const cf*)p->tlo, (const cf*)p->thi, (const cf*)p->tws))
+                return 1;
+            if (timed) HIP_TRY(hipEventRecord(e[2], st));
+            if (g2_launch(p->k2_last, gcol, bcol, st, (const float2*)in, out, work, ch, p->S, p->n2, p->n2p,
+                          (const cf*)p->qw1))
+                return 1;
+        }
+    } else if (p->generic) {
         if (nch) return fail("osm: the fused channelizer needs a power-of-two block length");
         if (p->n1 == 1) {
             const size_t lds = (size_t)p->n2 * sizeof(f4);
@@ -1351,11 +1474,54 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if (!factor_7smooth(p->n2, &p->g2) || (p->n1 > 1 && !factor_7smooth(p->n1, &p->g1)))
             return bail(fail("bbt_osm_plan_create: cannot factor %d x %d", p->n1, p->n2));
         if (get_gen_table(&p->g2, &p->wn2) || get_reversed(p->g2, &p->g2r, &p->wn2r)) return bail(1);
+        // columns per tile: a power of two (gen_stage), as many as fit the LDS tile up to 8
+        // (128-byte runs of the stream and of the work buffer; measured: 8 columns 18.9, 16
+        // columns 18.1, 4 columns 17.3 Gsamples/s for the 1 666 980-sample block)
+        p->gen_ct = 1;
+        if (p->n1 > 1) {
+            const int ct_cap = getenv("BBT_GEN_CT") ? atoi(getenv("BBT_GEN_CT")) : 8;         // (dev)
+            while (p->gen_ct < ct_cap && 2 * p->gen_ct * p->n1 <= 2 * BBT_GEN_MAX_LEN) p->gen_ct *= 2;
+        }
+        // The kernels specialised on this length (fft_gen2.hpp), compiled now; if that is not
+        // possible the plan runs on the general ones.
+        if (rtc_mode()) {
+            bool ok = g2_plan(p->n2, 1, &p->q2);
+            if (ok) p->q2r = g2_reversed(p->q2);
+            if (ok && p->n1 > 1) ok = g2_plan(p->n1, p->gen_ct, &p->q1);
+            if (!ok) fail("no stage list for %d x %d", p->n1, p->n2);
+            if (ok) {
+                std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", p->q2) +
+                                  g2_trait_source("GB", p->q2r);
+                // (workgroups of 7 waves or more: at most 128 registers, two of them per CU)
+                const std::string w2 = p->q2.threads() >= 448 ? "4" : "0";
+                if (p->n1 == 1) {
+                    src += "BBT_G2_KERNEL_OSM_SMALL(k_small, GA, GB, " + w2 + ")\n";
+                    ok = !g2_build(src, {"k_small"}, &p->k2_small);
+                } else {
+                    const std::string w1 = p->q1.threads() >= 448 ? "4" : "0";
+                    src += g2_trait_source("GC", p->q1) + "BBT_G2_KERNEL_ROW(k_row, GA, GB, " + w2 + ")\n"
+                           "BBT_G2_KERNEL_COL(k_first, GC, true, " + w1 + ")\nBBT_G2_KERNEL_COL(k_last, GC, false, " + w1 + ")\n";
+                    hipFunction_t f[3];
+                    ok = !g2_build(src, {"k_row", "k_first", "k_last"}, f);
+                    if (ok) {
+                        p->k2_row = f[0];
+                        p->k2_first = f[1];
+                        p->k2_last = f[2];
+                    }
+                }
+            }
+            if (ok) ok = !(get_g2_table(p->q2, &p->qw2) || get_g2_table(p->q2r, &p->qw2r) ||
+                           (p->n1 > 1 && get_g2_table(p->q1, &p->qw1)));
+            if (!ok && rtc_mode() == 2) return bail(1);
+            if (!ok) g2_warn_once("bbt_osm_plan_create");
+            p->rtc = ok;
+        }
         if (p->n1 > 1) {
             if (get_gen_table(&p->g1, &p->wn1) || make_big_twiddle(n_fft, &p->tlo, &p->thi))
                 return bail(1);
-            {   // the uniform factors of the row kernel's four-step twiddles (GenRowSrc)
-                const int r0 = p->g2.fac[0];
+            {   // the uniform factors of the row kernel's four-step twiddles (GenRowSrc): the first
+                // forward and the last inverse stage have radix r0
+                const int r0 = p->rtc ? p->q2.fac[0] : p->g2.fac[0];
                 const long long m = p->n2 / r0;
                 std::vector<cf> t((size_t)p->n1 * r0);
                 for (int k1 = 0; k1 < p->n1; ++k1)
@@ -1363,12 +1529,6 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
                         t[(size_t)k1 * r0 + r] = unit_root((long long)k1 * m % n_fft * r, n_fft);
                 if (upload(&p->tws, t)) return bail(1);
             }
-            // columns per tile: a power of two (gen_stage), as many as fit the LDS tile up to 8
-            // (128-byte runs of the stream and of the work buffer; measured: 8 columns 18.9, 16
-            // columns 18.1, 4 columns 17.3 Gsamples/s for the 1 666 980-sample block)
-            const int ct_cap = 8;
-            p->gen_ct = 1;
-            while (p->gen_ct < ct_cap && 2 * p->gen_ct * p->n1 <= BBT_GEN_MAX_LEN) p->gen_ct *= 2;
         }
     } else {
         if (p->n2 > 4096) {
@@ -1456,7 +1616,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     if (const char* env = getenv("BBT_OSM_LANES")) lanes = atoi(env);
     lanes = lanes < 1 ? 1 : (lanes > BBT_MAX_LANES ? BBT_MAX_LANES : lanes);
     if (const char* env = getenv("BBT_OSM_TIMING_STRIDE")) p->timing_stride = std::max(1, atoi(env));
-    const size_t per_block = (size_t)p->npair * n_fft * 16;
+    // (plans on the specialised generic kernels pad the rows of the work buffer to whole lines)
+    p->n2p = p->rtc ? (p->n2 + 7) / 8 * 8 : p->n2;
+    const size_t per_block = p->rtc ? (size_t)p->npair * p->n1 * p->n2p * 16 : (size_t)p->npair * n_fft * 16;
     int chunk = (int)((192u << 20) / per_block / lanes);
     if (const char* env = getenv("BBT_OSM_CHUNK")) chunk = atoi(env);
     if (chunk < 1) chunk = 1;
@@ -1915,6 +2077,11 @@ struct bbt_chan_plan {
     GenGeo g = {};
     cf* wn = nullptr;
     int ct = 1;                 // stream pairs per workgroup tile
+    // ... on the run-time specialised engine (gen2_kernels.hpp; null: not in use)
+    G2Plan q;                   // q.ct columns per workgroup: cp stream pairs of q.ct / cp transforms
+    int cp = 1;
+    cf* qw = nullptr;
+    hipFunction_t k2 = nullptr;
 };
 
 template <int N, int SIGN>
@@ -2059,6 +2226,45 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
                 p->ct = ct;
                 break;
             }
+        // The specialised kernels where they are ahead of the general ones (MI355X, round 5, one
+        // stream pair, Gsamples/s general -> specialised): short transforms, which fill their waves
+        // with several of them (14: 25 -> 73, 30: 44 -> 71), and transforms whose general kernel
+        // needs more than 512 threads (6174: 83 -> 106).  In between both stream at 4-5 TB/s and
+        // the general kernels' smaller register footprint wins (1000: 154 against 97-112, 1536:
+        // 152 against 119, 3000: 113 against 110).  BBT_G2_CHAN=all / none overrides.
+        const char* chan_env = getenv("BBT_G2_CHAN");
+        const bool want = chan_env ? !strcmp(chan_env, "all") : (n_chan < 256 || n_chan > 4096);
+        if (rtc_mode() && want && !(chan_env && !strcmp(chan_env, "none"))) {
+            // columns of a workgroup: as many neighbouring pairs as divide the pair count (up to 8:
+            // 128-byte pieces of a complete sample), then consecutive transforms until the
+            // workgroup has 256 threads
+            G2Plan probe;
+            bool ok = g2_plan(n_chan, 1, &probe);
+            if (!ok) fail("no stage list for %d", n_chan);
+            if (ok) {
+                int cp = 1;
+                while (cp < 8 && p->npair % (2 * cp) == 0 && probe.tj * 2 * cp <= 256) cp *= 2;
+                int ct = cp;
+                const int ct_cap = getenv("BBT_G2_CHAN_CT") ? atoi(getenv("BBT_G2_CHAN_CT")) : 256;      // (dev)
+                while (2 * ct <= ct_cap && probe.tj * 2 * ct <= 256 && (int64_t)n_chan * 2 * ct * 8 <= 64 * 1024) ct *= 2;
+                p->cp = cp;
+                ok = g2_plan(n_chan, ct, &p->q);
+            }
+            if (ok) {
+                const std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", p->q) +
+                                        "BBT_G2_KERNEL_FFT_ROWS(k_rows, GA, " + (direction < 0 ? "-1" : "+1") +
+                                        (p->q.threads() >= 448 ? ", 4)\n" : ", 0)\n");
+                ok = !g2_build(src, {"k_rows"}, &p->k2) && !get_g2_table(p->q, &p->qw);
+            }
+            if (!ok && rtc_mode() == 2) {
+                delete p;
+                return 1;
+            }
+            if (!ok) {
+                g2_warn_once("bbt_chan_plan_create");
+                p->k2 = nullptr;
+            }
+        }
     } else if ((n_chan >= 256 && get_tables(n_chan, &p->tab)) ||
                (n_chan < 256 && get_wroot(&p->wroot))) {
         delete p;
@@ -2109,6 +2315,14 @@ int bbt_chan_execute(bbt_chan_plan* p, const void* in_dev, void* out_dev, int64_
     for (int64_t s0 = 0; s0 < n_spectra; s0 += slab) {
         const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
         const int64_t off = s0 * p->n * p->S;
+        if (p->generic && p->k2) {
+            const int bt = p->q.ct / p->cp;
+            const dim3 grid((unsigned)(((ns + bt - 1) / bt) * (p->npair / p->cp))), block(p->q.threads());
+            if (g2_launch(p->k2, grid, block, (hipStream_t)stream, in + off, out + off, p->S, p->cp, (long long)ns,
+                          p->dir < 0 ? 1.0f : 1.0f / (float)p->n, (const cf*)p->qw))
+                return 1;
+            continue;
+        }
         if (p->generic) {
             const size_t lds = (size_t)p->n * p->ct * sizeof(f4);
             const dim3 grid((unsigned)(ns * (p->npair / p->ct))), block(gen_threads(p->n * p->ct));

@@ -29,7 +29,9 @@
 // No MFMA: this is butterfly arithmetic at ~6 flop/byte of on-chip data
 // (DESIGN.md).
 #pragma once
+#if !defined(__HIPCC_RTC__)          // (hipRTC provides the runtime's declarations itself)
 #include <hip/hip_runtime.h>
+#endif
 
 namespace bbt {
 
@@ -55,6 +57,50 @@ __device__ __forceinline__ c2 cmul2(c2 a, c2 h) {
 }
 __device__ __forceinline__ cf cmul(cf a, cf b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// The same two products for operands that live in VECTOR registers (table twiddles), written with
+// the operand selectors of the packed instructions: a v_pk_* whose scalar factor is the same in
+// both lanes takes it from one half of a register pair (op_sel / op_sel_hi), so the twiddle is
+// used as loaded.  The compiler does not form these: it copies w.x and w.y into pairs first (two
+// v_mov per product, 8 % of the instructions of a generic-length row pass).  Constants (SGPRs,
+// literals) stay with twmul / cmul.
+#ifndef BBT_OPSEL
+#define BBT_OPSEL 1
+#endif
+template <int SIGN>
+__device__ __forceinline__ c2 twmul_v(c2 a, cf w) {
+#if BBT_OPSEL
+    const v2 wv = {w.x, w.y};
+    v2 t1, t2, re, im;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t1) : "v"(a.im), "v"(wv));          // im * w.y
+    if (SIGN < 0) {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=v"(re) : "v"(a.re), "v"(wv), "v"(t1));                                                    // re * w.x - t1
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t2) : "v"(a.im), "v"(wv));                   // im * w.x
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+            : "=v"(im) : "v"(a.re), "v"(wv), "v"(t2));                                                    // re * w.y + t2
+    } else {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(re) : "v"(a.re), "v"(wv), "v"(t1));    // re * w.x + t1
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t2) : "v"(a.re), "v"(wv));      // re * w.y
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=v"(im) : "v"(a.im), "v"(wv), "v"(t2));                                                    // im * w.x - t2
+    }
+    return c2{re, im};
+#else
+    return twmul<SIGN>(a, w);
+#endif
+}
+// a * b of two table values as two packed instructions: (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+__device__ __forceinline__ cf cmul_v(cf a, cf b) {
+#if BBT_OPSEL
+    const v2 av = {a.x, a.y}, bv = {b.x, b.y};
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(av), "v"(bv));   // (-a.y b.y, a.y b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));               // a.x (b.x, b.y) + t
+    return make_float2(r.x, r.y);
+#else
+    return cmul(a, b);
+#endif
 }
 __device__ __forceinline__ c2 splat(cf w) { return c2{v2{w.x, w.x}, v2{w.y, w.y}}; }
 __device__ __forceinline__ c2 czero() { return c2{v2{0.f, 0.f}, v2{0.f, 0.f}}; }

@@ -32,7 +32,9 @@
 // so neighbouring lanes read neighbouring entries), evaluated in double on the host.  Butterflies for 2, 4, 8 are those of fft_core.hpp; 3, 5
 // and 7 use the symmetric form (pairs v[k] +- v[p-k], real coefficient sums).
 #pragma once
+#if !defined(__HIPCC_RTC__)          // (hipRTC provides the runtime's declarations itself)
 #include <hip/hip_runtime.h>
+#endif
 #include "fft_core.hpp"
 
 namespace bbt {

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "bbt_kernels.hpp"
 #include "fft_generic.hpp"
+#include "gen_functors.hpp"
 
 namespace bbt {
 
@@ -25,88 +26,6 @@ namespace bbt {
 // nothing else to hide that latency with).
 #define BBT_GEN_FOR(e, idx, total) \
     _Pragma("unroll") for (int e = 0, idx = tid; e < BBT_GEN_EPT; ++e, idx += nthr)
-
-__device__ __forceinline__ f4 ld_ext_f4(const float2* p) {
-    const float4 x = *reinterpret_cast<const float4*>(p);
-    return f4{x.x, x.z, x.y, x.w};
-}
-__device__ __forceinline__ void st_ext_f4(float2* p, f4 a) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.x, a.z, a.y, a.w);
-}
-__device__ __forceinline__ f4 f4_mul_resp(f4 a, cf x, cf y) {     // stream A times x, stream B times y
-    return f4{a.x * x.x - a.z * x.y, a.y * y.x - a.w * y.y, a.x * x.y + a.z * x.x, a.y * y.y + a.w * y.x};
-}
-__device__ __forceinline__ f4 f4_twmul(f4 a, cf w) { return f4_mul_resp(a, w, w); }
-
-// ---- sources, multipliers and sinks of the open-ended transforms (fft_generic.hpp) ----------
-// elements i = j + r m of one column of stream pairs, m apart
-
-// rows of a (n, S) stream: element i at base[i * stride] (stride in float2 units), external format
-struct GenStreamSrc {
-    const float2* base;
-    long long stride;
-    bool live;                           // (a column past the edge of the last tile reads zeros)
-    template <int R>
-    __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            v[r] = live ? f4_to_c2(ld_ext_f4(base + (long long)(j + r * m) * stride)) : czero();
-    }
-};
-// the same for the work buffer (internal format, f4 units)
-struct GenWorkSrc {
-    const f4* base;
-    long long stride;
-    bool live;
-    template <int R>
-    __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = live ? f4_to_c2(base[(long long)(j + r * m) * stride]) : czero();
-    }
-};
-struct GenWorkDst {
-    f4* base;
-    long long stride;
-    bool live;
-    template <int R>
-    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
-        if (!live) return;
-#pragma unroll
-        for (int r = 0; r < R; ++r) base[(long long)(j + r * m) * stride] = c2_to_f4(v[r]);
-    }
-};
-// kept samples of an overlap-save block: element i of the block goes to output row i - valid_start
-struct GenValidDst {
-    float2* out;                         // out + (out_off * S + 2 sp), external format
-    long long stride;                    // S
-    long long first, step;               // block sample of element i: first + i * step
-    int valid_start, valid_count;
-    bool live;
-    template <int R>
-    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
-        if (!live) return;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const long long q = first + (long long)(j + r * m) * step - valid_start;
-            if (q >= 0 && q < valid_count) st_ext_f4(out + q * stride, c2_to_f4(v[r]));
-        }
-    }
-};
-// spectral multiply: element i times the response columns of the pair's two streams
-struct GenRespMul {
-    const cf* h0;
-    const cf* h1;
-    bool same;
-    template <int R>
-    __device__ __forceinline__ void apply(int j, int m, c2 (&v)[R]) const {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const cf x = h0[j + r * m];
-            const cf y = same ? x : h1[j + r * m];
-            v[r] = cmul2(v[r], c2{v2{x.x, y.x}, v2{x.y, y.y}});
-        }
-    }
-};
 
 // One workgroup per (block, pair): n = g.n <= 8192 elements of dynamic LDS.
 //   g / gr: the stages and their reversal (forward and inverse transform), wn / wnr their tables
@@ -156,42 +75,7 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_col(const float2* _
     }
 }
 
-// Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair).
-//   resp  : [C][N1][N2] = H[c][k1 + N1 k2] / N
-//   g / gr, wn / wnr: stages of the N2-point transform and their reversal;  tlo / thi : W_N^m
-// The four-step twiddles W_N^{k1 i} of a butterfly's elements i = j + r m are a s_r with
-// a = W_N^{k1 j} (one look-up per butterfly) and s_r = W_N^{k1 m r}, the same for the whole
-// workgroup: a row of a small table made in double at plan creation (srow[r], r < R: scalar
-// loads; forming them as powers of s_1 cost R - 2 complex products per butterfly and three
-// more roundings).  Folded into the source and, conjugated, into the sink.
-struct GenRowSrc {
-    const f4* row;
-    const cf* tlo;
-    const cf* thi;
-    const cf* srow;
-    int k1;
-    template <int R>
-    __device__ __forceinline__ void load(int j, int m, c2 (&v)[R]) const {
-        const cf a = big_twiddle(tlo, thi, k1 * j);
-        v[0] = twmul<-1>(f4_to_c2(row[j]), a);
-#pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = twmul<-1>(f4_to_c2(row[j + r * m]), cmul(a, srow[r]));
-    }
-};
-struct GenRowDst {
-    f4* row;
-    const cf* tlo;
-    const cf* thi;
-    const cf* srow;
-    int k1;
-    template <int R>
-    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
-        const cf a = big_twiddle(tlo, thi, k1 * j);
-        row[j] = c2_to_f4(twmul<+1>(v[0], a));
-#pragma unroll
-        for (int r = 1; r < R; ++r) row[j + r * m] = c2_to_f4(twmul<+1>(v[r], cmul(a, srow[r])));
-    }
-};
+// Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair); sources and sinks: gen_functors.hpp
 __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restrict__ work, int N1,
                                                   const cf* __restrict__ resp,
                                                   const int* __restrict__ resp_index, int npair,
@@ -217,17 +101,6 @@ __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_row(float2* __restr
 // Batched transforms over contiguous groups of n = g.n complete samples, for a
 // tile of `ct` stream pairs (ct * 16 contiguous bytes per complete sample).
 //   grid (n_fft * (npair / ct))
-struct GenScaledDst {
-    float2* base;
-    long long stride;
-    float scale;
-    template <int R>
-    __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            st_ext_f4(base + (long long)(j + r * m) * stride, c2_to_f4(v[r]) * scale);
-    }
-};
 template <int SIGN>
 __global__ __launch_bounds__(BBT_GEN_MAX_THREADS) void k_gen_fft_rows(const float2* __restrict__ in,
                                                        float2* __restrict__ out, int S, int ct,

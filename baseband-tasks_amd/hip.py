@@ -36,6 +36,7 @@ _pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
 # name -> argtypes ; every entry point declared in include/bbt_hip.h
 SIGNATURES = {
     'bbt_version': [],
+    'bbt_rtc_info': [C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
     'bbt_device_count': [C.POINTER(_int)],
     'bbt_set_device': [_int],
     'bbt_get_device': [C.POINTER(_int)],
@@ -111,7 +112,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 141
+MIN_LIB_VERSION = 150
 
 _lib = None
 _lock = threading.Lock()
@@ -162,6 +163,7 @@ def lib():
                 # initialised yet; an explicit setting wins.
                 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
                 _preload_torch_runtime()
+                _preload_torch_runtime('libhiprtc.so')     # (csrc/rtc.hpp opens it by soname)
                 if not os.path.exists(LIB_PATH):
                     raise HipLibraryMissing(
                         f"{LIB_PATH} not found: build it with "
@@ -209,6 +211,14 @@ def get_device():
     index = _int(0)
     check(lib().bbt_get_device(C.byref(index)))
     return index.value
+
+
+def rtc_info():
+    """Run-time specialisation of the kernels for lengths that are not powers of two
+    (include/bbt_hip.h: bbt_rtc_info): dict(mode, modules, seconds)."""
+    mode, modules, seconds = _int(0), _i64(0), C.c_double(0)
+    check(lib().bbt_rtc_info(C.byref(mode), C.byref(modules), C.byref(seconds)))
+    return dict(mode=('off', 'on', 'required')[mode.value], modules=modules.value, seconds=seconds.value)
 
 
 def device_name():

@@ -50,6 +50,14 @@ typedef struct bbt_comm bbt_comm;
 const char* bbt_last_error(void);
 int bbt_version(void);
 int bbt_device_count(int* count);
+/* Lengths that are not powers of two -- the block and channel counts the reference's own FFT
+ * engine picks by default, next_fast_len: baseband_tasks/fourier/numpy.py:99-126, block rule
+ * base.py:750-758 -- run on kernels specialised on that length when the plan is made (hipRTC,
+ * csrc/rtc.hpp; as rocFFT builds its kernels).  mode: 0 off (BBT_RTC=0: the general kernels run
+ * every length), 1 on with a fall back to them, 2 required (BBT_RTC=require); modules: code
+ * objects compiled by this process so far, seconds: the time that took.  BBT_RTC_CACHE=<dir> keeps
+ * them on disk, BBT_CSRC=<dir> says where the kernel headers are if not next to the library. */
+int bbt_rtc_info(int* mode, int64_t* modules, double* seconds);
 int bbt_set_device(int device);
 int bbt_get_device(int* device);
 int bbt_device_name(char* buf, int buflen);

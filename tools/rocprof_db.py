@@ -19,6 +19,9 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r'bbt::(k_\w+(?:<[^>]*>)?)', name)
+    if m:
+        return m.group(1)
+    m = re.match(r'(k_\w+)', name)           # (the run-time compiled kernels are extern "C")
     return m.group(1) if m else None
 
 
