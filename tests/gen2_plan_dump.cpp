@@ -1,0 +1,53 @@
+// Prints what the host planner of the generic-length engine (csrc/gen2_host.hpp) decides, as
+// JSON lines, for tests/test_gen2_planner.py:   gen2_plan_dump plan <n> <ct> ... | split <N> ...
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "gen2_host.hpp"
+using namespace bbt;
+
+static void dump(const G2Plan& g) {
+    printf("{\"n\": %d, \"tj\": %d, \"ct\": %d, \"threads\": %d, \"slots\": %d, \"lds_elems\": %d, \"table_len\": %d, \"fac\": [",
+           g.n, g.tj, g.ct, g.threads(), g.slots, g.lds_elems, g.table_len);
+    for (int s = 0; s < g.nfac; ++s) printf("%s%d", s ? ", " : "", g.fac[s]);
+    printf("], \"pitch\": [");
+    for (int s = 0; s < g.nfac; ++s) printf("%s%d", s ? ", " : "", g.pitch[s]);
+    printf("], \"woff\": [");
+    for (int s = 0; s < g.nfac; ++s) printf("%s%d", s ? ", " : "", g.woff[s]);
+    printf("]}");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    if (!strcmp(argv[1], "plan")) {
+        for (int i = 2; i + 1 < argc; i += 2) {
+            G2Plan g;
+            if (!g2_plan(atoi(argv[i]), atoi(argv[i + 1]), &g)) { printf("null\n"); continue; }
+            printf("{\"forward\": ");
+            dump(g);
+            printf(", \"reversed\": ");
+            dump(g2_reversed(g));
+            printf(", \"source\": \"%s\"}\n", "ok");
+        }
+    } else if (!strcmp(argv[1], "split")) {
+        for (int i = 2; i < argc; ++i) {
+            int n1 = 0, n2 = 0;
+            if (!g2_choose_split(atoll(argv[i]), 8, 1024, 8192, &n1, &n2)) { printf("null\n"); continue; }
+            G2Plan c, r;
+            g2_plan(n1, 8, &c);
+            g2_plan(n2, 1, &r);
+            printf("{\"n1\": %d, \"n2\": %d, \"col\": ", n1, n2);
+            dump(c);
+            printf(", \"row\": ");
+            dump(r);
+            printf("}\n");
+        }
+    } else if (!strcmp(argv[1], "source")) {
+        G2Plan g;
+        if (!g2_plan(atoi(argv[2]), 1, &g)) return 1;
+        const G2Plan gr = g2_reversed(g);
+        printf("#include \"gen2_kernels.hpp\"\n%s%sBBT_G2_KERNEL_OSM_SMALL(k_small, GA, GB, 0)\nBBT_G2_KERNEL_FFT_ROWS(k_rows, GA, -1, 0)\n",
+               g2_trait_source("GA", g).c_str(), g2_trait_source("GB", gr).c_str());
+    }
+    return 0;
+}

@@ -1,0 +1,125 @@
+"""The generic-length engine without a GPU: what its host planner decides (csrc/gen2_host.hpp),
+that the index maps of those plans give the transform (the model of tools/fft_gen2_model.py
+follows every value through them and compares with numpy.fft), and that the kernel source the
+library writes for a length compiles through hipRTC for gfx950 (csrc/rtc.hpp's path: the
+compiler needs no device).  The lengths are the reference's default block lengths -- the
+smallest 2^a 3^b 5^c 7^d >= n of its NumPy engine, baseband_tasks/fourier/numpy.py:99-126 -- and
+the ones its tests use (6174: tests/test_base.py:522-529)."""
+import ctypes as C
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'baseband-tasks_amd', 'csrc')
+
+
+@pytest.fixture(scope='module')
+def dump(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp('gen2') / 'gen2_plan_dump')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-I', CSRC, os.path.join(ROOT, 'tests', 'gen2_plan_dump.cpp'),
+                           '-o', exe])
+
+    def run(*args):
+        out = subprocess.check_output([exe] + [str(a) for a in args], text=True)
+        return [json.loads(line) for line in out.splitlines()]
+    run.exe = exe
+    return run
+
+
+def model():
+    spec = importlib.util.spec_from_file_location('fft_gen2_model', os.path.join(ROOT, 'tools', 'fft_gen2_model.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+LENGTHS = [2, 3, 14, 30, 100, 490, 540, 1000, 1536, 3000, 3087, 3402, 3430, 6174, 6561, 8100, 8192, 3125, 2401]
+
+
+def test_plans_of_the_host_planner_transform_correctly(dump):
+    """Every plan: the stage list multiplies to n, no stage asks a thread for more than its
+    registers hold, the exchange area holds every buffer -- and the model, fed the plan's stages,
+    threads and pitches, reproduces numpy.fft (forward on the plan, inverse on its reversal)."""
+    m = model()
+    args = []
+    for n in LENGTHS:
+        args += [n, 1]
+    args += [490, 8, 486, 8, 30, 4]
+    for plans in dump('plan', *args):
+        for key, sign in (('forward', -1), ('reversed', +1)):
+            g = plans[key]
+            n, fac, tj = g['n'], g['fac'], g['tj']
+            assert int(np.prod(fac)) == n and all(2 <= r <= 16 for r in fac) or n == 1
+            assert g['threads'] % 64 == 0 and g['threads'] >= tj * g['ct']
+            ns, need = 1, 0
+            for s, r in enumerate(fac):
+                b = -(-(n // r) // tj)
+                assert b <= 4 and b * r <= 20, (n, fac, tj)          # (BBT_G2_MAXB, BBT_G2_PMAX)
+                assert g['slots'] >= b * r
+                assert g['pitch'][s] >= ns * r
+                if s + 1 < len(fac):
+                    need = max(need, (n // (ns * r)) * g['pitch'][s])
+                ns *= r
+            assert g['lds_elems'] >= need * g['ct']
+            if n <= 3500:                                            # (the model is plain Python)
+                m.run(n, fac=fac, sign=sign, tj=tj, pitches=g['pitch'][:len(fac) - 1], verbose=False)
+        assert plans['forward']['fac'] == plans['reversed']['fac'][::-1]
+        assert plans['forward']['tj'] == plans['reversed']['tj']
+        assert plans['forward']['slots'] == plans['reversed']['slots']
+
+
+def test_the_model_and_the_planner_agree_on_stages_and_threads(dump):
+    m = model()
+    for n, plans in zip(LENGTHS, dump('plan', *sum(([n, 1] for n in LENGTHS), []))):
+        fac = m.factorise(n)
+        assert len(fac) == len(plans['forward']['fac'])
+        assert m.threads(n, fac) == plans['forward']['tj'], n
+
+
+def test_split_rule_prefers_workgroups_that_pack_a_cu(dump):
+    """The reference's default blocks at 800 / 600 MHz and for Resample: both kernels of
+    the chosen split have 1, 2, 4 or 8 waves (measured: 29.5 -> 34-35.7 Gsamples/s at 800 MHz)."""
+    for n, got in zip((1666980, 3936600, 1049760, 93312), dump('split', 1666980, 3936600, 1049760, 93312)):
+        assert got['n1'] * got['n2'] == n and got['n2'] <= 8192 and got['n1'] <= 1024
+        for k in ('col', 'row'):
+            assert got[k]['threads'] // 64 in (1, 2, 4, 8), (n, got[k])
+    assert dump('split', 11059200) == [None]         # (N2 <= 8192 needs N1 >= 1350: the general rule takes over)
+
+
+def _hiprtc():
+    for name in ('libhiprtc.so.7', 'libhiprtc.so', '/opt/rocm/lib/libhiprtc.so'):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    return None
+
+
+def test_generated_source_compiles_through_hiprtc(dump):
+    """What csrc/rtc.hpp does at plan time, without a device: source for one length -> hipRTC with
+    the library's options -> a code object for gfx950 that holds both entry points."""
+    rtc = _hiprtc()
+    if rtc is None:
+        pytest.skip('libhiprtc.so not found')
+    src = subprocess.check_output([dump.exe, 'source', '6174'], text=True).encode()
+    prog = C.c_void_p()
+    assert rtc.hiprtcCreateProgram(C.byref(prog), src, b'bbt_g2.hip', 0, None, None) == 0
+    opts = [b'--offload-arch=gfx950', b'-I' + CSRC.encode(), b'-O3', b'-std=c++17', b'-Wno-unused-value',
+            b'-mllvm', b'-simplifycfg-sink-common=false']
+    rc = rtc.hiprtcCompileProgram(prog, len(opts), (C.c_char_p * len(opts))(*opts))
+    n = C.c_size_t()
+    rtc.hiprtcGetProgramLogSize(prog, C.byref(n))
+    log = C.create_string_buffer(n.value + 1)
+    rtc.hiprtcGetProgramLog(prog, log)
+    assert rc == 0, log.value.decode(errors='replace')[-2000:]
+    assert rtc.hiprtcGetCodeSize(prog, C.byref(n)) == 0 and n.value > 10000
+    code = C.create_string_buffer(n.value)
+    assert rtc.hiprtcGetCode(prog, code) == 0
+    assert b'k_small' in code.raw and b'k_rows' in code.raw
+    rtc.hiprtcDestroyProgram(C.byref(prog))

@@ -6,6 +6,8 @@ Tolerances (float32 arithmetic against a float64-FFT
 oracle):  relative L2 <= 1e-6  and  max|delta| <= 1e-5 * rms(oracle).
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -18,6 +20,7 @@ from conftest import rel_l2, max_over_rms
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REL_L2_TOL = 1e-6
 MAX_TOL = 1e-5
 T0 = '2020-01-01T00:00:00'
@@ -400,6 +403,83 @@ def test_block_lengths_that_are_not_powers_of_two(n_fft):
                               ih_samples_per_frame=1000)
     assert info['ih_spf'] == n_fft
     assert_parity(got, want, f'n_fft {n_fft}')
+
+
+def test_lengths_that_are_not_powers_of_two_run_on_kernels_compiled_for_them():
+    """The default path for such lengths: kernels specialised on the length when the plan is made
+    (csrc/rtc.hpp; include/bbt_hip.h: bbt_rtc_info).  A length this process has not met yet costs
+    one compilation, a second plan of the same length none; the result is the oracle's."""
+    info = bt.hip.rtc_info()
+    if info['mode'] == 'off':
+        pytest.skip('BBT_RTC=0: the general kernels run every length')
+    n_fft, n_tap = 2 * 3 * 5 * 7 * 7 * 3, 1470              # 4410: in no other test (more than 513 taps: no short-block plan)
+    rng = np.random.default_rng(4410)
+    resp = ((rng.standard_normal((n_tap, 1)) + 1j * rng.standard_normal((n_tap, 1))) / np.sqrt(n_tap)).astype(np.complex64)
+    x = rng.standard_normal((3 * n_fft, 4), dtype=np.float32).view(np.complex64)
+    limit = bt.Convolve.FIR_MAX_TAPS_COMPLEX
+    bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0
+    try:
+        got = []
+        for _ in range(2):
+            cv = bt.Convolve(bt.DeviceStream(x, T0, 1 * u.MHz), resp, samples_per_frame=n_fft - n_tap + 1)
+            assert cv._ih_samples_per_frame == n_fft
+            got.append(cv.read())
+            after = bt.hip.rtc_info()
+            if len(got) == 1:
+                assert after['modules'] == info['modules'] + 1 and after['seconds'] > info['seconds']
+                first = after
+            else:
+                assert after['modules'] == first['modules']          # (cached: the same source text)
+    finally:
+        bt.Convolve.FIR_MAX_TAPS_COMPLEX = limit
+    want, _ = orc.convolve(x, resp, samples_per_frame=n_fft - n_tap + 1, ih_samples_per_frame=1000)
+    assert_parity(got[0], want, 'n_fft 4410, specialised kernels')
+    assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize('mode', ['0', 'require'])
+def test_general_and_specialised_kernels_agree_with_the_oracle(mode):
+    """BBT_RTC=0 keeps every such length on the general kernels (the fall-back when hipRTC is not
+    available), BBT_RTC=require makes a failing compilation an error: one child process each runs
+    one-kernel and two-level blocks, several streams, and channel counts either side of the
+    engines' ranges, against the oracle."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import baseband_tasks_amd as bt
+from baseband_tasks_amd import units as u
+from oracle import bbt_oracle as orc
+assert bt.hip.rtc_info()['mode'] == %r
+worst = 0.
+def check(got, want):
+    global worst
+    err = np.linalg.norm((got - want).ravel()) / np.linalg.norm(want.ravel())
+    assert err < 1e-6, err
+    worst = max(worst, err)
+bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0
+for n_fft, n_stream in ((630, 2), (6174, 4), (25725, 2), (131250, 6)):
+    n_tap = max(2, min(n_fft // 3, 5000))
+    rng = np.random.default_rng(n_fft)
+    resp = ((rng.standard_normal((n_tap, n_stream)) + 1j * rng.standard_normal((n_tap, n_stream))) / np.sqrt(n_tap)).astype(np.complex64)
+    x = rng.standard_normal((2 * n_fft + 77, 2 * n_stream), dtype=np.float32).view(np.complex64)
+    cv = bt.Convolve(bt.DeviceStream(x, '2020-01-01T00:00:00', 1 * u.MHz), resp, samples_per_frame=n_fft - n_tap + 1)
+    assert cv._ih_samples_per_frame == n_fft
+    want, _ = orc.convolve(x, resp, samples_per_frame=n_fft - n_tap + 1, ih_samples_per_frame=1000)
+    check(cv.read(), want)
+for n, n_stream in ((6, 2), (30, 2), (14, 6), (1000, 2), (6174, 2), (5000, 4)):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((37 * n, 2 * n_stream), dtype=np.float32).view(np.complex64)
+    ch = bt.Channelize(bt.DeviceStream(x, '2020-01-01T00:00:00', 1 * u.MHz), n)
+    z = ch.read()
+    check(z, orc.channelize(x, n))
+    check(bt.Dechannelize(bt.DeviceStream(z, '2020-01-01T00:00:00', 1 * u.MHz / n), n).read(), x)
+print('worst rel-L2 %%.2e, modules %%d' %% (worst, bt.hip.rtc_info()['modules']))
+""" % (ROOT, {'0': 'off', 'require': 'required'}[mode])
+    env = dict(os.environ, BBT_RTC=mode)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    modules = int(out.stdout.split()[-1])
+    assert (modules == 0) if mode == '0' else (modules >= 8), out.stdout
 
 
 def test_config5_at_the_references_default_block():

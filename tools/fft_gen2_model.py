@@ -20,12 +20,13 @@ import sys
 
 import numpy as np
 
-PMAX = 20
+PMAX = 20           # points a thread holds at most (BBT_G2_PMAX)
+MAXB = 4            # butterflies per thread and stage at most (BBT_G2_MAXB)
 RADICES = (16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2)
 
 
 def maxb(r):
-    return max(1, PMAX // r)
+    return min(MAXB, max(1, PMAX // r))
 
 
 def factorise(n):
@@ -56,15 +57,17 @@ def conflicts(addresses):
     return max(len(v) for v in banks.values())
 
 
-def choose_pitches(n, fac, tj, ct=1):
-    """Pitch of the buffer after stage s: rows of Ns R; the smallest pad (<= 8) with the fewest
-    passes for the writes of the first 32 lanes (lanes: column fastest, then butterfly)."""
+def choose_pitches(n, fac, tj, ct=1, pad_max=0):
+    """Pitch of the buffer after stage s: rows of Ns R plus the pad (<= pad_max) with the fewest
+    passes for the writes of the first 32 lanes (lanes: column fastest, then butterfly).  The
+    library pads nothing by default (gen2_host.hpp: measured, padding buys no time and costs
+    occupancy)."""
     ns, pitches = 1, []
     for s, r in enumerate(fac[:-1]):
         row = ns * r
         rows = n // row
         best = None
-        for pad in range(0, 9 if rows > 1 else 1):
+        for pad in range(0, pad_max + 1 if rows > 1 else 1):
             p = row + pad
             worst = 0
             for r_el in (0, r - 1):
@@ -82,11 +85,13 @@ def choose_pitches(n, fac, tj, ct=1):
     return pitches
 
 
-def run(n, fac=None, sign=-1, ct=1, verbose=True):
+def run(n, fac=None, sign=-1, ct=1, verbose=True, tj=None, pitches=None):
+    """Follow every value through the stages (`fac`, `tj`, `pitches`: a plan of the library's
+    host planner, or this file's own choice) and compare with numpy.fft."""
     fac = tuple(fac or factorise(n))
     assert np.prod(fac) == n
-    tj = threads(n, fac)
-    pitches = choose_pitches(n, fac, tj, ct)
+    tj = tj or threads(n, fac)
+    pitches = list(pitches) if pitches is not None else choose_pitches(n, fac, tj, ct)
     rng = np.random.default_rng(n)
     x = rng.normal(size=n) + 1j * rng.normal(size=n)
     # registers of thread tj_: list of slots
