@@ -1487,8 +1487,17 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         if (rtc_mode()) {
             bool ok = g2_plan(p->n2, 1, &p->q2);
             if (ok) p->q2r = g2_reversed(p->q2);
-            if (ok && p->n1 > 1) ok = g2_plan(p->n1, p->gen_ct, &p->q1);
-            if (!ok) fail("no stage list for %d x %d", p->n1, p->n2);
+            if (ok && p->n1 > 1) {
+                // (a column tile is one workgroup: at most 1024 threads and 64 KiB of exchange area)
+                int ct = p->gen_ct;
+                while ((ok = g2_plan(p->n1, ct, &p->q1)) && ct > 1 &&
+                       (p->q1.threads() > 1024 || p->q1.lds_elems * 8 > 64 * 1024))
+                    ct /= 2;
+                p->gen_ct = ct;
+                ok = ok && p->q1.threads() <= 1024 && p->q1.lds_elems * 8 <= 64 * 1024;
+            }
+            ok = ok && p->q2.threads() <= 1024 && std::max(p->q2.lds_elems, p->q2r.lds_elems) * 8 <= 96 * 1024;
+            if (!ok) fail("no stage list within a workgroup for %d x %d", p->n1, p->n2);
             if (ok) {
                 std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", p->q2) +
                                   g2_trait_source("GB", p->q2r);

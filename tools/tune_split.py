@@ -18,7 +18,8 @@ if len(sys.argv) > 2 and sys.argv[1] == 'one':
     g.manual_seed(1)
     x = torch.view_as_complex(torch.randn((64 * 2**20, 2, 2), generator=g, device=dev, dtype=torch.float32))
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=fc, sideband=1)
-    dd = bt.Dedisperse(ds, float(os.environ.get('TUNE_DM', '100')))
+    spf = os.environ.get('TUNE_SPF')
+    dd = bt.Dedisperse(ds, float(os.environ.get('TUNE_DM', '100')), samples_per_frame=int(spf) if spf else None)
     dd.max_frames_per_call = 10**6
     info = dd._get_plan().info()
     n = dd.shape[0]
