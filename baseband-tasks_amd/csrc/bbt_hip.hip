@@ -2238,11 +2238,17 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
         // The specialised kernels where they are ahead of the general ones (MI355X, round 5, one
         // stream pair, Gsamples/s general -> specialised): short transforms, which fill their waves
         // with several of them (14: 25 -> 73, 30: 44 -> 71), and transforms whose general kernel
-        // needs more than 512 threads (6174: 83 -> 106).  In between both stream at 4-5 TB/s and
-        // the general kernels' smaller register footprint wins (1000: 154 against 97-112, 1536:
-        // 152 against 119, 3000: 113 against 110).  BBT_G2_CHAN=all / none overrides.
+        // takes more stages -- its radices end at 12, the specialised ones at 16 (6174 = 14 9 7 7
+        // against 9 7 7 7 2: 83 -> 106).  With equal stages both stream at 4-5 TB/s and the general
+        // kernels' smaller register footprint wins (1000: 154 against 97-112, 1536: 152 against
+        // 119, 3000: 113 against 110, 6561: 100-104 against 94).  BBT_G2_CHAN=all / none overrides.
         const char* chan_env = getenv("BBT_G2_CHAN");
-        const bool want = chan_env ? !strcmp(chan_env, "all") : (n_chan < 256 || n_chan > 4096);
+        bool want = n_chan < 256;
+        {
+            G2Plan probe;
+            if (!want && g2_plan(n_chan, 1, &probe)) want = probe.nfac < p->g.nfac;
+        }
+        if (chan_env) want = !strcmp(chan_env, "all");
         if (rtc_mode() && want && !(chan_env && !strcmp(chan_env, "none"))) {
             // columns of a workgroup: as many neighbouring pairs as divide the pair count (up to 8:
             // 128-byte pieces of a complete sample), then consecutive transforms until the

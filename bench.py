@@ -78,7 +78,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=['headline', 'config4'], default='headline')
     ap.add_argument('--blocks', type=int, default=None,
-                    help='overlap-save blocks per step per GPU (default 768 headline, 3 config4)')
+                    help='overlap-save blocks per step per GPU (default 768 headline, 8 config4)')
     ap.add_argument('--subbands-per-rank', type=int, default=8, help='config4: sub-bands per rank')
     ap.add_argument('--cpu-seconds', type=float, default=20.,
                     help='target wall time of the all-core CPU baseline')
@@ -118,7 +118,7 @@ def measure_traffic(args):
              '--steps', '2', '--warmup', '1', '--no-cpu', '--no-verify', '--no-host-path', '--no-traffic',
              '--no-kernel-timing']
     child += ['--blocks', str(min(args.blocks or 96, 96))] if args.workload == 'headline' else \
-        ['--blocks', str(args.blocks or 3), '--subbands-per-rank', str(args.subbands_per_rank)]
+        ['--blocks', str(args.blocks or 8), '--subbands-per-rank', str(args.subbands_per_rank)]
     env = dict(os.environ, TMPDIR='/tmp')
     per = {}
     try:
@@ -745,7 +745,7 @@ def run_rank(args):
                     'overlap-save blocks (836100 valid) -> Channelize(1024), 2-pol complex64, '
                     'HBM-resident input')
     else:
-        blocks = args.blocks or 3
+        blocks = args.blocks or 8          # (a call of 6-12 blocks keeps both lanes busy: DESIGN 4.4)
         nsub = args.subbands_per_rank
         spf = C4_NFFT - C4_PAD
         n_in = (blocks - 1) * spf + C4_NFFT
