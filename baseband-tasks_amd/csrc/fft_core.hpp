@@ -63,7 +63,10 @@ __device__ __forceinline__ cf cmul(cf a, cf b) {
 // both lanes takes it from one half of a register pair (op_sel / op_sel_hi), so the twiddle is
 // used as loaded.  The compiler does not form these: it copies w.x and w.y into pairs first (two
 // v_mov per product, 8 % of the instructions of a generic-length row pass).  Constants (SGPRs,
-// literals) stay with twmul / cmul.
+// literals) stay with twmul / cmul.  Measured on MI355X (round 5): rows of 3402 points 16.77 ->
+// 16.39 us per block; in the power-of-two kernels (fft_butterfly_twiddle and the passes of
+// bbt_kernels.hpp) nothing -- headline 52.2 / 52.2 / 51.8 without, 51.1 / 51.7 / 51.7 with, 6
+// registers more in the row pass -- so those keep the compiler's form.
 #ifndef BBT_OPSEL
 #define BBT_OPSEL 1
 #endif
