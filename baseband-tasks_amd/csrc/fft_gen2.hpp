@@ -216,9 +216,9 @@ __device__ __forceinline__ void g2_butterflies(c2 (&v)[V], const cf (&tw1)[BM]) 
     }
 }
 
-// first stage: source -> butterfly (no twiddles: Ns == 1)
-template <class G, int SIGN, int V, class Src>
-__device__ __forceinline__ void g2_first(const G2Ctx& c, c2 (&v)[V], Src& src) {
+// first stage: source -> butterfly (no twiddles: Ns == 1), loads and arithmetic apart
+template <class G, int V, class Src>
+__device__ __forceinline__ void g2_load(const G2Ctx& c, c2 (&v)[V], Src& src) {
     typedef G2Stage<G, 0> St;
     constexpr int R = St::R;
 #pragma unroll
@@ -233,6 +233,11 @@ __device__ __forceinline__ void g2_first(const G2Ctx& c, c2 (&v)[V], Src& src) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[b * R + r] = u[r];
     }
+}
+template <class G, int SIGN, int V>
+__device__ __forceinline__ void g2_first_butterflies(c2 (&v)[V]) {
+    typedef G2Stage<G, 0> St;
+    constexpr int R = St::R;
 #pragma unroll
     for (int b = 0; b < St::B; ++b) {
         c2 u[R];
@@ -242,6 +247,11 @@ __device__ __forceinline__ void g2_first(const G2Ctx& c, c2 (&v)[V], Src& src) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[b * R + r] = u[r];
     }
+}
+template <class G, int SIGN, int V, class Src>
+__device__ __forceinline__ void g2_first(const G2Ctx& c, c2 (&v)[V], Src& src) {
+    g2_load<G>(c, v, src);
+    g2_first_butterflies<G, SIGN>(v);
 }
 // last stage's results -> sink (natural order: elements j + r m)
 template <class G, int S, int V, class Dst>

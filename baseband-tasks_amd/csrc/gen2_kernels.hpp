@@ -113,12 +113,6 @@ __device__ __forceinline__ void g2_fft_rows(v2* lds, const float2* __restrict__ 
     const long long i = (long long)(blockIdx.x / npg) * (ct >> lgcp) + (col >> lgcp);
     const int sp = (blockIdx.x % npg) * cp + (col & (cp - 1));
     const bool live = i < n_fft;
-#if defined(BBT_G2_STAGGER)              // (experiment: break the convoy of workgroups that start together)
-    if (blockIdx.x < 8192) {
-        const unsigned k = (blockIdx.x * 2654435761u) >> 30;
-        for (unsigned it = 0; it < k * BBT_G2_STAGGER; ++it) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     GenStreamSrc src{in + (i * n * S + 2 * sp), S, live};
     GenScaledDst dst{out + (i * n * S + 2 * sp), S, scale, live};
     g2_fft_open<G, SIGN>(lds, wn, tid, src, dst);
