@@ -2377,6 +2377,9 @@ struct bbt_pfb_plan {
     FftTables tab;
     FftTables tab4096;   // for the sliding-window kernel
     bool window = false;
+    // many streams: the window as a streaming pass over whole rows (k_pfb_fir_rows), then the
+    // transform in place through a channelizer plan (k_fft_rows_pp)
+    bbt_chan_plan* two_pass = nullptr;
 };
 
 template <int N, int NTAP>
@@ -2463,6 +2466,18 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
         bbt_pfb_plan_destroy(p);
         return 1;
     }
+    // Two passes from 16 streams on (MI355X, round 5, 4 / 12 x 1024, G stream-samples/s one pass ->
+    // two: 8 streams 199 / 160 -> 159 / 152, 16 streams 140 / 107 -> 150 / 144, 128 streams
+    // 99 / 54 -> 159 / 154, 2048 streams 82 / 54 -> 141-146 / 130-133); BBT_PFB_TWO_PASS=0 / 1 overrides.
+    {
+        const char* env = getenv("BBT_PFB_TWO_PASS");
+        const bool ok = !split_real && n_stream >= 4 && (n_tap == 4 || n_tap == 8 || n_tap == 12 || n_tap == 16);
+        const bool want = env ? atoi(env) != 0 : n_stream >= 16;
+        if (ok && want && bbt_chan_plan_create(&p->two_pass, n_chan, n_stream, -1)) {
+            bbt_pfb_plan_destroy(p);
+            return 1;
+        }
+    }
     if (p->window) {
         // taps of column tau + 256 c, four at a time: quads[((c * n_tap / 4) + q) * 256 + tau][k] = h[4 q + k]
         const int cols = n_chan / 256, quads = n_tap / 4;
@@ -2486,6 +2501,7 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
 
 int bbt_pfb_plan_destroy(bbt_pfb_plan* p) {
     if (!p) return 0;
+    if (p->two_pass) bbt_chan_plan_destroy(p->two_pass);
     if (p->taps_quads) hipFree(p->taps_quads);
     if (p->taps) hipFree(p->taps);
     delete p;
@@ -2504,6 +2520,25 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
         const int64_t ns = (n_spectra - s0 < slab) ? n_spectra - s0 : slab;
         const int64_t off = s0 * p->n * p->S;
         hipStream_t st = (hipStream_t)stream;
+        if (p->two_pass) {
+            // (one launch of each pass per slab: in pieces whose windowed rows would stay in the
+            // Infinity Cache between the passes -- 48 ... 192 MiB -- it is SLOWER, 93-147 against
+            // 148-159 G stream-samples/s for 16 / 128 streams: shorter launches, nothing to overlap)
+            constexpr int NI = 96;
+            const long long row16 = (long long)p->n * p->npair;
+            const dim3 grid((unsigned)((row16 + 255) / 256), (unsigned)((ns + NI - 1) / NI));
+            const float4* src = reinterpret_cast<const float4*>(in + off);
+            float4* dst = reinterpret_cast<float4*>(out + off);
+            switch (p->n_tap) {
+#define BBT_PF(T_) case T_: hipLaunchKernelGGL((k_pfb_fir_rows<T_, NI>), grid, dim3(256), 0, st, src, dst, (long long)ns, \
+                                               row16, p->npair, p->n, p->taps); break;
+                BBT_PF(4) BBT_PF(8) BBT_PF(12) BBT_PF(16)
+#undef BBT_PF
+                default: return fail("pfb: two passes need 4, 8, 12 or 16 taps");
+            }
+            if (bbt_chan_execute(p->two_pass, out + off, out + off, ns, stream)) return 1;
+            continue;
+        }
         if (p->window) {
             // input of slab s0 starts at spectrum s0 (same offset as the output, except
             // for half spectra of a real pair: n/2 + 1 channels x 2 streams per spectrum)

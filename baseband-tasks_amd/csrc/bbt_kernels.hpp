@@ -1401,6 +1401,57 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
     }
 }
 
+// Polyphase filter bank on MANY streams, first of two passes: the window alone,
+//   y[i, c, s] = sum_t x[(i + t) N + c, s] h[t, c]          (reference pfb.py:91-100),
+// as a streaming filter over whole rows -- a row is the N complete samples of one spectrum, N * S
+// contiguous complex numbers, and thread `idx` owns one 16-byte piece (a stream pair of one
+// column) of every row, so every access is a whole line whatever the stream count (the
+// one-pass kernels below take 16 bytes out of every S * 8-byte sample: 330 G stream-samples/s
+// for two streams, 144 / 99 / 86 for 16 / 128 / 2048).  A workgroup sweeps NI + NTAP - 1 rows for
+// NI spectra, each row loaded once, NTAP running sums in registers (the sum of output i lives in
+// register i mod NTAP).  The transform follows in place (k_fft_rows_pp).  Real taps: the external
+// format (re_A im_A re_B im_B) is scaled as it is.
+//   grid (ceil(row16 / 256), ceil(n_spec / NI));  row16 = N * S / 2 sixteen-byte pieces per row
+template <int NTAP, int NI>
+__global__ __launch_bounds__(256) void k_pfb_fir_rows(const float4* __restrict__ in, float4* __restrict__ out,
+                                                      long long n_spec, long long row16, int npair, int N,
+                                                      const float* __restrict__ taps) {
+    static_assert(NI % NTAP == 0, "rows are swept in groups of NTAP");
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= row16) return;
+    const int c = (int)(idx / npair);
+    const long long i0 = (long long)blockIdx.y * NI;
+    const long long rows = n_spec + NTAP - 1 - i0;           // input rows that exist from i0 on
+    const long long outs = n_spec - i0;                       // spectra left from i0 on
+    float h[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) h[t] = taps[(long long)t * N + c];
+    f4v acc[NTAP];
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
+    const f4v* src = reinterpret_cast<const f4v*>(in) + i0 * row16 + idx;
+    f4v* dst = reinterpret_cast<f4v*>(out) + i0 * row16 + idx;
+    for (int g = 0; g < NI / NTAP + 1; ++g) {
+        f4v x[NTAP];
+#pragma unroll
+        for (int u = 0; u < NTAP; ++u) {                      // (the group's loads in flight together)
+            const long long r = (long long)g * NTAP + u;
+            x[u] = (r < rows && r < NI + NTAP - 1) ? src[r * row16] : f4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NTAP; ++u) {
+            const long long r = (long long)g * NTAP + u;
+            // row r is tap t of output r - t: register (u - t) mod NTAP
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) acc[(u - t + NTAP) % NTAP] += x[u] * h[t];
+            // output r - NTAP + 1 is complete (its last tap was this row): register (u + 1) mod NTAP
+            const long long k = r - (NTAP - 1);
+            if (k >= 0 && k < NI && k < outs) dst[k * row16] = acc[(u + 1) % NTAP];
+            acc[(u + 1) % NTAP] = f4v{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // Polyphase filter bank, register sliding window.  A 256-thread workgroup
 // computes NG = 4096 / N consecutive spectra of one stream pair: thread t owns
 // columns t + 256 c (c < P = N / 256) of every spectrum and, one column at a

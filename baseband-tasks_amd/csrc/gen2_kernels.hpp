@@ -71,13 +71,13 @@ __device__ __forceinline__ void g2_col(v2* lds, const float2* __restrict__ in, f
     const bool live = n2 < N2;
     f4* w = reinterpret_cast<f4*>(work) + ((long long)(b * npair + sp) * N1) * N2p + n2;
     if (FIRST) {
-        GenStreamSrc src{in + ((blk.in_off + n2) * S + 2 * sp), (long long)N2 * S, live, BBT_G2_NT && S == 2};
+        GenStreamSrc src{in + ((blk.in_off + n2) * S + 2 * sp), (long long)N2 * S, live, BBT_G2_NT_LOAD && S == 2};
         GenWorkDst dst{w, N2p, live};
         g2_fft_open<G, -1>(lds, wn, tid, src, dst);
     } else {
         GenWorkSrc src{w, N2p, live};
         GenValidDst dst{out + (blk.out_off * S + 2 * sp), S, n2, N2, blk.valid_start, blk.valid_count, live,
-                        BBT_G2_NT && S == 2};
+                        BBT_G2_NT_STORE && S == 2};
         g2_fft_open<G, +1>(lds, wn, tid, src, dst);
     }
 }

@@ -15,8 +15,11 @@
 namespace bbt {
 
 // (dev switches of the run-time compiled kernels: BBT_RTC_DEFINES="-DBBT_G2_NT=0 ...")
-#ifndef BBT_G2_NT
-#define BBT_G2_NT 0                      // stream side of the column passes non-temporal when S == 2
+#ifndef BBT_G2_NT_LOAD
+#define BBT_G2_NT_LOAD 0                 // stream side of the first column pass non-temporal when S == 2
+#endif
+#ifndef BBT_G2_NT_STORE
+#define BBT_G2_NT_STORE 0                // ... of the last one
 #endif
 #ifndef BBT_G2_WORK_ST
 #define BBT_G2_WORK_ST 0                 // work-buffer stores write-through (st_int)
@@ -77,6 +80,9 @@ struct GenWorkDst {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             f4* p = base + (long long)(j + r * m) * stride;
+#if defined(BBT_DBG_NOSTORE)
+            if (v[r].re.x != 12345.678f) continue;
+#endif
 #if BBT_G2_WORK_ST
             st_int(reinterpret_cast<float2*>(p), v[r]);        // (write-through, as the power-of-two passes)
 #else

@@ -353,6 +353,28 @@ def test_config3_polyphase_filter_bank(golden):
     assert_parity(z[-3:], golden['c3_tail'], 'golden tail')
 
 
+@pytest.mark.parametrize('sample_shape', [(8, 2), (64, 2), (3, 2)])
+@pytest.mark.parametrize('n_tap,n_chan', [(4, 1024), (12, 256), (16, 512)])
+def test_filter_bank_on_many_streams(sample_shape, n_tap, n_chan):
+    """`PolyphaseFilterBank` broadcasts over the trailing sample axes (reference pfb.py:136-154).  From
+    16 streams on the window is a streaming pass over whole rows and the transform follows in place
+    (`k_pfb_fir_rows` + the channelizer; 6 streams: the one-pass kernels): both against the oracle,
+    over more spectra than one sweep of the window pass (96) and a ragged last sweep."""
+    n_spec = 96 + 37
+    n_in = (n_spec + n_tap - 1) * n_chan
+    rng = np.random.default_rng(n_chan + sample_shape[0])
+    x = rng.standard_normal((n_in,) + sample_shape + (2,), dtype=np.float32).view(np.complex64)[..., 0]
+    resp = bt.sinc_hamming(n_tap, n_chan)
+    ds = bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=n_in)
+    pfb = bt.PolyphaseFilterBank(ds, resp, samples_per_frame=n_spec)
+    z = pfb.read()
+    flat = x.reshape(n_in, -1)
+    want, _ = orc.polyphase_filter_bank(flat, orc.sinc_hamming(n_tap, n_chan), n_in, samples_per_frame=n_spec)
+    want = want.reshape((want.shape[0], n_chan) + sample_shape)
+    assert z.shape == want.shape
+    assert_parity(z, want, f'pfb {n_tap} x {n_chan} on {sample_shape}')
+
+
 # --------------------------------------------------------------------------- small, complete outputs
 def test_small_dedisperse_two_sidebands_golden(golden):
     nh = noise(10000, (2,), 4000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,

@@ -8,7 +8,7 @@ import baseband_tasks_amd as bt
 dev = torch.device('cuda', 0)
 bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
 gc.disable()
-for S in (4, 8, 16, 128, 2048):
+for S in ((4, 8, 16, 128, 2048) if os.environ.get('CHAN', '1') != '0' else ()):
     n = (2**28) // S
     x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 1e6, samples_per_frame=2**16, frequency=300e6, sideband=1)
@@ -22,3 +22,23 @@ for S in (4, 8, 16, 128, 2048):
         _ = y.ptr; torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
         print(f"S={S:5d} Channelize({nc:4d}): {t.shape[0] * nc * S / dt / 1e9:7.1f} G stream-samples/s", flush=True)
     del ds, x
+
+# PolyphaseFilterBank on the same stream counts (PFB=0 skips; BBT_PFB_TWO_PASS=0 / 1 forces the route)
+if os.environ.get('PFB', '1') != '0':
+    for S in (2, 4, 8, 16, 128, 2048):
+        n = (2**28) // S
+        x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
+        ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 1e6, samples_per_frame=2**16 if S > 2 else 2**20, frequency=300e6, sideband=1)
+        for ntap, nc in ((4, 1024), (12, 1024)):
+            t = bt.PolyphaseFilterBank(ds, bt.sinc_hamming(ntap, nc))
+            def step():
+                u = t
+                while u is not None and hasattr(u, 'invalidate_cache'):
+                    u.invalidate_cache(); u = getattr(u, 'ih', None)
+                t.seek(0); return t.read_device(t.shape[0])
+            for _ in range(3): step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(4): y = step()
+            _ = y.ptr; torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+            print(f"S={S:5d} PolyphaseFilterBank {ntap:2d} x {nc}: {t.shape[0] * nc * S / dt / 1e9:7.1f} G stream-samples/s", flush=True)
+        del ds, x, t

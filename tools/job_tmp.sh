@@ -1,3 +1,3 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/g2u; export G2_NO_OLD=1
-for per in 4 16; do
-for spec in "chan 3000 32768 10" "chan 1000 65536 10" "chan 6561 16384 10"; do echo "== $spec loop $per"; G2_LOOP=$per timeout -k 10 100 baseband-tasks_amd/lib/gen2_bench $spec 2>&1 | grep "us \|rtc k_loop\|FAIL"; done; done | tee gpurun_out/g2u/harness.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/pfb3
+for mib in 100000 96 48 192; do echo "== piece $mib MiB"; CHAN=0 BBT_PFB_PIECE_MIB=$mib timeout -k 10 400 python3 -u tools/bench_many_streams.py 2>&1 | grep "S=   16\|S=  128\|S= 2048"; done | tee gpurun_out/pfb3/log.txt
+timeout -k 10 600 python3 -u -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "filter_bank" 2>&1 | tail -3
