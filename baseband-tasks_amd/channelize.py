@@ -179,6 +179,26 @@ class Channelize(_RowFFTTask):
                          samples_per_frame=samples_per_frame, frequency=frequency,
                          sideband=sideband, dtype=np.complex64)
 
+    @property
+    def max_frames_per_call(self):
+        """As `DeviceTaskMixin.max_frames_per_call`; a channelizer that is folded into an upstream
+        overlap-save task computes whole blocks of that task with every call, so a call covers at
+        least two of them (with the default bound of 512 MiB a call of 2048 streams on 2^16-sample
+        blocks covered 0.6 of a block, and every block was computed twice)."""
+        base = DeviceTaskMixin.max_frames_per_call.fget(self)
+        if self._max_frames_per_call is None:
+            try:
+                dd = self._fusable_input()
+            except Exception:
+                dd = None
+            if dd is not None:
+                base = max(base, -(-2 * int(dd.samples_per_frame) // (self._n * int(self.samples_per_frame))))
+        return base
+
+    @max_frames_per_call.setter
+    def max_frames_per_call(self, value):
+        self._max_frames_per_call = None if value is None else int(value)
+
     def _fusable_input(self):
         """The upstream overlap-save task if its row pass can take over the
         channelizer FFT, else None."""

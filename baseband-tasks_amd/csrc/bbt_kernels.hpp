@@ -421,6 +421,8 @@ struct SpecOut {
     float det_scale;
     // n_chan < 256: the row pass leaves channel a + 16 bitrev_L(c) of group q at
     // row position (L q + c) + T a, L = n_chan / 16, T = N2 / 16 (k_osm_rowpass)
+    int tiny_lg;         // n_chan = 2, 4, 8 (log2 here, else 0): the row pass transforms the n_chan neighbouring
+                         // LANES that hold a group and leaves channel bitrev(c) at position q n_chan + c
     int small_l;         // 0: natural order (position == q * n_chan + channel)
     int small_row;       // row length N2 of the row pass (a column pass of a three-level
                          // transform sees 16 such rows side by side)
@@ -460,6 +462,10 @@ __device__ __forceinline__ void col_twiddles(c2 (&v)[16], const cf* __restrict__
 
 // Column position -> q * n_chan + channel for the small-channel-count layout.
 __device__ __forceinline__ int small_channel_slot(int pos, const SpecOut& so) {
+    if (so.tiny_lg) {
+        const int c = pos & ((1 << so.tiny_lg) - 1);
+        return pos - c + (int)(__brev((unsigned)c) >> (32 - so.tiny_lg));
+    }
     if (!so.small_l) return pos;
     const int L = so.small_l, N2 = so.small_row, T = N2 >> 4;
     const int row = pos / N2, p = pos - row * N2;
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(256) void k_osm_col16(const float2* __restrict__ in
         for (int j = 0; j < 16; ++j) v[j] = ld_int(w + (long long)j * N2 * 2);
         radix16<+1>(v);
         SpecCursor cur;
-        if (SPEC) cur = spec_cursor(out, so, blk, 0, 1, N2, n2, S, sp, npair);
+        if (SPEC) cur = spec_cursor(out, so, blk, 0, 1, N2, small_channel_slot(n2, so), S, sp, npair);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (SPEC) {
@@ -1165,6 +1171,23 @@ __global__ __launch_bounds__(N2 / 16, (BBT_ROWPASS_MINWAVES > 1 ? BBT_ROWPASS_MI
     // above, is what made the plain row pass 199 VGPRs / 2 waves per SIMD and
     // plain Dedisperse slower than the fused pipeline; now 148 / 3.)
     if constexpr (NCH == 0) {
+        float2* row2 = row;
+        asm volatile("" : "+s"(row2));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st_int(row2 + (long long)(tau + T * j) * 2, v[j]);
+    } else if constexpr (NCH < 16) {
+        // Very few channels, NCH = 2, 4, 8 (Channelize(4) behind a many-stream Dedisperse: the
+        // CHIME-native form of config 4, reference channelize.py:73-74): register j of thread tau is
+        // n2 = tau + T j, so the NCH consecutive samples of a group sit in the same register of NCH
+        // neighbouring LANES (groups start at multiples of NCH, T is a multiple of 16).  The
+        // transform is the lane butterflies alone -- no exchange, no register stage --: lane c of a
+        // group ends up with channel bitrev(c), stored where the sample was; the column pass maps
+        // the position back (small_channel_slot, SpecOut::tiny_lg).
+        static_assert(NCH == 2 || NCH == 4 || NCH == 8, "NCH below 16: 2, 4 or 8");
+        const int c = tau & (NCH - 1);
+        if constexpr (NCH >= 8) lane_radix2_stage<4, NCH>(v, c, wroot);
+        if constexpr (NCH >= 4) lane_radix2_stage<2, NCH>(v, c, wroot);
+        lane_radix2_stage<1, NCH>(v, c, wroot);
         float2* row2 = row;
         asm volatile("" : "+s"(row2));
 #pragma unroll

@@ -334,6 +334,45 @@ def test_fused_and_unfused_channelizer_agree(golden, monkeypatch):
     assert_parity(z, orc.channelize(ys[:z.shape[0] * 256], 256), 'fused small')
 
 
+@pytest.mark.parametrize('n_stream', [2, 16, 66])
+@pytest.mark.parametrize('n_chan', [2, 4, 8])
+@pytest.mark.parametrize('n_fft', [2**14, 2**15, 2**16])
+def test_very_few_channels_fused_into_16_column_plans(n_stream, n_chan, n_fft, monkeypatch):
+    """`Channelize(2 ... 8)` behind `Dedisperse` on 2^14 ... 2^16-sample blocks (the CHIME-native
+    form of config 4, SURVEY 8d: Channelize(4) on the defaults' 2^16-sample blocks; reference
+    channelize.py:73-74) is the lane butterflies of the row pass: fused and unfused routes against
+    the oracle, on one pair, on pairs in eights (the multi-pair column passes) and on an odd pair
+    count; unaligned frames, so that spectra straddle block seams."""
+    from baseband_tasks_amd import channelize as chmod
+    if n_fft == 2**14 and n_stream != 16:
+        pytest.skip('16384-sample blocks run in one kernel unless the stream pairs come in eights')
+    fs, fc, dm = 1 * u.MHz, 300 * u.MHz, 0.3 if n_fft == 2**14 else 1.0
+    n_in = 3 * n_fft + 4321
+    rng = np.random.default_rng(n_fft + n_stream + n_chan)
+    x = rng.standard_normal((n_in, n_stream, 2), dtype=np.float32).view(np.complex64)[..., 0]
+    pow2 = HipFFTMaker(power_of_two=True)
+    probe = bt.Dedisperse(bt.DeviceStream(x, T0, fs, samples_per_frame=n_fft, frequency=fc, sideband=1), dm)
+    pad = probe._pad_start + probe._pad_end
+    assert pad < n_fft // 2
+    y, info = orc.dedisperse(x, 1e6, 300., 1, dm, samples_per_frame=n_fft - pad, ih_samples_per_frame=n_fft)
+    assert info['ih_spf'] == n_fft
+    got = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(chmod, 'FUSE_WITH_OVERLAP_SAVE', fuse)
+        dd = bt.Dedisperse(bt.DeviceStream(x, T0, fs, samples_per_frame=n_fft, frequency=fc, sideband=1), dm,
+                           samples_per_frame=n_fft - pad)
+        assert dd._ih_samples_per_frame == n_fft and dd._get_plan().info()['n1'] == 16
+        ch = bt.Channelize(dd, n_chan, samples_per_frame=1000)
+        assert (ch._fusable_input() is not None) == fuse
+        z = ch.read()
+        assert_parity(z, orc.channelize(y[:z.shape[0] * n_chan], n_chan), f'fuse={fuse} {n_stream} streams n={n_chan}')
+        k = (n_fft - pad) // n_chan                      # across the first block seam
+        ch.seek(k - 5)
+        assert np.array_equal(ch.read(11), z[k - 5:k + 6])
+        got[fuse] = z
+    assert rel_l2(got[True], got[False]) < 6e-7
+
+
 # --------------------------------------------------------------------------- config 3
 def test_config3_polyphase_filter_bank(golden):
     nh = noise(2 * 2**20, (2,), 2**20, frequency=1000 * u.MHz, sideband=1)
