@@ -840,6 +840,7 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
         return 0;                                               \
     }
     BBT_RP(256, 0) BBT_RP(512, 0) BBT_RP(1024, 0) BBT_RP(2048, 0) BBT_RP(4096, 0)
+    BBT_RP(256, 2) BBT_RP(256, 4) BBT_RP(256, 8) BBT_RP(512, 2) BBT_RP(512, 4) BBT_RP(512, 8)
     BBT_RP(1024, 2) BBT_RP(1024, 4) BBT_RP(1024, 8) BBT_RP(2048, 2) BBT_RP(2048, 4) BBT_RP(2048, 8)
     BBT_RP(4096, 2) BBT_RP(4096, 4) BBT_RP(4096, 8)
     BBT_RP(256, 16) BBT_RP(256, 32) BBT_RP(256, 64) BBT_RP(256, 128)
@@ -1770,7 +1771,7 @@ int bbt_osm_plan_fusable(const bbt_osm_plan* p, int n_chan) {
     if (n_chan == 16 || n_chan == 32 || n_chan == 64 || n_chan == 128)       // few channels: after an
         return p->n1 >= 256 || p->outer == 256;                             // exchange in the row pass
     if (n_chan == 2 || n_chan == 4 || n_chan == 8)       // very few: lane butterflies in the row pass,
-        return p->n1 == 16 && p->outer == 1 && p->n2 >= 1024;              // 16 x N2 plans (2^14 ... 2^16 samples)
+        return p->outer == 1 && (p->n1 == 16 || p->n1 == 256);           // two-level plans (2^13 ... 2^20 samples)
     return fft_len_ok(n_chan) && n_chan <= p->n2 && p->n2 % n_chan == 0;
 }
 
@@ -1855,7 +1856,7 @@ static int osm_channelized(bbt_osm_plan* p, const char* who, const void* in_dev,
             (long long)p->n);
     ARG_TRY(bbt_osm_plan_fusable(p, n_chan),
             "%s: n_chan=%d must be a power of two in [256, %d] (or 16..128 for blocks with 256 "
-            "columns or of three levels, 2..8 for blocks of 2^14..2^16 samples)", who, n_chan, p->n2);
+            "columns or of three levels, 2..8 for two-level blocks of up to 2^20 samples)", who, n_chan, p->n2);
     const bool small = n_chan < 256;
     ARG_TRY(!(small && det_step > 0), "%s: fused detection needs n_chan >= 256", who);
     ARG_TRY(!(p->single && det_step > 0), "%s: one-stream plans have no fused detection", who);
