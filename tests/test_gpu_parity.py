@@ -545,6 +545,47 @@ print('worst rel-L2 %%.2e, modules %%d' %% (worst, bt.hip.rtc_info()['modules'])
     assert (modules == 0) if mode == '0' else (modules >= 8), out.stdout
 
 
+def test_plan_time_compilation_falls_back_and_caches(tmp_path):
+    """The two other ways through csrc/rtc.hpp: (1) the kernel headers cannot be found (BBT_CSRC
+    points nowhere): the plan runs on the general kernels, with one warning, and the result is
+    the oracle's; (2) BBT_RTC_CACHE: a second process takes the code object from disk instead of
+    compiling it."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import baseband_tasks_amd as bt
+from baseband_tasks_amd import units as u
+from oracle import bbt_oracle as orc
+n_fft, n_tap = 5670, 1890
+rng = np.random.default_rng(1)
+resp = ((rng.standard_normal((n_tap, 1)) + 1j * rng.standard_normal((n_tap, 1))) / np.sqrt(n_tap)).astype(np.complex64)
+x = rng.standard_normal((2 * n_fft + 9, 4), dtype=np.float32).view(np.complex64)
+bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0
+cv = bt.Convolve(bt.DeviceStream(x, '2020-01-01T00:00:00', 1 * u.MHz), resp, samples_per_frame=n_fft - n_tap + 1)
+got = cv.read()
+want, _ = orc.convolve(x, resp, samples_per_frame=n_fft - n_tap + 1, ih_samples_per_frame=1000)
+err = np.linalg.norm((got - want).ravel()) / np.linalg.norm(want.ravel())
+assert err < 1e-6, err
+info = bt.hip.rtc_info()
+print('modules %%d seconds %%.3f' %% (info['modules'], info['seconds']))
+""" % (ROOT,)
+
+    def run(**env):
+        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True,
+                             timeout=200)
+        assert out.returncode == 0, out.stderr[-3000:]
+        words = out.stdout.split()
+        return int(words[-3]), float(words[-1]), out.stderr
+    modules, _, err = run(BBT_CSRC=str(tmp_path / 'nowhere'), BBT_RTC='1')
+    assert modules == 0 and 'general kernels' in err, err[-2000:]
+    cache = tmp_path / 'cache'
+    cache.mkdir()
+    modules, first, _ = run(BBT_RTC='require', BBT_RTC_CACHE=str(cache))
+    assert modules == 1 and len(list(cache.glob('bbt_g2_*.co'))) == 1
+    modules, second, _ = run(BBT_RTC='require', BBT_RTC_CACHE=str(cache))
+    assert second < first / 3 and len(list(cache.glob('bbt_g2_*.co'))) == 1, (first, second)
+
+
 def test_config5_at_the_references_default_block():
     """Config 5 with default arguments: Resample picks 1 049 760 = 2^5 3^8 5
     sample blocks, Dedisperse on top keeps 2^20."""
