@@ -2477,8 +2477,11 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
     // 99 / 54 -> 159 / 154, 2048 streams 82 / 54 -> 141-146 / 130-133); BBT_PFB_TWO_PASS=0 / 1 overrides.
     {
         const char* env = getenv("BBT_PFB_TWO_PASS");
-        const bool ok = !split_real && n_stream >= 4 && (n_tap == 4 || n_tap == 8 || n_tap == 12 || n_tap == 16);
-        const bool want = env ? atoi(env) != 0 : n_stream >= 16;
+        const bool ok = !split_real && n_stream >= 2 && (n_tap == 4 || n_tap == 8 || n_tap == 12 || n_tap == 16);
+        // (also where no sliding-window kernel exists and every spectrum would re-read its rows: 16 x 4096 on
+        // two streams 64.4 -> 84.2 G complete samples/s, 0.26 -> 0.34; with a window kernel one pass wins:
+        // 8 x 2048 125 against 91, 4 x 1024 164 against 88)
+        const bool want = env ? atoi(env) != 0 : (n_stream >= 16 || (!p->window && n_tap >= 8));
         if (ok && want && bbt_chan_plan_create(&p->two_pass, n_chan, n_stream, -1)) {
             bbt_pfb_plan_destroy(p);
             return 1;
