@@ -14,7 +14,7 @@
 
 namespace bbt {
 
-// (dev switches of the run-time compiled kernels: BBT_RTC_DEFINES="-DBBT_G2_NT=0 ...")
+// (dev switches of the run-time compiled kernels: BBT_RTC_DEFINES="-DBBT_G2_NT_LOAD=1 ...")
 #ifndef BBT_G2_NT_LOAD
 #define BBT_G2_NT_LOAD 0                 // stream side of the first column pass non-temporal when S == 2
 #endif

@@ -147,7 +147,7 @@ static inline int rtc_compile(const std::string& source, std::vector<char>* code
     // static register indices into selected ones, and a thread's points land in scratch)
     std::vector<const char*> opts = {o_arch.c_str(), o_inc.c_str(), "-O3", "-std=c++17", "-Wno-unused-value",
                                      "-mllvm", "-simplifycfg-sink-common=false"};
-    std::vector<std::string> extra;      // dev: BBT_RTC_DEFINES="-DBBT_G2_NT=0 -D..." (part of the cache key)
+    std::vector<std::string> extra;      // dev: BBT_RTC_DEFINES="-DBBT_G2_NT_LOAD=1 -D..." (part of the cache key)
     {
         std::istringstream in(defines);
         std::string tok;
