@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/bbt_hip.h"
@@ -1488,12 +1489,12 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         // The kernels specialised on this length (fft_gen2.hpp), compiled now; if that is not
         // possible the plan runs on the general ones.
         if (rtc_mode()) {
-            bool ok = g2_plan(p->n2, 1, &p->q2);
+            bool ok = g2_plan(p->n2, 1, &p->q2, g2_pmax(BBT_G2_KIND_ROW));
             if (ok) p->q2r = g2_reversed(p->q2);
             if (ok && p->n1 > 1) {
                 // (a column tile is one workgroup: at most 1024 threads and 64 KiB of exchange area)
                 int ct = p->gen_ct;
-                while ((ok = g2_plan(p->n1, ct, &p->q1)) && ct > 1 &&
+                while ((ok = g2_plan(p->n1, ct, &p->q1, g2_pmax(BBT_G2_KIND_COL))) && ct > 1 &&
                        (p->q1.threads() > 1024 || p->q1.lds_elems * 8 > 64 * 1024))
                     ct /= 2;
                 p->gen_ct = ct;
@@ -2197,6 +2198,140 @@ static int chan_dispatch(const bbt_chan_plan* p, const float2* in, float2* out, 
 
 extern "C" {
 
+}  // extern "C"
+
+// One candidate of a generic-length channelizer plan on the compiled kernels: columns of a
+// workgroup = cp neighbouring stream pairs (up to 8: 128-byte pieces of a complete sample, as
+// many as divide the pair count) x consecutive transforms while they still fit ONE wave (a
+// transform of 100 threads gains nothing from a neighbour: 1000 channels 160 G alone, 128 G in
+// twos).  0 = ok (k2 set), 1 = not available (g_err says why).
+static int chan_candidate(bbt_chan_plan* p, int n_chan, int direction, int pmax) {
+    G2Plan probe;
+    if (!g2_plan(n_chan, 1, &probe, pmax)) return fail("no stage list for %d", n_chan);
+    int cp = 1;
+    while (cp < 8 && p->npair % (2 * cp) == 0 && probe.tj * 2 * cp <= 256) cp *= 2;
+    int ct = cp;
+    const int ct_cap = getenv("BBT_G2_CHAN_CT") ? atoi(getenv("BBT_G2_CHAN_CT")) : 256;      // (dev)
+    while (2 * ct <= ct_cap && probe.tj * 2 * ct <= 64 && (int64_t)n_chan * 2 * ct * 8 <= 64 * 1024) ct *= 2;
+    G2Plan q;
+    if (!g2_plan(n_chan, ct, &q, pmax) || q.threads() > 1024) return fail("no plan for %d x %d columns", n_chan, ct);
+    const std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", q) +
+                            "BBT_G2_KERNEL_FFT_ROWS(k_rows, GA, " + (direction < 0 ? "-1" : "+1") +
+                            (q.threads() >= 448 ? ", 4)\n" : ", 0)\n");
+    hipFunction_t k = nullptr;
+    cf* w = nullptr;
+    if (g2_build(src, {"k_rows"}, &k) || get_g2_table(q, &w)) return 1;
+    p->q = q;
+    p->cp = cp;
+    p->k2 = k;
+    p->qw = w;
+    return 0;
+}
+// Choose among the candidates (and the general kernel) by timing them; 0 = ok (p->k2 null: the
+// general kernel stays), 1 = error (only in `require` mode).
+static int chan_pick(bbt_chan_plan* p, int n_chan, int direction) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, int> chosen;       // (device, n, streams, direction) -> points, 0 = general
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const auto key = std::make_tuple(dev, n_chan, p->S, direction);
+    const bool tune = !(getenv("BBT_G2_TUNE") && !strcmp(getenv("BBT_G2_TUNE"), "0"));
+    int pick = -1;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = chosen.find(key);
+        if (it != chosen.end()) pick = it->second;
+    }
+    if (pick < 0 && !tune) pick = g2_pmax(BBT_G2_KIND_CHAN);
+    if (pick == 0) return 0;                                           // (the general kernel won before)
+    if (pick > 0) {
+        if (!chan_candidate(p, n_chan, direction, pick)) return 0;
+        if (rtc_mode() == 2) return 1;
+        g2_warn_once("bbt_chan_plan_create");
+        p->k2 = nullptr;
+        return 0;
+    }
+    // time the candidates on scratch memory: 1 GiB each way when the card has it to spare (well
+    // past the 256 MiB memory-side cache: at 256 MiB the general kernel looked as fast as the
+    // 10-point one for 1536 channels, from HBM it is 150 against 171 G)
+    const size_t per = (size_t)n_chan * p->S * sizeof(cf);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const size_t target = std::min<size_t>((size_t)1 << 30, free_b / 8);
+    const int64_t ns = (int64_t)std::max<size_t>(8, target / per);
+    void *a = nullptr, *b = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ready = hipMalloc(&a, ns * per) == hipSuccess && hipMalloc(&b, ns * per) == hipSuccess &&
+                 hipMemsetAsync(a, 0, ns * per, nullptr) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
+                 hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+                 hipDeviceSynchronize() == hipSuccess;
+    auto time_current = [&]() -> float {
+        float best = 1e30f;
+        if (bbt_chan_execute(p, a, b, ns, st)) return best;           // (warm-up: code object upload, tables)
+        for (int r = 0; r < 2; ++r) {
+            float ms = 0.f;
+            if (hipEventRecord(e0, st) != hipSuccess || bbt_chan_execute(p, a, b, ns, st) ||
+                hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                return 1e30f;
+            best = std::min(best, ms);
+        }
+        return best;
+    };
+    float best_ms = 1e30f;
+    int any = 0;
+    if (ready) {
+        p->k2 = nullptr;
+        best_ms = time_current();                                       // the general kernel
+        pick = 0;
+        bbt_chan_plan best_plan = *p;
+        G2Plan last = {};
+        for (int pmax : {10, 16, 20}) {
+            if (chan_candidate(p, n_chan, direction, pmax)) continue;
+            ++any;
+            bool same = last.nfac == p->q.nfac && last.tj == p->q.tj && last.ct == p->q.ct;
+            for (int i = 0; same && i < last.nfac; ++i) same = last.fac[i] == p->q.fac[i];
+            last = p->q;
+            if (same) continue;
+            const float ms = time_current();
+            if (getenv("BBT_RTC_VERBOSE")) fprintf(stderr, "bbt: Channelize(%d) x %d streams, %d points per thread: %.3f ms (general %.3f)\n",
+                                                     n_chan, p->S, pmax, ms, best_plan.k2 ? -1.f : best_ms);
+            if (ms < best_ms) {
+                best_ms = ms;
+                pick = pmax;
+                best_plan = *p;
+            }
+        }
+        *p = best_plan;
+    }
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (st) hipStreamDestroy(st);
+    if (!ready) {                                                       // (no scratch memory: the rule, untimed)
+        hipGetLastError();
+        if (chan_candidate(p, n_chan, direction, g2_pmax(BBT_G2_KIND_CHAN))) {
+            if (rtc_mode() == 2) return 1;
+            g2_warn_once("bbt_chan_plan_create");
+            p->k2 = nullptr;
+        }
+        return 0;
+    }
+    if (!any) {
+        if (rtc_mode() == 2) return 1;
+        g2_warn_once("bbt_chan_plan_create");
+        p->k2 = nullptr;
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    chosen[key] = pick;
+    return 0;
+}
+
+extern "C" {
+
 int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int direction) {
     ARG_TRY(plan, "bbt_chan_plan_create: null argument");
     *plan = nullptr;
@@ -2241,50 +2376,20 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
                 p->ct = ct;
                 break;
             }
-        // The specialised kernels where they are ahead of the general ones (MI355X, round 5, one
-        // stream pair, Gsamples/s general -> specialised): short transforms, which fill their waves
-        // with several of them (14: 25 -> 73, 30: 44 -> 71), and transforms whose general kernel
-        // takes more stages -- its radices end at 12, the specialised ones at 16 (6174 = 14 9 7 7
-        // against 9 7 7 7 2: 83 -> 106).  With equal stages both stream at 4-5 TB/s and the general
-        // kernels' smaller register footprint wins (1000: 154 against 97-112, 1536: 152 against
-        // 119, 3000: 113 against 110, 6561: 100-104 against 94).  BBT_G2_CHAN=all / none overrides.
+        // The kernels compiled for this length -- and which of them.  A streaming transform wants few
+        // registers and many waves, but how few depends on the length (MI355X, round 5, one stream
+        // pair, 1 GB and more in HBM, Gsamples/s general | specialised at 20 / 16 / 10 points per
+        // thread: 1536: 150 | 141 / 142 / 171, 2187: 119 | 122 / 167 / 164, 4374: 116 | 139 / 156 / 139,
+        // 6174: 96 | 132 / 107 / 113, 6561: 119 | 121 / 147 / 151, 3000: 122 | 127 / 135 / 128, 1000: 164 |
+        // 144 / 158 / 160, 360: 162 | 90 / 118 / 166; short transforms fill a wave with several of them:
+        // 14: 25 -> 73, 30: 44 -> 71).  So the plan is made for 10, 16 and 20 points, each candidate --
+        // and the general kernel -- is timed once on scratch memory, and the fastest is kept (a few
+        // hundred milliseconds per new length and stream count, remembered for the process).
+        // BBT_G2_TUNE=0: no timing, 10 points; BBT_G2_CHAN=none: the general kernels.
         const char* chan_env = getenv("BBT_G2_CHAN");
-        bool want = n_chan < 256;
-        {
-            G2Plan probe;
-            if (!want && g2_plan(n_chan, 1, &probe)) want = probe.nfac < p->g.nfac;
-        }
-        if (chan_env) want = !strcmp(chan_env, "all");
-        if (rtc_mode() && want && !(chan_env && !strcmp(chan_env, "none"))) {
-            // columns of a workgroup: as many neighbouring pairs as divide the pair count (up to 8:
-            // 128-byte pieces of a complete sample), then consecutive transforms until the
-            // workgroup has 256 threads
-            G2Plan probe;
-            bool ok = g2_plan(n_chan, 1, &probe);
-            if (!ok) fail("no stage list for %d", n_chan);
-            if (ok) {
-                int cp = 1;
-                while (cp < 8 && p->npair % (2 * cp) == 0 && probe.tj * 2 * cp <= 256) cp *= 2;
-                int ct = cp;
-                const int ct_cap = getenv("BBT_G2_CHAN_CT") ? atoi(getenv("BBT_G2_CHAN_CT")) : 256;      // (dev)
-                while (2 * ct <= ct_cap && probe.tj * 2 * ct <= 256 && (int64_t)n_chan * 2 * ct * 8 <= 64 * 1024) ct *= 2;
-                p->cp = cp;
-                ok = g2_plan(n_chan, ct, &p->q);
-            }
-            if (ok) {
-                const std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", p->q) +
-                                        "BBT_G2_KERNEL_FFT_ROWS(k_rows, GA, " + (direction < 0 ? "-1" : "+1") +
-                                        (p->q.threads() >= 448 ? ", 4)\n" : ", 0)\n");
-                ok = !g2_build(src, {"k_rows"}, &p->k2) && !get_g2_table(p->q, &p->qw);
-            }
-            if (!ok && rtc_mode() == 2) {
-                delete p;
-                return 1;
-            }
-            if (!ok) {
-                g2_warn_once("bbt_chan_plan_create");
-                p->k2 = nullptr;
-            }
+        if (rtc_mode() && !(chan_env && !strcmp(chan_env, "none")) && chan_pick(p, n_chan, direction)) {
+            delete p;
+            return 1;
         }
     } else if ((n_chan >= 256 && get_tables(n_chan, &p->tab)) ||
                (n_chan < 256 && get_wroot(&p->wroot))) {

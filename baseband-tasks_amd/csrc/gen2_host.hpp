@@ -31,15 +31,34 @@ struct G2Plan {
     int table_len = 1;
     int lds_elems = 0;                 // exchange area of the workgroup, 8-byte elements
     int slots = 0;                     // register slots (points) a thread needs
+    int pmax = 0;                      // the bound it was planned with
     int threads() const { return std::max(64, (tj * ct + 63) / 64 * 64); }
 };
 
-static inline int g2_maxb(int r) { return std::min(BBT_G2_MAXB, std::max(1, BBT_G2_PMAX / r)); }
+// Points a thread holds at most, per kind of kernel (measured on MI355X, round 5).  The row pass
+// of a convolution, eight stages between its load and its store, wants the fewest stages and
+// exchanges (20 points: 19.0 against 25.1 us at 10).  The column passes alone run faster with few
+// registers and many waves (first column pass of the 1.67 M-point block 16.6 -> 12.8 us at 12),
+// but their bound also decides which split N1 x N2 is taken, and over the whole two-lane
+// pipeline the six pairs (COL, ROW) in {10, 12, 16, 20} x {16, 20} all measured 34.1-35.5 G (800
+// MHz block) and 30.4-31.8 G (600 MHz): within the run-to-run spread, so both stay at 20.  The
+// streaming channelizer's optimum depends on the length: its plans time 10, 16 and 20 and keep
+// the fastest (bbt_hip.hip, chan_pick); CHAN is what is used untimed.  Environment variables of
+// the same names override (dev).
+enum { BBT_G2_KIND_CHAN = 0, BBT_G2_KIND_COL = 1, BBT_G2_KIND_ROW = 2 };
+static inline int g2_pmax(int kind = BBT_G2_KIND_ROW) {
+    static const int v[3] = {
+        getenv("BBT_G2_PMAX_CHAN") ? std::max(2, atoi(getenv("BBT_G2_PMAX_CHAN"))) : 10,
+        getenv("BBT_G2_PMAX_COL") ? std::max(2, atoi(getenv("BBT_G2_PMAX_COL"))) : BBT_G2_PMAX,
+        getenv("BBT_G2_PMAX_ROW") ? std::max(2, atoi(getenv("BBT_G2_PMAX_ROW"))) : BBT_G2_PMAX};
+    return v[kind];
+}
+static inline int g2_maxb(int r, int pmax) { return std::min(BBT_G2_MAXB, std::max(1, pmax / r)); }
 
 // threads one transform needs: every stage's n / R butterflies in rounds of at most MAXB(R)
-static inline int g2_threads(int n, const std::vector<int>& fac) {
+static inline int g2_threads(int n, const std::vector<int>& fac, int pmax) {
     int t = 1;
-    for (int r : fac) t = std::max(t, (n / r + g2_maxb(r) - 1) / g2_maxb(r));
+    for (int r : fac) t = std::max(t, (n / r + g2_maxb(r, pmax) - 1) / g2_maxb(r, pmax));
     return t;
 }
 
@@ -47,7 +66,7 @@ static inline int g2_threads(int n, const std::vector<int>& fac) {
 // exchange through LDS with four barriers -- and among those the list needing the fewest threads
 // (most points per thread), large radices first (the first stage has no twiddles, and an odd or
 // large first radix keeps the padding of the first buffer small).
-static inline bool g2_factor(int n, std::vector<int>* out) {
+static inline bool g2_factor(int n, std::vector<int>* out, int pmax) {
     static const int radices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     out->clear();
     if (n < 1) return false;
@@ -68,11 +87,11 @@ static inline bool g2_factor(int n, std::vector<int>* out) {
         const Best cur = it->second;
         for (int r : radices) {
             const int64_t e = (int64_t)d * r;
-            if (e > n || n % e) continue;
+            if (r > pmax || e > n || n % e) continue;
             Best cand{cur.stages + 1, 0, cur.fac};
             cand.fac.push_back(r);
             std::sort(cand.fac.begin(), cand.fac.end(), std::greater<int>());
-            cand.threads = g2_threads(n, cand.fac);
+            cand.threads = g2_threads(n, cand.fac, pmax);
             auto jt = best.find((int)e);
             if (jt == best.end() || std::make_pair(cand.stages, cand.threads) <
                                         std::make_pair(jt->second.stages, jt->second.threads))
@@ -112,12 +131,13 @@ static inline int g2_extra_passes(const int (&addr)[64], bool write) {
 
 // Geometry for the stage list `fac` (in execution order) with `ct` interleaved transforms per
 // workgroup and `tj` threads per transform (0: the fewest the stages allow).
-static inline G2Plan g2_make_plan(int n, const std::vector<int>& fac, int ct, int tj = 0) {
+static inline G2Plan g2_make_plan(int n, const std::vector<int>& fac, int ct, int pmax, int tj = 0) {
     G2Plan g;
     g.n = n;
     g.nfac = (int)fac.size();
     g.ct = ct;
-    g.tj = tj > 0 ? tj : g2_threads(n, fac);
+    g.tj = tj > 0 ? tj : g2_threads(n, fac, pmax);
+    g.pmax = pmax;
     int ns = 1, total = 0, lds = 0;
     for (int s = 0; s < g.nfac; ++s) {
         const int r = fac[s];
@@ -178,17 +198,17 @@ static inline G2Plan g2_make_plan(int n, const std::vector<int>& fac, int ct, in
     g.lds_elems = std::max(lds * ct, 1);
     return g;
 }
-static inline bool g2_plan(int n, int ct, G2Plan* g) {
+static inline bool g2_plan(int n, int ct, G2Plan* g, int pmax) {
     std::vector<int> fac;
-    if (!g2_factor(n, &fac)) return false;
-    *g = g2_make_plan(n, fac, ct);
+    if (!g2_factor(n, &fac, pmax)) return false;
+    *g = g2_make_plan(n, fac, ct, pmax);
     return true;
 }
 // the same stages in reversed order (the inverse of a convolution)
 static inline G2Plan g2_reversed(const G2Plan& g) {
     std::vector<int> fac(g.fac, g.fac + g.nfac);
     std::reverse(fac.begin(), fac.end());
-    return g2_make_plan(g.n, fac, g.ct, g.tj);
+    return g2_make_plan(g.n, fac, g.ct, g.pmax, g.tj);
 }
 
 // N = N1 x N2 for a two-level plan: column transforms of N1 points over tiles of `ct` columns,
@@ -210,7 +230,7 @@ static inline bool g2_choose_split(int64_t n, int ct, int max_n1, int max_n2, in
     for (int64_t d = 2; d <= max_n1 && d * 2 <= n; ++d) {
         if (n % d || n / d > max_n2 || n / d < d / 4) continue;
         G2Plan c, r;
-        if (!g2_plan((int)d, ct, &c) || !g2_plan((int)(n / d), 1, &r)) continue;
+        if (!g2_plan((int)d, ct, &c, g2_pmax(BBT_G2_KIND_COL)) || !g2_plan((int)(n / d), 1, &r, g2_pmax(BBT_G2_KIND_ROW))) continue;
         if (c.lds_elems * 8 > 64 * 1024 || c.threads() > 1024 || r.threads() > 1024) continue;
         const double eff = (double)(c.tj * ct) / c.threads() * (double)r.tj / r.threads();
         const double key[4] = {(double)(!pow2_waves(c.threads()) + !pow2_waves(r.threads())),

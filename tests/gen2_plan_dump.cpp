@@ -1,5 +1,5 @@
 // Prints what the host planner of the generic-length engine (csrc/gen2_host.hpp) decides, as
-// JSON lines, for tests/test_gen2_planner.py:   gen2_plan_dump plan <n> <ct> ... | split <N> ...
+// JSON lines, for tests/test_gen2_planner.py:   gen2_plan_dump plan <pmax> <n> <ct> ... | split <N> ...
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,9 +20,10 @@ static void dump(const G2Plan& g) {
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
     if (!strcmp(argv[1], "plan")) {
-        for (int i = 2; i + 1 < argc; i += 2) {
+        const int pmax = atoi(argv[2]);
+        for (int i = 3; i + 1 < argc; i += 2) {
             G2Plan g;
-            if (!g2_plan(atoi(argv[i]), atoi(argv[i + 1]), &g)) { printf("null\n"); continue; }
+            if (!g2_plan(atoi(argv[i]), atoi(argv[i + 1]), &g, pmax)) { printf("null\n"); continue; }
             printf("{\"forward\": ");
             dump(g);
             printf(", \"reversed\": ");
@@ -34,8 +35,8 @@ int main(int argc, char** argv) {
             int n1 = 0, n2 = 0;
             if (!g2_choose_split(atoll(argv[i]), 8, 1024, 8192, &n1, &n2)) { printf("null\n"); continue; }
             G2Plan c, r;
-            g2_plan(n1, 8, &c);
-            g2_plan(n2, 1, &r);
+            g2_plan(n1, 8, &c, g2_pmax(BBT_G2_KIND_COL));
+            g2_plan(n2, 1, &r, g2_pmax(BBT_G2_KIND_ROW));
             printf("{\"n1\": %d, \"n2\": %d, \"col\": ", n1, n2);
             dump(c);
             printf(", \"row\": ");
@@ -44,7 +45,7 @@ int main(int argc, char** argv) {
         }
     } else if (!strcmp(argv[1], "source")) {
         G2Plan g;
-        if (!g2_plan(atoi(argv[2]), 1, &g)) return 1;
+        if (!g2_plan(atoi(argv[2]), 1, &g, g2_pmax(BBT_G2_KIND_ROW))) return 1;
         const G2Plan gr = g2_reversed(g);
         printf("#include \"gen2_kernels.hpp\"\n%s%sBBT_G2_KERNEL_OSM_SMALL(k_small, GA, GB, 0)\nBBT_G2_KERNEL_FFT_ROWS(k_rows, GA, -1, 0)\n",
                g2_trait_source("GA", g).c_str(), g2_trait_source("GB", gr).c_str());

@@ -503,12 +503,14 @@ def test_lengths_that_are_not_powers_of_two_run_on_kernels_compiled_for_them():
     assert np.array_equal(got[0], got[1])
 
 
-@pytest.mark.parametrize('mode', ['0', 'require'])
-def test_general_and_specialised_kernels_agree_with_the_oracle(mode):
+@pytest.mark.parametrize('mode, points', [('0', None), ('require', None), ('require', 10), ('require', 16), ('require', 20)])
+def test_general_and_specialised_kernels_agree_with_the_oracle(mode, points):
     """BBT_RTC=0 keeps every such length on the general kernels (the fall-back when hipRTC is not
     available), BBT_RTC=require makes a failing compilation an error: one child process each runs
     one-kernel and two-level blocks, several streams, and channel counts either side of the
-    engines' ranges, against the oracle."""
+    engines' ranges, against the oracle.  A channelizer plan keeps the fastest of its candidates
+    (bbt_hip.hip chan_pick); with `points` the timing is off and every channel count runs on the
+    kernels compiled for that many points per thread, so that each candidate is checked."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -523,7 +525,7 @@ def check(got, want):
     assert err < 1e-6, err
     worst = max(worst, err)
 bt.Convolve.FIR_MAX_TAPS_COMPLEX = 0
-for n_fft, n_stream in ((630, 2), (6174, 4), (25725, 2), (131250, 6)):
+for n_fft, n_stream in ((630, 2), (6174, 4), (25725, 2), (131250, 6)) if %r else ():
     n_tap = max(2, min(n_fft // 3, 5000))
     rng = np.random.default_rng(n_fft)
     resp = ((rng.standard_normal((n_tap, n_stream)) + 1j * rng.standard_normal((n_tap, n_stream))) / np.sqrt(n_tap)).astype(np.complex64)
@@ -532,7 +534,7 @@ for n_fft, n_stream in ((630, 2), (6174, 4), (25725, 2), (131250, 6)):
     assert cv._ih_samples_per_frame == n_fft
     want, _ = orc.convolve(x, resp, samples_per_frame=n_fft - n_tap + 1, ih_samples_per_frame=1000)
     check(cv.read(), want)
-for n, n_stream in ((6, 2), (30, 2), (14, 6), (1000, 2), (6174, 2), (5000, 4)):
+for n, n_stream in ((6, 2), (30, 2), (14, 6), (1000, 2), (6174, 2), (5000, 4), (360, 16), (2187, 2)):
     rng = np.random.default_rng(n)
     x = rng.standard_normal((37 * n, 2 * n_stream), dtype=np.float32).view(np.complex64)
     ch = bt.Channelize(bt.DeviceStream(x, '2020-01-01T00:00:00', 1 * u.MHz), n)
@@ -540,8 +542,10 @@ for n, n_stream in ((6, 2), (30, 2), (14, 6), (1000, 2), (6174, 2), (5000, 4)):
     check(z, orc.channelize(x, n))
     check(bt.Dechannelize(bt.DeviceStream(z, '2020-01-01T00:00:00', 1 * u.MHz / n), n).read(), x)
 print('worst rel-L2 %%.2e, modules %%d' %% (worst, bt.hip.rtc_info()['modules']))
-""" % (ROOT, {'0': 'off', 'require': 'required'}[mode])
+""" % (ROOT, {'0': 'off', 'require': 'required'}[mode], points is None)
     env = dict(os.environ, BBT_RTC=mode)
+    if points is not None:
+        env.update(BBT_G2_TUNE='0', BBT_G2_PMAX_CHAN=str(points))
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     modules = int(out.stdout.split()[-1])

@@ -162,7 +162,7 @@ static double rel_err(const std::vector<cd>& want, const float* got4, int stream
 static int run_row(int N1, int N2, int blocks, int reps, bool with_old) {
     const long long N = (long long)N1 * N2;
     G2Plan g;
-    if (!g2_plan(N2, 1, &g)) { printf("cannot factor %d\n", N2); return 1; }
+    if (!g2_plan(N2, 1, &g, g2_pmax(BBT_G2_KIND_ROW))) { printf("cannot factor %d\n", N2); return 1; }
     const G2Plan gr = g2_reversed(g);
     print_geo("row fwd", g);
     print_geo("row inv", gr);
@@ -251,7 +251,7 @@ static int run_row(int N1, int N2, int blocks, int reps, bool with_old) {
 
 static int run_chan(int n, int nspec, int reps, bool with_old) {
     G2Plan g;
-    if (!g2_plan(n, 1, &g)) { printf("cannot factor %d\n", n); return 1; }
+    if (!g2_plan(n, 1, &g, g2_pmax(BBT_G2_KIND_CHAN))) { printf("cannot factor %d\n", n); return 1; }
     print_geo("chan", g);
     cf* wn = upload_tables(g);
     const std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", g) + std::string("BBT_G2_KERNEL_FFT_ROWS(k_chan, GA, -1, ") + (g.threads() >= 448 ? "4" : "0") + ")\n";
@@ -300,7 +300,7 @@ static int run_chan(int n, int nspec, int reps, bool with_old) {
 static int run_col(int N1, int N2, int blocks, int reps, int ct, bool with_old) {
     const long long N = (long long)N1 * N2;
     G2Plan g;
-    if (!g2_plan(N1, ct, &g)) { printf("cannot factor %d\n", N1); return 1; }
+    if (!g2_plan(N1, ct, &g, g2_pmax(BBT_G2_KIND_COL))) { printf("cannot factor %d\n", N1); return 1; }
     print_geo("col", g);
     cf* wn = upload_tables(g);
     const std::string src = "#include \"gen2_kernels.hpp\"\n" + g2_trait_source("GA", g) +
