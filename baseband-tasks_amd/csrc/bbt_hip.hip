@@ -2200,6 +2200,60 @@ extern "C" {
 
 }  // extern "C"
 
+// Scratch device memory of the plans that time their candidates (chan_pick, pfb_pick): ONE buffer
+// per device, allocated when the first such plan is made, grown when a plan needs more, and kept
+// -- mapping and unmapping a GiB per plan preempts every queue of the process and took 0.3-2 s
+// each after a few dozen plans.  1 GiB each way when the card has it to spare (well past the 256
+// MiB memory-side cache: at 256 MiB each way 1536 channels ranked wrongly), at most an eighth of
+// what is free; BBT_TUNE_KEEP=0 frees it after every plan.
+struct TuneScratch {
+    std::mutex mu;
+    std::map<int, std::pair<void*, size_t>> buf;         // device -> (pointer, bytes)
+};
+static TuneScratch& tune_scratch() {
+    static TuneScratch* t = new TuneScratch;              // (never destroyed: the runtime may be gone by then)
+    return *t;
+}
+// A buffer of at least `least` bytes (as much as `want` if the card has it to spare); null if not to be had.
+// The caller holds it until tune_release(): plans are made one at a time (the mutex is held).
+static void* tune_acquire(size_t least, size_t want, size_t* got) {
+    TuneScratch& t = tune_scratch();
+    t.mu.lock();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        t.mu.unlock();
+        return nullptr;
+    }
+    auto& slot = t.buf[dev];
+    if (slot.second < least) {
+        if (slot.first) hipFree(slot.first);
+        slot = {nullptr, 0};
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        size_t bytes = std::max(least, std::min(want, free_b / 4));
+        void* ptr = nullptr;
+        if (bytes > free_b / 2 || hipMalloc(&ptr, bytes) != hipSuccess) {
+            hipGetLastError();
+            t.mu.unlock();
+            return nullptr;
+        }
+        slot = {ptr, bytes};
+    }
+    *got = slot.second;
+    return slot.first;
+}
+static void tune_release() {
+    TuneScratch& t = tune_scratch();
+    if (getenv("BBT_TUNE_KEEP") && !strcmp(getenv("BBT_TUNE_KEEP"), "0")) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && t.buf[dev].first) {
+            hipFree(t.buf[dev].first);
+            t.buf[dev] = {nullptr, 0};
+        }
+    }
+    t.mu.unlock();
+}
+
 // One candidate of a generic-length channelizer plan on the compiled kernels: columns of a
 // workgroup = cp neighbouring stream pairs (up to 8: 128-byte pieces of a complete sample, as
 // many as divide the pair count) x consecutive transforms while they still fit ONE wave (a
@@ -2251,19 +2305,16 @@ static int chan_pick(bbt_chan_plan* p, int n_chan, int direction) {
         p->k2 = nullptr;
         return 0;
     }
-    // time the candidates on scratch memory: 1 GiB each way when the card has it to spare (well
-    // past the 256 MiB memory-side cache: at 256 MiB the general kernel looked as fast as the
-    // 10-point one for 1536 channels, from HBM it is 150 against 171 G)
+    // time the candidates on scratch memory (tune_acquire), from HBM as in use, on the null stream (a
+    // stream of its own would be one more hardware queue made and destroyed per plan)
     const size_t per = (size_t)n_chan * p->S * sizeof(cf);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    const size_t target = std::min<size_t>((size_t)1 << 30, free_b / 8);
-    const int64_t ns = (int64_t)std::max<size_t>(8, target / per);
-    void *a = nullptr, *b = nullptr;
+    size_t got = 0;
+    char* base = (char*)tune_acquire(16 * per, (size_t)2 << 30, &got);
+    const int64_t ns = (int64_t)(got / (2 * per));
+    void *a = base, *b = base ? base + ns * per : nullptr;
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool ready = hipMalloc(&a, ns * per) == hipSuccess && hipMalloc(&b, ns * per) == hipSuccess &&
-                 hipMemsetAsync(a, 0, ns * per, nullptr) == hipSuccess && hipStreamCreate(&st) == hipSuccess &&
+    bool ready = base && hipMemsetAsync(a, 0, ns * per, nullptr) == hipSuccess &&
                  hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
                  hipDeviceSynchronize() == hipSuccess;
     auto time_current = [&]() -> float {
@@ -2305,11 +2356,9 @@ static int chan_pick(bbt_chan_plan* p, int n_chan, int direction) {
         }
         *p = best_plan;
     }
-    if (a) hipFree(a);
-    if (b) hipFree(b);
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
-    if (st) hipStreamDestroy(st);
+    if (base) tune_release();
     if (!ready) {                                                       // (no scratch memory: the rule, untimed)
         hipGetLastError();
         if (chan_candidate(p, n_chan, direction, g2_pmax(BBT_G2_KIND_CHAN))) {
@@ -2488,10 +2537,19 @@ struct bbt_pfb_plan {
     FftTables tab;
     FftTables tab4096;   // for the sliding-window kernel
     bool window = false;
+    // several stream pairs per workgroup of the sliding-window kernel (pp > 1: geometry gn, tables tabg,
+    // taps_quads permuted for gn / 16 threads)
+    int pp = 1, gn = 4096, gl = 0;
+    FftTables tabg;
+    float* taps_quads_pp = nullptr;
     // many streams: the window as a streaming pass over whole rows (k_pfb_fir_rows), then the
     // transform in place through a channelizer plan (k_fft_rows_pp)
     bbt_chan_plan* two_pass = nullptr;
 };
+
+// geometry of one pair in the several-pairs form of the window kernel: 128 threads and 2048 / N
+// spectra per workgroup up to 1024 channels, 256 threads and two spectra for 2048
+static constexpr int pfb_pp_geometry(int n) { return n <= 1024 ? 2048 : 4096; }
 
 template <int N, int NTAP>
 static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* out, int64_t n_spec,
@@ -2505,6 +2563,21 @@ static void launch_pfb_window(const bbt_pfb_plan* p, const float2* in, float2* o
         else
             hipLaunchKernelGGL((k_pfb_window<N, NTAP, true>), dim3(gx), dim3(256), 0, st, in, out,
                                (long long)n_spec, 1, p->taps_quads, p->tab4096.tw0, p->tab4096.tw1);
+        return;
+    }
+    if (p->pp > 1) {            // several pairs per workgroup (many streams): pfb_pick
+        constexpr int GN = pfb_pp_geometry(N);
+        const unsigned gy = (unsigned)((n_spec + GN / N - 1) / (GN / N));
+        if (p->pp == 4)
+            hipLaunchKernelGGL((k_pfb_window<N, NTAP, false, false, 4, GN>), dim3(gy * (p->npair / 4)),
+                               dim3(GN / 16 * 4), 0, st, in, out, (long long)n_spec, p->S, p->taps_quads_pp,
+                               p->tabg.tw0, p->tabg.tw1, p->gl);
+        if constexpr (GN == 2048) {
+            if (p->pp == 8)
+                hipLaunchKernelGGL((k_pfb_window<N, NTAP, false, false, 8, GN>), dim3(gy * (p->npair / 8)),
+                                   dim3(GN / 16 * 8), 0, st, in, out, (long long)n_spec, p->S, p->taps_quads_pp,
+                                   p->tabg.tw0, p->tabg.tw1, p->gl);
+        }
         return;
     }
     const unsigned gx = (unsigned)((n_spec + NG - 1) / NG);
@@ -2541,6 +2614,139 @@ static void launch_pfb(const bbt_pfb_plan* p, const float2* in, float2* out, int
                        (long long)n_spec, p->S, p->n_tap, p->taps, p->tab.tw0, p->tab.tw1);
 }
 
+// Which route a filter-bank plan takes.  Measured on MI355X (round 5, 1024 channels, G
+// stream-samples/s at 16 / 128 / 2048 streams): one pair per workgroup (16 bytes of every complete
+// sample per lane) 4 taps 140 / 99 / 82, 12 taps 107 / 54 / 54; two passes (window over whole rows,
+// transform in place: 33 bytes per stream-sample instead of 16) 150 / 159 / 146 and 144 / 154 / 133;
+// several pairs per workgroup, lanes over the pairs first (64- or 128-byte runs): 4 taps
+// 223 / 228 / 186, 12 taps 148 / 131 / 130 -- with 128 registers and at most two workgroups per CU
+// its NTAP + NG - 1 row loads for NG spectra weigh more the more taps there are.  Which of them
+// and which order of workgroups wins depends on taps, channels and streams, so the candidates
+// are timed once on scratch memory (as chan_pick) and the choice is remembered for the process.
+// BBT_PFB_TUNE=0: the round-4 rule (two passes from 16 streams on); BBT_PFB_TWO_PASS=0 / 1,
+// BBT_PFB_PP=4 / 8 (+ BBT_PFB_GL) force a route (dev).
+static int pfb_pick(bbt_pfb_plan* p, bool pp_ok) {
+    const int n_tap = p->n_tap, n_stream = p->S;
+    const bool two_ok = !p->split_real && n_stream >= 2 && (n_tap == 4 || n_tap == 8 || n_tap == 12 || n_tap == 16);
+    const char* env2 = getenv("BBT_PFB_TWO_PASS");
+    const char* envp = getenv("BBT_PFB_PP");
+    auto set_pp = [&](int pp, int gl) {
+        p->pp = pp;
+        p->gl = (gl > 0 && (p->npair / pp) % gl == 0) ? gl : 0;
+    };
+    auto need_two_pass = [&]() -> int {
+        return p->two_pass ? 0 : bbt_chan_plan_create(&p->two_pass, p->n, n_stream, -1);
+    };
+    if (envp && pp_ok) {
+        const int pp = atoi(envp);
+        if ((pp == 4 || (pp == 8 && p->gn == 2048)) && p->npair % pp == 0) {
+            set_pp(pp, getenv("BBT_PFB_GL") ? atoi(getenv("BBT_PFB_GL")) : 0);
+            return 0;
+        }
+    }
+    // (two passes also where no sliding-window kernel exists and every spectrum would re-read its rows:
+    // 16 x 4096 on two streams 64.4 -> 84.2 G complete samples/s, 0.26 -> 0.34; with a window kernel one
+    // pass wins on few streams: 8 x 2048 125 against 91, 4 x 1024 164 against 88)
+    const bool rule_two = two_ok && (n_stream >= 16 || (!p->window && n_tap >= 8));
+    if (env2) return (two_ok && atoi(env2) != 0) ? need_two_pass() : 0;
+    const bool tune = !(getenv("BBT_PFB_TUNE") && !strcmp(getenv("BBT_PFB_TUNE"), "0"));
+    if (!pp_ok || !tune || n_stream < 8) return rule_two ? need_two_pass() : 0;
+
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> chosen;   // -> (pp: 0 two passes, 1 one pair; gl)
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const auto key = std::make_tuple(dev, p->n, n_tap, n_stream);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = chosen.find(key);
+        if (it != chosen.end()) {
+            if (it->second.first == 0) return need_two_pass();
+            if (it->second.first > 1) set_pp(it->second.first, it->second.second);
+            return 0;
+        }
+    }
+    if (two_ok && need_two_pass()) return 1;
+    bbt_chan_plan* const tp = p->two_pass;
+    const size_t per = (size_t)p->n * p->S * sizeof(cf);
+    const auto t_start = std::chrono::steady_clock::now();
+    auto trace = [&](const char* what, int x = 0, int y = 0) {
+        if (!getenv("BBT_PFB_TRACE")) return;
+        fprintf(stderr, "bbt: pfb_pick %d x %d on %d streams, %8.3f ms: %s %d %d\n", n_tap, p->n, n_stream,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what, x, y);
+        fflush(stderr);
+    };
+    trace("allocating");
+    // (scratch memory: tune_acquire; on the null stream, as chan_pick)
+    size_t got = 0;
+    char* base = (char*)tune_acquire((2 * 16 + n_tap) * per, (size_t)2 << 30, &got);
+    const int64_t ns = base ? (int64_t)((got - (n_tap - 1) * per) / (2 * per)) : 0;
+    void *a = base, *b = base ? base + (ns + n_tap - 1) * per : nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool ready = base && hipMemsetAsync(a, 0, (ns + n_tap - 1) * per, nullptr) == hipSuccess &&
+                       hipEventCreate(&e0) == hipSuccess &&
+                       hipEventCreate(&e1) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    trace("allocated");
+    struct Cand { int pp, gl; };
+    std::vector<Cand> cands;
+    if (two_ok) cands.push_back({0, 0});
+    if (n_stream < 16) cands.push_back({1, 0});
+    cands.push_back({4, 0});
+    if ((p->npair / 4) % 4 == 0) cands.push_back({4, 4});
+    if (p->gn == 2048 && p->npair % 8 == 0) {
+        cands.push_back({8, 0});
+        if (p->npair / 8 > 1) cands.push_back({8, 1});
+    }
+    Cand best = rule_two ? Cand{0, 0} : Cand{1, 0};
+    float best_ms = 1e30f;
+    for (const Cand& c : cands) {
+        if (!ready) break;
+        p->two_pass = c.pp == 0 ? tp : nullptr;
+        p->pp = 1;
+        p->gl = 0;
+        if (c.pp > 1) set_pp(c.pp, c.gl);
+        float ms = 1e30f;
+        trace("candidate", c.pp, c.gl);
+        if (!bbt_pfb_execute(p, a, b, ns, st)) {
+            for (int r = 0; r < 2; ++r) {
+                float t = 0.f;
+                if (hipEventRecord(e0, st) != hipSuccess || bbt_pfb_execute(p, a, b, ns, st) ||
+                    hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                    hipEventElapsedTime(&t, e0, e1) != hipSuccess) {
+                    ms = 1e30f;
+                    break;
+                }
+                ms = std::min(ms, t);
+            }
+        }
+        if (getenv("BBT_RTC_VERBOSE"))
+            fprintf(stderr, "bbt: PolyphaseFilterBank %d x %d on %d streams, %s (pairs %d, order %d): %.3f ms\n", n_tap, p->n,
+                    n_stream, c.pp == 0 ? "two passes" : "one pass", c.pp, c.gl, ms);
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = c;
+        }
+    }
+    trace("timed");
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (base) tune_release();
+    if (!ready) hipGetLastError();
+    trace("freed");
+    p->two_pass = nullptr;
+    p->pp = 1;
+    p->gl = 0;
+    if (best.pp == 0) p->two_pass = tp;
+    else if (tp) bbt_chan_plan_destroy(tp);
+    if (best.pp > 1) set_pp(best.pp, best.gl);
+    if (ready) {
+        std::lock_guard<std::mutex> lock(mu);
+        chosen[key] = std::make_pair(best.pp, p->gl);
+    }
+    return 0;
+}
+
 extern "C" {
 
 int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream,
@@ -2570,44 +2776,41 @@ int bbt_pfb_plan_create(bbt_pfb_plan** plan, int n_tap, int n_chan, int n_stream
         return fail("bbt_pfb_plan_create: one stream needs n_chan in 256..2048 and 4, 8, 12 or 16 taps "
                     "(got %d x %d); pad to two streams otherwise", n_tap, n_chan);
     }
-    if ((p->window && get_tables(4096, &p->tab4096)) ||
+    // several stream pairs per workgroup of the window kernel are possible for (pfb_pick chooses)
+    const bool pp_ok = p->window && !split_real && n_chan <= 2048 && p->npair % 4 == 0;
+    p->gn = pp_ok ? pfb_pp_geometry(n_chan) : 4096;
+    if ((pp_ok && get_tables(p->gn, &p->tabg)) ||
+        (p->window && get_tables(4096, &p->tab4096)) ||
         get_tables(n_chan, &p->tab) || hipMalloc((void**)&p->taps, tb) != hipSuccess ||
         hipMemcpy(p->taps, taps_host, tb, hipMemcpyHostToDevice) != hipSuccess) {
         if (g_err.empty()) fail("bbt_pfb_plan_create: tap upload failed");
         bbt_pfb_plan_destroy(p);
         return 1;
     }
-    // Two passes from 16 streams on (MI355X, round 5, 4 / 12 x 1024, G stream-samples/s one pass ->
-    // two: 8 streams 199 / 160 -> 159 / 152, 16 streams 140 / 107 -> 150 / 144, 128 streams
-    // 99 / 54 -> 159 / 154, 2048 streams 82 / 54 -> 141-146 / 130-133); BBT_PFB_TWO_PASS=0 / 1 overrides.
-    {
-        const char* env = getenv("BBT_PFB_TWO_PASS");
-        const bool ok = !split_real && n_stream >= 2 && (n_tap == 4 || n_tap == 8 || n_tap == 12 || n_tap == 16);
-        // (also where no sliding-window kernel exists and every spectrum would re-read its rows: 16 x 4096 on
-        // two streams 64.4 -> 84.2 G complete samples/s, 0.26 -> 0.34; with a window kernel one pass wins:
-        // 8 x 2048 125 against 91, 4 x 1024 164 against 88)
-        const bool want = env ? atoi(env) != 0 : (n_stream >= 16 || (!p->window && n_tap >= 8));
-        if (ok && want && bbt_chan_plan_create(&p->two_pass, n_chan, n_stream, -1)) {
-            bbt_pfb_plan_destroy(p);
-            return 1;
+    if (p->window) {
+        // taps of column tau + T c, four at a time: quads[((c * n_tap / 4) + q) * T + tau][k] = h[4 q + k]
+        // (T = 256 threads per pair; gn / 16 in the several-pairs form)
+        for (int form = 0; form < (pp_ok ? 2 : 1); ++form) {
+            const int T = form ? p->gn / 16 : 256, cols = n_chan / T, quads = n_tap / 4;
+            std::vector<float> perm((size_t)n_tap * n_chan);
+            for (int c = 0; c < cols; ++c)
+                for (int q = 0; q < quads; ++q)
+                    for (int tau = 0; tau < T; ++tau)
+                        for (int k = 0; k < 4; ++k)
+                            perm[(((size_t)c * quads + q) * T + tau) * 4 + k] =
+                                taps_host[(size_t)(4 * q + k) * n_chan + tau + T * c];
+            float** dst = form ? &p->taps_quads_pp : &p->taps_quads;
+            if (hipMalloc((void**)dst, tb) != hipSuccess ||
+                hipMemcpy(*dst, perm.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
+                fail("bbt_pfb_plan_create: tap upload failed");
+                bbt_pfb_plan_destroy(p);
+                return 1;
+            }
         }
     }
-    if (p->window) {
-        // taps of column tau + 256 c, four at a time: quads[((c * n_tap / 4) + q) * 256 + tau][k] = h[4 q + k]
-        const int cols = n_chan / 256, quads = n_tap / 4;
-        std::vector<float> perm((size_t)n_tap * n_chan);
-        for (int c = 0; c < cols; ++c)
-            for (int q = 0; q < quads; ++q)
-                for (int tau = 0; tau < 256; ++tau)
-                    for (int k = 0; k < 4; ++k)
-                        perm[(((size_t)c * quads + q) * 256 + tau) * 4 + k] =
-                            taps_host[(size_t)(4 * q + k) * n_chan + tau + 256 * c];
-        if (hipMalloc((void**)&p->taps_quads, tb) != hipSuccess ||
-            hipMemcpy(p->taps_quads, perm.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
-            fail("bbt_pfb_plan_create: tap upload failed");
-            bbt_pfb_plan_destroy(p);
-            return 1;
-        }
+    if (pfb_pick(p, pp_ok)) {
+        bbt_pfb_plan_destroy(p);
+        return 1;
     }
     *plan = p;
     return 0;
@@ -2617,6 +2820,7 @@ int bbt_pfb_plan_destroy(bbt_pfb_plan* p) {
     if (!p) return 0;
     if (p->two_pass) bbt_chan_plan_destroy(p->two_pass);
     if (p->taps_quads) hipFree(p->taps_quads);
+    if (p->taps_quads_pp) hipFree(p->taps_quads_pp);
     if (p->taps) hipFree(p->taps);
     delete p;
     return 0;

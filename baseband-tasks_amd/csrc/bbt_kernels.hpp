@@ -1491,22 +1491,39 @@ __global__ __launch_bounds__(256) void k_pfb_fir_rows(const float4* __restrict__
 // [i0, i0 + NG) and [i0 + NG, i0 + 2 NG) of the one stream (rows NG further on).
 // SPLIT (with SINGLE): the one stream is z = a + i b of two real streams and the
 // half spectra of a and b are written, as in k_fft_rows.
-template <int N, int NTAP, bool SINGLE = false, bool SPLIT = false>
-__global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ in,
-                                                    float2* __restrict__ out, long long n_spec,
-                                                    int S, const float* __restrict__ taps,
-                                                    const cf* __restrict__ tw0,
-                                                    const cf* __restrict__ tw1) {
-    typedef FftGeo<4096> G;
-    constexpr int T = 256;
-    constexpr int NG = 4096 / N;       // spectra per workgroup
+// MANY streams (PP > 1): PP neighbouring stream pairs per workgroup, lanes over the pairs first
+// (thread = pp + PP tau), so that a wave's load of one row takes PP * 16 contiguous bytes of
+// each of 64 / PP complete samples instead of 16 bytes out of 64 lines; each pair is the
+// one-pair kernel on T = GN / 16 threads of a GN-point geometry: NG = GN / N spectra per
+// workgroup, its own exchange area.
+template <int N, int NTAP, bool SINGLE = false, bool SPLIT = false, int PP = 1, int GN = 4096>
+__global__ __launch_bounds__(GN / 16 * PP, (GN / 16 * PP == 512 ? 4 : 1))      // (512 threads: two workgroups per CU)
+void k_pfb_window(const float2* __restrict__ in, float2* __restrict__ out, long long n_spec,
+                  int S, const float* __restrict__ taps, const cf* __restrict__ tw0,
+                  const cf* __restrict__ tw1, int GL = 0) {
+    static_assert((PP == 1 && GN == 4096) || (!SINGLE && !SPLIT), "several pairs: plain stream pairs only");
+    typedef FftGeo<GN> G;
+    constexpr int T = GN / 16;
+    constexpr int NG = GN / N;         // spectra per workgroup
     constexpr int P = 16 / NG;         // columns per thread
-    __shared__ v2 lds[G::LDS_ELEMS];
-    const int tau = threadIdx.x;
+    static_assert(P >= 1 && P <= 8, "GN = N NG with 2 <= NG <= 16");
+    constexpr int REGION = G::LDS_ELEMS + (PP > 1 ? 8 : 0);          // (pairs side by side start 8 banks apart)
+    __shared__ v2 lds_all[PP * REGION];
+    const int tau = threadIdx.x / PP, pp = threadIdx.x % PP;
+    v2* lds = lds_all + pp * REGION;
     const int npair = SINGLE ? 1 : S >> 1;
+    const int ngrp = npair / PP;                                      // (the host checks npair % PP == 0)
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
-    const long long i0 = (long long)(vb / npair) * (SINGLE ? 2 * NG : NG);   // first spectrum of this workgroup
-    const int sp = vb % npair;
+    // Order of the workgroups: the GL pair groups that share 128-byte lines first, then the
+    // spectra, then the further pair groups -- an XCD then walks along the spectra of one slab of
+    // columns and finds the NTAP - 1 rows it shares with the previous workgroup in its L2 (GL = 0:
+    // all pair groups first, as the one-pair kernel always did).
+    const unsigned gl = (PP > 1 && GL > 0) ? (unsigned)GL : (unsigned)ngrp;
+    const unsigned n_sg = gridDim.x / ngrp;
+    const unsigned lo = vb % gl, rest = vb / gl;
+    const unsigned grp = (rest / n_sg) * gl + lo;
+    const long long i0 = (long long)(rest % n_sg) * (SINGLE ? 2 * NG : NG);   // first spectrum of this workgroup
+    const int sp = grp * PP + pp;
     c2 v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = czero();
@@ -1536,7 +1553,9 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
         // rows past the end of the stream (last workgroup only): read the last
         // existing row instead and zero it, so the loads stay branch free
         constexpr int NR = NTAP + NG - 1;
-        constexpr int RB = (BBT_PFB_BATCH < NR) ? BBT_PFB_BATCH : NR;      // rows in flight per batch
+        // (512 threads and more: 128 registers, so the rows in two or three batches)
+        constexpr int RBMAX = (GN / 16 * PP >= 512) ? ((NR + 1) / 2 < 8 ? (NR + 1) / 2 : 8) : BBT_PFB_BATCH;
+        constexpr int RB = (RBMAX < NR) ? RBMAX : NR;                      // rows in flight per batch
 #pragma unroll
         for (int r0 = 0; r0 < NR; r0 += RB) {
             c2 x[RB];
@@ -1598,7 +1617,7 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
 #pragma unroll
         for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
     }
-    wg_fft_tail<4096, -1, 0, 0, BBT_PFB_TW_POW>(v, lds, tau, 0, tw1);
+    wg_fft_tail<GN, -1, 0, 0, BBT_PFB_TW_POW>(v, lds, tau, 0, tw1);
     const int f = tau & 15, g = tau >> 4;
     const int q = f / P, c = f - q * P;
     if constexpr (SINGLE && SPLIT) {
@@ -1700,10 +1719,12 @@ __global__ __launch_bounds__(256) void k_pfb_window(const float2* __restrict__ i
         return;
     }
     if (i0 + q < n_spec) {
+        // register u + U c2 holds output k' = g + R2 u + 16 c2 of the thread's sequence (wg_fft_tail)
+        constexpr int R2 = G::R2, U = 16 / R2;
         float2* dst = out + (((i0 + q) * N + c) * S + 2 * sp);
 #pragma unroll
-        for (int c2i = 0; c2i < 16; ++c2i)
-            st_ext(dst + (long long)(P * (g + 16 * c2i)) * S, v[c2i], S == 2);
+        for (int reg = 0; reg < 16; ++reg)
+            st_ext(dst + (long long)(P * (g + R2 * (reg % U) + 16 * (reg / U))) * S, v[reg], S == 2);
     }
 }
 

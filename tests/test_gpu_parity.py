@@ -419,6 +419,31 @@ def test_filter_bank_on_many_streams(sample_shape, n_tap, n_chan):
     assert_parity(z, want, f'pfb {n_tap} x {n_chan} on {sample_shape}')
 
 
+@pytest.mark.parametrize('route', [dict(BBT_PFB_TWO_PASS='1'), dict(BBT_PFB_TWO_PASS='0'), dict(BBT_PFB_PP='4'),
+                                   dict(BBT_PFB_PP='4', BBT_PFB_GL='4'), dict(BBT_PFB_PP='8'),
+                                   dict(BBT_PFB_PP='8', BBT_PFB_GL='1'), dict(BBT_PFB_TUNE='0'), {}],
+                         ids=lambda r: '-'.join(f'{k[8:]}{v}' for k, v in r.items()) or 'timed')
+@pytest.mark.parametrize('n_tap,n_chan', [(4, 1024), (12, 256), (16, 512), (8, 2048)])
+def test_filter_bank_routes_on_many_streams(route, n_tap, n_chan, monkeypatch):
+    """A filter-bank plan on 8 streams and more times its routes and keeps the fastest (bbt_hip.hip
+    pfb_pick): two passes, one pair per workgroup, or 4 / 8 neighbouring pairs per workgroup with the
+    lanes over the pairs first, in two orders of the workgroups.  Every route forced in turn, on
+    32 streams and a ragged number of spectra, against the oracle (reference pfb.py:91-100,
+    136-154)."""
+    for k, v in route.items():
+        monkeypatch.setenv(k, v)
+    sample_shape = (16, 2)
+    n_spec = 96 + 37
+    n_in = (n_spec + n_tap - 1) * n_chan
+    rng = np.random.default_rng(n_chan + n_tap)
+    x = rng.standard_normal((n_in,) + sample_shape + (2,), dtype=np.float32).view(np.complex64)[..., 0]
+    pfb = bt.PolyphaseFilterBank(bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=n_in), bt.sinc_hamming(n_tap, n_chan),
+                                 samples_per_frame=n_spec)
+    z = pfb.read()
+    want, _ = orc.polyphase_filter_bank(x.reshape(n_in, -1), orc.sinc_hamming(n_tap, n_chan), n_in, samples_per_frame=n_spec)
+    assert_parity(z, want.reshape((want.shape[0], n_chan) + sample_shape), f'pfb {n_tap} x {n_chan}, route {route}')
+
+
 # --------------------------------------------------------------------------- small, complete outputs
 def test_small_dedisperse_two_sidebands_golden(golden):
     nh = noise(10000, (2,), 4000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,

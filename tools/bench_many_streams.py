@@ -23,9 +23,9 @@ for S in ((4, 8, 16, 128, 2048) if os.environ.get('CHAN', '1') != '0' else ()):
         print(f"S={S:5d} Channelize({nc:4d}): {t.shape[0] * nc * S / dt / 1e9:7.1f} G stream-samples/s", flush=True)
     del ds, x
 
-# PolyphaseFilterBank on the same stream counts (PFB=0 skips; BBT_PFB_TWO_PASS=0 / 1 forces the route)
+# PolyphaseFilterBank on the same stream counts (PFB=0 skips; PFB_S=16,128: only those stream counts; BBT_PFB_TWO_PASS=0 / 1 forces the route)
 if os.environ.get('PFB', '1') != '0':
-    for S in (2, 4, 8, 16, 128, 2048):
+    for S in [int(a) for a in os.environ.get('PFB_S', '2,4,8,16,128,2048').split(',')]:
         n = (2**28) // S
         x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
         ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 1e6, samples_per_frame=2**16 if S > 2 else 2**20, frequency=300e6, sideband=1)
