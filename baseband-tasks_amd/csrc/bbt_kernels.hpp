@@ -1507,10 +1507,12 @@ void k_pfb_window(const float2* __restrict__ in, float2* __restrict__ out, long 
     constexpr int NG = GN / N;         // spectra per workgroup
     constexpr int P = 16 / NG;         // columns per thread
     static_assert(P >= 1 && P <= 8, "GN = N NG with 2 <= NG <= 16");
-    constexpr int REGION = G::LDS_ELEMS + (PP > 1 ? 8 : 0);          // (pairs side by side start 8 banks apart)
-    __shared__ v2 lds_all[PP * REGION];
+    // (several pairs: their exchange areas interleaved element by element, the pair fastest like the
+    // lanes -- COLMODE = PP of fft_core.hpp: side by side in areas of their own 48 % (PP = 4) and 74 % (8)
+    // of the LDS cycles were bank conflicts)
+    constexpr int CM = PP > 1 ? PP : 0;
+    __shared__ v2 lds[PP * G::LDS_ELEMS];
     const int tau = threadIdx.x / PP, pp = threadIdx.x % PP;
-    v2* lds = lds_all + pp * REGION;
     const int npair = SINGLE ? 1 : S >> 1;
     const int ngrp = npair / PP;                                      // (the host checks npair % PP == 0)
     const unsigned vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -1617,7 +1619,7 @@ void k_pfb_window(const float2* __restrict__ in, float2* __restrict__ out, long 
 #pragma unroll
         for (int q = 0; q < NG; ++q) v[q * P + c] = twmul<-1>(v[q * P + c], w);
     }
-    wg_fft_tail<GN, -1, 0, 0, BBT_PFB_TW_POW>(v, lds, tau, 0, tw1);
+    wg_fft_tail<GN, -1, CM, 0, BBT_PFB_TW_POW>(v, lds, tau, pp, tw1);
     const int f = tau & 15, g = tau >> 4;
     const int q = f / P, c = f - q * P;
     if constexpr (SINGLE && SPLIT) {

@@ -351,36 +351,39 @@ __device__ __forceinline__ void fft_exchange1_stage2(c2 (&v)[16], v2* __restrict
     constexpr int R2 = G::R2;
     if constexpr (R2 > 1) {
         constexpr int NU = 16 / R2;
+        // (COLMODE 4 / 8: a few transforms interleaved, lanes over them first -- the many-stream filter
+        // bank -- so 16 lanes of a write are 4 or 2 consecutive b1: their rows must differ by an odd pitch)
+        constexpr int PB1 = ((COLMODE == 4 || COLMODE == 8) && G::PB1 % 2 == 0) ? G::PB1 - 1 : G::PB1;
         const int c0s = tau / R2, b1 = tau % R2;
         const int c0r = tau & 15, g = tau >> 4;
         v2* __restrict__ lds_im = lds + IMOFF;
         c2 t[NU][R2];
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].re;
+        for (int c = 0; c < 16; ++c) lds[lds_idx<COLMODE>(c * G::PC1 + b1 * PB1 + c0s, f)] = v[c].re;
         if (IMOFF) {
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                lds_im[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
+                lds_im[lds_idx<COLMODE>(c * G::PC1 + b1 * PB1 + c0s, f)] = v[c].im;
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int bb = 0; bb < R2; ++bb)
-                t[u][bb].re = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
+                t[u][bb].re = lds[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * PB1 + c0r, f)];
         if (!IMOFF) {
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                lds[lds_idx<COLMODE>(c * G::PC1 + b1 * G::PB1 + c0s, f)] = v[c].im;
+                lds[lds_idx<COLMODE>(c * G::PC1 + b1 * PB1 + c0s, f)] = v[c].im;
             __syncthreads();
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int bb = 0; bb < R2; ++bb)
-                t[u][bb].im = lds_im[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * G::PB1 + c0r, f)];
+                t[u][bb].im = lds_im[lds_idx<COLMODE>((g + R2 * u) * G::PC1 + bb * PB1 + c0r, f)];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             radixR<SIGN, R2>(t[u]);
