@@ -284,7 +284,7 @@ class Channelize(_RowFFTTask):
         if dd is None or dd._single or dd._ih_samples_per_frame > (1 << 20) or self._n < MIN_FFT_LEN:
             return False
         plan = dd._get_plan()
-        if plan.info()['n1'] != 256 or plan.detect_bins_max(self._n, step) > 64:
+        if plan.info()['n1'] != 256 or (step > 1 and plan.detect_bins_max(self._n, step) > 64):
             return False
         n, spf = self._n, dd.samples_per_frame
         start, stop = first_spectrum, first_spectrum + n_bins * step

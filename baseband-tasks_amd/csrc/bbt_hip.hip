@@ -1992,11 +1992,12 @@ int bbt_osm_execute_channelized_detect(bbt_osm_plan* p, const void* in_dev, void
             who);
     ARG_TRY(step >= 1 && n_bins >= 0 && (mode == 0 || mode == 1), "%s: bad step/bins/mode", who);
     ARG_TRY(n_bins * (int64_t)step < (1ll << 40), "%s: too many spectra", who);
-    ARG_TRY(bbt_osm_detect_bins_max(p, n_chan, step) <= BBT_DET_MAX_BINS,
+    // (step 1 -- Square / Power without integration -- stores every power itself: no bins, no zeroing)
+    ARG_TRY(step == 1 || bbt_osm_detect_bins_max(p, n_chan, step) <= BBT_DET_MAX_BINS,
             "%s: step=%d is too short for %d channels on rows of %d (a workgroup would touch more "
             "than %d bins)", who, step, n_chan, p->n2, BBT_DET_MAX_BINS);
     const size_t out_bytes = (size_t)n_bins * n_chan * p->npair * (mode ? 4 : 2) * sizeof(float);
-    if (out_bytes) HIP_TRY(hipMemsetAsync(out_dev, 0, out_bytes, (hipStream_t)stream));
+    if (out_bytes && step > 1) HIP_TRY(hipMemsetAsync(out_dev, 0, out_bytes, (hipStream_t)stream));
     take.give_back(p);
     return osm_channelized(p, who, in_dev, out_dev, n_blocks, in_off, out_off, valid_start,
                            valid_count, n_chan, first_spectrum, n_bins * step, step, mode,

@@ -914,6 +914,7 @@ __global__ __launch_bounds__(FCOL * (N1 / 16)) void k_osm_col256(const float2* _
             const int ch0 = (n2 - f) & (cur.nch - 1);
             const int nb = (int)((s_wg + 255ll * spr) / step - b_wg) + 1;   // local bins (<= BBT_DET_MAX_BINS)
             float4 p[16];
+            unsigned whole = 0;                                      // (bit j: p[j] is a spectrum of this call)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 int rel = cur.rel + j * cur.drel;
@@ -930,8 +931,24 @@ __global__ __launch_bounds__(FCOL * (N1 / 16)) void k_osm_col256(const float2* _
                     st_ext(cur.seam1, v[j]);
                 }
                 const long long sj = cur.s0 + j * cur.ds;
-                p[j] = (full && sj >= 0 && sj < cur.n_out) ? detect_pair(v[j], mode)
-                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool mine = full && sj >= 0 && sj < cur.n_out;
+                whole |= (unsigned)mine << j;
+                p[j] = mine ? detect_pair(v[j], mode) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (step == 1) {
+                // Square / Power without integration: every power is final, so it is stored where the
+                // spectrum would have gone -- no sums, no atomics, no zeroed output
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (!((whole >> j) & 1)) continue;
+                    float* dst = so.det + detect_index(cur.s0 + j * cur.ds, ch0 + f, sp, so.lg_chan, npair, mode);
+                    if (mode)
+                        *reinterpret_cast<float4*>(dst) = make_float4(p[j].x * so.det_scale, p[j].y * so.det_scale,
+                                                                      p[j].z * so.det_scale, p[j].w * so.det_scale);
+                    else
+                        *reinterpret_cast<float2*>(dst) = make_float2(p[j].x * so.det_scale, p[j].y * so.det_scale);
+                }
+                return;
             }
             const int npass = mode ? 2 : 1;
             for (int pass = 0; pass < npass; ++pass) {
@@ -1345,6 +1362,14 @@ __global__ __launch_bounds__(NCH / 16) void k_seam_fix(const float2* __restrict_
         for (int j = 0; j < 16; ++j) {
             const float4 pw = detect_pair(va[j], so.det_mode);
             float* dst = so.det + detect_index(bin, tau + T * j, sp, so.lg_chan, npair, so.det_mode);
+            if (so.det_step == 1) {                          // (no integration: the value itself)
+                if (so.det_mode)
+                    *reinterpret_cast<float4*>(dst) = make_float4(pw.x * so.det_scale, pw.y * so.det_scale,
+                                                                  pw.z * so.det_scale, pw.w * so.det_scale);
+                else
+                    *reinterpret_cast<float2*>(dst) = make_float2(pw.x * so.det_scale, pw.y * so.det_scale);
+                continue;
+            }
             unsafeAtomicAdd(dst + 0, pw.x * so.det_scale);
             unsafeAtomicAdd(dst + 1, pw.y * so.det_scale);
             if (so.det_mode) {

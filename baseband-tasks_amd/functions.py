@@ -39,6 +39,13 @@ class _DetectTask(DeviceTaskMixin, TaskBase):
 
     def _compute_frames(self, first, last, out):
         start, stop = self._frame_span(first, last)
+        # a channelizer on top of an overlap-save task detects in that task's last pass: the
+        # spectra are never stored (as `Integrate` of this task does, with sums)
+        fused = getattr(self.ih, '_compute_detected', None)
+        if (fused is not None and not self._real and getattr(self, '_inner', 1) == 1
+                and not getattr(self.ih, 'closed', False)
+                and fused(start, stop - start, 1, self._mode, False, out)):
+            return
         x = fetch_device(self.ih, start, stop - start)
         self._detect(x, stop - start, 1, out)
 

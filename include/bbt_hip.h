@@ -243,7 +243,10 @@ int bbt_osm_execute_channelized(bbt_osm_plan* plan, const void* in_dev, void* ou
  * (|z|^2 per stream); average != 0 divides by step.  Sums are formed with float
  * atomics, so the last bits depend on the order of arrival.  Needs block lengths
  * 2^16..2^20 and bbt_osm_detect_bins_max(plan, n_chan, step) <= 64 (e.g. step
- * >= 17 for 1024 channels on 2^20-sample blocks). */
+ * >= 17 for 1024 channels on 2^20-sample blocks).  step == 1 is
+ * Power|Square(Channelize(...)) without integration: every power is stored where
+ * its spectrum would have gone (plain stores: deterministic, no zeroing of out_dev,
+ * no limit on bins). */
 int bbt_osm_execute_channelized_detect(bbt_osm_plan* plan, const void* in_dev, void* out_dev,
                                        int64_t n_blocks, const int64_t* in_off,
                                        const int64_t* out_off, const int32_t* valid_start,

@@ -1823,6 +1823,45 @@ def test_fused_detection_matches_stored_spectra(sample_shape, monkeypatch):
     _close(it.read(), orc.integrate(orc.power(z), 8), rtol=1e-5)
 
 
+@pytest.mark.parametrize('sample_shape', [(2,), (2, 2)])
+def test_detection_without_integration_in_the_last_pass(sample_shape, monkeypatch):
+    """Power|Square(Channelize(Dedisperse)) on its own (no Integrate): the last pass of the
+    overlap-save plan stores the powers where the spectra would have gone (plain stores, step 1 of
+    the fused route; reference functions.py:15-16, 131-143 on channelize.py:73-74).  Equal to
+    detecting the stored spectra and to the oracle, also for reads that start and end inside
+    frames."""
+    import baseband_tasks_amd.channelize as chz
+    nh = noise(3 * 2**18 + 5000, sample_shape, 2**18, seed=33, frequency=1000 * u.MHz, sideband=1,
+               polarization=['X', 'Y'])
+    ds = bt.DeviceStream(nh, T0, 16 * u.MHz)
+    x = orc.noise_stream(33, 0, nh.shape[0], 2**18, sample_shape)
+    y, info = orc.dedisperse(x, 16e6, 1000., 1, 30., ih_samples_per_frame=2**18)
+    n_chan = 256
+    n_spec = (y.shape[0] // (n_chan * 32)) * 32
+    z = orc.channelize(y[:n_spec * n_chan], n_chan)
+    calls = []
+    real = bt.hip.OsmPlan.execute_channelized_detect
+    monkeypatch.setattr(bt.hip.OsmPlan, 'execute_channelized_detect',
+                        lambda self, *a, **k: (calls.append(a[-3]), real(self, *a, **k))[1])
+    for detect, want in ((bt.Power, orc.power(z)), (bt.Square, orc.square(z))):
+        def build():
+            return detect(bt.Channelize(bt.Dedisperse(ds, 30.), n_chan, 32))
+        task = build()
+        del calls[:]
+        got = task.read()
+        assert calls and all(step == 1 for step in calls), calls
+        assert got.shape == want.shape and got.dtype == np.float32
+        _close(got, want, rtol=1e-5)
+        task.seek(1000)
+        _close(task.read(777), want[1000:1777], rtol=1e-5)
+        monkeypatch.setattr(chz, 'FUSE_DETECTION', False)
+        del calls[:]
+        stored = build().read()
+        assert not calls
+        monkeypatch.setattr(chz, 'FUSE_DETECTION', True)
+        _close(got, stored, rtol=2e-6)
+
+
 def test_subband_shards_equal_columns_of_the_whole():
     """Config-4 style sharding: a rank's run of sub-bands is the same series as
     those columns of the whole stream (bit-exact through a per-stream filter),
