@@ -444,6 +444,32 @@ def test_filter_bank_routes_on_many_streams(route, n_tap, n_chan, monkeypatch):
     assert_parity(z, want.reshape((want.shape[0], n_chan) + sample_shape), f'pfb {n_tap} x {n_chan}, route {route}')
 
 
+@pytest.mark.parametrize('route', [dict(BBT_PFB_PP='4'), dict(BBT_PFB_PP='4', BBT_PFB_GL='2'), dict(BBT_PFB_PP='8', BBT_PFB_GL='1'),
+                                   dict(BBT_PFB_TWO_PASS='1')],
+                         ids=lambda r: '-'.join(f'{k[8:]}{v}' for k, v in r.items()))
+@pytest.mark.filterwarnings('ignore:task will be inefficient')
+def test_filter_bank_routes_on_very_few_spectra(route, monkeypatch):
+    """The several-pairs window kernels sweep 2048 / N spectra per workgroup (two for 1024 channels,
+    eight for 256): streams with fewer spectra than one sweep, and one more than a sweep, on 16
+    and 48 streams (the pair groups of the second do not fill the `GL` order evenly), against the
+    oracle."""
+    for k, v in route.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(5)
+    for n_tap, n_chan in ((4, 1024), (12, 256), (8, 512)):
+        for n_spec in (1, 2, 3, 9):
+            for n_pair in (8, 24):
+                n_in = (n_spec + n_tap - 1) * n_chan
+                x = rng.standard_normal((n_in, n_pair, 2, 2), dtype=np.float32).view(np.complex64)[..., 0]
+                pfb = bt.PolyphaseFilterBank(bt.DeviceStream(x, T0, 1 * u.MHz, samples_per_frame=n_in),
+                                             bt.sinc_hamming(n_tap, n_chan), samples_per_frame=n_spec)
+                z = pfb.read()
+                want, _ = orc.polyphase_filter_bank(x.reshape(n_in, -1), orc.sinc_hamming(n_tap, n_chan), n_in,
+                                                    samples_per_frame=n_spec)
+                assert_parity(z, want.reshape((n_spec, n_chan, n_pair, 2)),
+                              f'pfb {n_tap} x {n_chan}, {n_spec} spectra, {n_pair} pairs, route {route}')
+
+
 # --------------------------------------------------------------------------- small, complete outputs
 def test_small_dedisperse_two_sidebands_golden(golden):
     nh = noise(10000, (2,), 4000, seed=11, fs=1 * u.MHz, frequency=300 * u.MHz,
