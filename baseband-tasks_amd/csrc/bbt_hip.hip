@@ -26,7 +26,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 150
+#define BBT_VERSION 151
 
 // ---------------------------------------------------------------------------
 // errors
@@ -2253,6 +2253,19 @@ static void tune_release() {
         }
     }
     t.mu.unlock();
+}
+extern "C" int bbt_tune_scratch(int release, int64_t* bytes) {
+    TuneScratch& t = tune_scratch();
+    std::lock_guard<std::mutex> lock(t.mu);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    auto& slot = t.buf[dev];
+    if (bytes) *bytes = (int64_t)slot.second;
+    if (release && slot.first) {
+        HIP_TRY(hipFree(slot.first));
+        slot = {nullptr, 0};
+    }
+    return 0;
 }
 
 // One candidate of a generic-length channelizer plan on the compiled kernels: columns of a

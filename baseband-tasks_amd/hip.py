@@ -37,6 +37,7 @@ _pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
 SIGNATURES = {
     'bbt_version': [],
     'bbt_rtc_info': [C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
+    'bbt_tune_scratch': [C.c_int, C.POINTER(C.c_int64)],
     'bbt_device_count': [C.POINTER(_int)],
     'bbt_set_device': [_int],
     'bbt_get_device': [C.POINTER(_int)],
@@ -112,7 +113,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 150
+MIN_LIB_VERSION = 151
 
 _lib = None
 _lock = threading.Lock()
@@ -219,6 +220,15 @@ def rtc_info():
     mode, modules, seconds = _int(0), _i64(0), C.c_double(0)
     check(lib().bbt_rtc_info(C.byref(mode), C.byref(modules), C.byref(seconds)))
     return dict(mode=('off', 'on', 'required')[mode.value], modules=modules.value, seconds=seconds.value)
+
+
+def tuning_scratch(release=False):
+    """Bytes of scratch device memory the library keeps on the current device for plans that time
+    their candidate kernels when they are made (include/bbt_hip.h: bbt_tune_scratch);
+    ``release=True`` frees them."""
+    held = _i64(0)
+    check(lib().bbt_tune_scratch(int(bool(release)), C.byref(held)))
+    return held.value
 
 
 def device_name():

@@ -58,6 +58,13 @@ int bbt_device_count(int* count);
  * objects compiled by this process so far, seconds: the time that took.  BBT_RTC_CACHE=<dir> keeps
  * them on disk, BBT_CSRC=<dir> says where the kernel headers are if not next to the library. */
 int bbt_rtc_info(int* mode, int64_t* modules, double* seconds);
+/* Plans whose best kernel depends on the length in no regular way -- Channelize / Dechannelize with
+ * channel counts that are not powers of two (channelize.py:73-74 on fourier/numpy.py:99-126) and
+ * PolyphaseFilterBank on 8 streams and more (pfb.py:136-154) -- time their candidates once when
+ * they are made, on scratch device memory the library keeps per device (2 GiB, at most a quarter
+ * of what is free when it is first needed).  bytes: what the current device holds now; release
+ * != 0 frees it (the next such plan allocates it again).  BBT_TUNE_KEEP=0 frees it after every plan. */
+int bbt_tune_scratch(int release, int64_t* bytes);
 int bbt_set_device(int device);
 int bbt_get_device(int* device);
 int bbt_device_name(char* buf, int buflen);

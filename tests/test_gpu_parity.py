@@ -603,6 +603,28 @@ print('worst rel-L2 %%.2e, modules %%d' %% (worst, bt.hip.rtc_info()['modules'])
     assert (modules == 0) if mode == '0' else (modules >= 8), out.stdout
 
 
+def test_scratch_memory_of_timed_plans_is_kept_and_can_be_released():
+    """Plans that time their candidate kernels (channel counts that are not powers of two; filter
+    banks on many streams) share one scratch buffer per device, kept between plans
+    (include/bbt_hip.h: bbt_tune_scratch): it exists after such a plan, is not allocated again for
+    the next, can be released, and comes back with the next plan that needs it."""
+    rng = np.random.default_rng(77)
+    def run(n):
+        x = rng.standard_normal((11 * n, 4), dtype=np.float32).view(np.complex64)
+        z = bt.Channelize(bt.DeviceStream(x, T0, 1 * u.MHz), n).read()
+        assert_parity(z, orc.channelize(x, n), f'Channelize({n})')
+    if bt.hip.rtc_info()['mode'] == 'off':
+        pytest.skip('BBT_RTC=0: no plan times candidates')
+    run(2 * 3 * 3 * 5 * 7)                                # 630
+    held = bt.hip.tuning_scratch()
+    assert held > 0
+    run(2 * 3 * 3 * 5 * 7 * 2)                            # 1260
+    assert bt.hip.tuning_scratch() == held
+    assert bt.hip.tuning_scratch(release=True) == held and bt.hip.tuning_scratch() == 0
+    run(2 * 5 * 5 * 7 * 3)                                # 1050
+    assert bt.hip.tuning_scratch() > 0
+
+
 def test_plan_time_compilation_falls_back_and_caches(tmp_path):
     """The two other ways through csrc/rtc.hpp: (1) the kernel headers cannot be found (BBT_CSRC
     points nowhere): the plan runs on the general kernels, with one warning, and the result is
