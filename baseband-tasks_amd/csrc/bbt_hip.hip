@@ -2146,14 +2146,19 @@ static void launch_rows(const bbt_chan_plan* p, const float2* in, float2* out, i
                            (long long)n_fft, 1, scale, p->tab.tw0, p->tab.tw1);
         return;
     }
-    // several pairs: the lanes over PP pairs first (k_fft_rows_pp) -- the largest of 8, 4, 2 that the
-    // exchange area allows (as k_osm_small: 8 up to 512 points, 4 up to 2048, 2 at 4096) and that divides
+    // several pairs: the lanes over PP pairs first (k_fft_rows_pp) -- the largest of 8, 4, 2 that fits a
+    // workgroup (1024 threads, 160 KiB of exchange area: 8 up to 2048 points, 4 at 4096) and that divides
     // the number of pairs.  Measured, Channelize(256 / 1024 / 4096) in G stream-samples/s: 16 streams
-    // 174 / 150 / 165 -> 361 / 294 / 252, 2048 streams 87 / 114 / 124 -> 355 / 274 / 168 (two streams: 383 / 374 / 318).
-    constexpr int CAP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
+    // 174 / 150 / 165 -> 361 / 294 / 252, 2048 streams 87 / 114 / 124 -> 355 / 274 / 168 (two streams: 383 / 374 / 318)
+    // with 8 / 4 / 2 pairs (round 4: as many as leave two workgroups per CU); whole 128-byte lines are worth
+    // more than the second workgroup (round 5, 8 / 8 / 4 pairs): 16 streams 345 / 340 / 280, 128 streams
+    // 357 / 343 / 279, 2048 streams 344 / 333 / 245.
+    constexpr int CAP = N <= 2048 ? 8 : 4;
+    const int cap = getenv("BBT_ROWS_CAP") ? atoi(getenv("BBT_ROWS_CAP")) : CAP;      // (dev)
 #define BBT_ROWS_PP(PP_)                                                                                         \
-    if (PP_ <= CAP && p->npair % PP_ == 0 && n_fft * (p->npair / PP_) < (1ll << 31)) {                          \
-        constexpr int Q = PP_ <= CAP ? PP_ : 1;                                                                  \
+    if ((PP_ * N / 16 <= 1024 && FftGeo<N>::LDS_ELEMS * sizeof(v2) * PP_ <= 160 * 1024) && PP_ <= cap &&        \
+        p->npair % PP_ == 0 && n_fft * (p->npair / PP_) < (1ll << 31)) {                                        \
+        constexpr int Q = (PP_ * N / 16 <= 1024 && FftGeo<N>::LDS_ELEMS * sizeof(v2) * PP_ <= 160 * 1024) ? PP_ : 1; \
         constexpr size_t lds = FftGeo<N>::LDS_ELEMS * sizeof(v2) * Q;                                            \
         if (ensure_dyn_lds((const void*)k_fft_rows_pp<N, SIGN, Q>, lds) == 0) {                                  \
             hipLaunchKernelGGL((k_fft_rows_pp<N, SIGN, Q>), dim3((unsigned)(n_fft * (p->npair / Q))),            \

@@ -12,7 +12,7 @@ for S in ((4, 8, 16, 128, 2048) if os.environ.get('CHAN', '1') != '0' else ()):
     n = (2**28) // S
     x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 1e6, samples_per_frame=2**16, frequency=300e6, sideband=1)
-    for nc in (256, 1024, 4096):
+    for nc in (256, 1024, 2048, 4096):
         t = bt.Channelize(ds, nc)
         def step():
             t.invalidate_cache(); t.seek(0); return t.read_device(t.shape[0])
