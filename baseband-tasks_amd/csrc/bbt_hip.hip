@@ -858,28 +858,35 @@ static int launch_rowpass(bbt_osm_plan* p, float2* work, const OsmChunk& ch, int
     return fail("osm: no row pass for row length %d with %d channels", p->n2, nch);
 }
 
+// pairs per workgroup of the one-kernel plans at most (round 4's rule; BBT_SMALL_CAP overrides: dev)
+#define BBT_SMALL_CAP(N_) ((N_) <= 512 ? 8 : ((N_) <= 2048 ? 4 : 2))
 template <int N>
 static int launch_small(bbt_osm_plan* p, const float2* in, float2* out, const OsmChunk& ch,
                         hipStream_t st) {
-    // lanes over groups of pairs when there are many (see k_osm_small); the
-    // interleaved exchange buffer needs up to 72 KiB of (dynamic) LDS
-    // (8 pairs for 1024 points -- 128-byte runs, 80 KiB, one 512-thread workgroup per CU -- measured
-    // slower than 4: inverse filter bank 56.9 against 62.1 G)
-    constexpr int PP = N <= 512 ? 8 : (N <= 2048 ? 4 : 2);
+    // lanes over groups of pairs when there are many (see k_osm_small): the largest of 8, 4, 2 pairs
+    // that divides the pair count and fits a workgroup (1024 threads; the interleaved exchange buffer
+    // is dynamic LDS, up to 136 KiB)
     constexpr size_t lds1 = FftGeo<N>::LDS_ELEMS * sizeof(v2);
     const int nblk = ch.reg_count ? ch.reg_count : ch.nblk;
     if (p->single) {
         hipLaunchKernelGGL((k_osm_small<N, 1, true>), dim3((nblk + 1) / 2), dim3(N / 16), lds1, st, in,
                            out, ch, 1, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
-    } else if (p->npair % PP == 0) {
-        if (ensure_dyn_lds((const void*)k_osm_small<N, PP>, lds1 * PP)) return 1;
-        hipLaunchKernelGGL((k_osm_small<N, PP>), dim3(nblk * (p->npair / PP)), dim3(PP * N / 16),
-                           lds1 * PP, st, in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0,
-                           p->tab2.tw1);
-    } else {
-        hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(nblk * p->npair), dim3(N / 16), lds1, st, in, out,
-                           ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
+        return 0;
     }
+    constexpr int CAP = BBT_SMALL_CAP(N);
+    const int cap = getenv("BBT_SMALL_CAP") ? atoi(getenv("BBT_SMALL_CAP")) : CAP;         // (dev)
+#define BBT_SMALL_PP(PP_)                                                                                    \
+    if ((PP_ * N / 16 <= 1024 && lds1 * PP_ <= 160 * 1024) && PP_ <= cap && p->npair % PP_ == 0) {          \
+        constexpr int Q = (PP_ * N / 16 <= 1024 && lds1 * PP_ <= 160 * 1024) ? PP_ : 1;                      \
+        if (ensure_dyn_lds((const void*)k_osm_small<N, Q>, lds1 * Q)) return 1;                              \
+        hipLaunchKernelGGL((k_osm_small<N, Q>), dim3(nblk * (p->npair / Q)), dim3(Q * N / 16), lds1 * Q,   \
+                           st, in, out, ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);        \
+        return 0;                                                                                            \
+    }
+    BBT_SMALL_PP(8) BBT_SMALL_PP(4) BBT_SMALL_PP(2)
+#undef BBT_SMALL_PP
+    hipLaunchKernelGGL((k_osm_small<N, 1>), dim3(nblk * p->npair), dim3(N / 16), lds1, st, in, out,
+                       ch, p->S, p->resp, p->resp_index, p->tab2.tw0, p->tab2.tw1);
     return 0;
 }
 
