@@ -2285,11 +2285,15 @@ extern "C" int bbt_tune_scratch(int release, int64_t* bytes) {
 // many as divide the pair count) x consecutive transforms while they still fit ONE wave (a
 // transform of 100 threads gains nothing from a neighbour: 1000 channels 160 G alone, 128 G in
 // twos).  0 = ok (k2 set), 1 = not available (g_err says why).
-static int chan_candidate(bbt_chan_plan* p, int n_chan, int direction, int pmax) {
+// `wide` (many streams): as many pairs as fit a workgroup of 1024 threads and 96 KiB instead of 256
+// threads -- whole 128-byte lines at one workgroup per CU, as k_fft_rows_pp.
+static int chan_candidate(bbt_chan_plan* p, int n_chan, int direction, int pmax, bool wide = false) {
     G2Plan probe;
     if (!g2_plan(n_chan, 1, &probe, pmax)) return fail("no stage list for %d", n_chan);
     int cp = 1;
-    while (cp < 8 && p->npair % (2 * cp) == 0 && probe.tj * 2 * cp <= 256) cp *= 2;
+    while (cp < 8 && p->npair % (2 * cp) == 0 &&
+           (wide ? probe.tj * 2 * cp <= 1024 && (int64_t)n_chan * 2 * cp * 8 <= 96 * 1024 : probe.tj * 2 * cp <= 256))
+        cp *= 2;
     int ct = cp;
     const int ct_cap = getenv("BBT_G2_CHAN_CT") ? atoi(getenv("BBT_G2_CHAN_CT")) : 256;      // (dev)
     while (2 * ct <= ct_cap && probe.tj * 2 * ct <= 64 && (int64_t)n_chan * 2 * ct * 8 <= 64 * 1024) ct *= 2;
@@ -2311,7 +2315,7 @@ static int chan_candidate(bbt_chan_plan* p, int n_chan, int direction, int pmax)
 // general kernel stays), 1 = error (only in `require` mode).
 static int chan_pick(bbt_chan_plan* p, int n_chan, int direction) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int>, int> chosen;       // (device, n, streams, direction) -> points, 0 = general
+    static std::map<std::tuple<int, int, int, int>, int> chosen;       // (device, n, streams, direction) -> points (+ 100: wide), 0 = general
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const auto key = std::make_tuple(dev, n_chan, p->S, direction);
@@ -2322,10 +2326,10 @@ static int chan_pick(bbt_chan_plan* p, int n_chan, int direction) {
         auto it = chosen.find(key);
         if (it != chosen.end()) pick = it->second;
     }
-    if (pick < 0 && !tune) pick = g2_pmax(BBT_G2_KIND_CHAN);
+    if (pick < 0 && !tune) pick = g2_pmax(BBT_G2_KIND_CHAN) + (getenv("BBT_G2_CHAN_WIDE") ? 100 : 0);      // (wide: tests)
     if (pick == 0) return 0;                                           // (the general kernel won before)
     if (pick > 0) {
-        if (!chan_candidate(p, n_chan, direction, pick)) return 0;
+        if (!chan_candidate(p, n_chan, direction, pick % 100, pick >= 100)) return 0;
         if (rtc_mode() == 2) return 1;
         g2_warn_once("bbt_chan_plan_create");
         p->k2 = nullptr;
@@ -2363,20 +2367,29 @@ static int chan_pick(bbt_chan_plan* p, int n_chan, int direction) {
         best_ms = time_current();                                       // the general kernel
         pick = 0;
         bbt_chan_plan best_plan = *p;
-        G2Plan last = {};
-        for (int pmax : {10, 16, 20}) {
-            if (chan_candidate(p, n_chan, direction, pmax)) continue;
+        std::vector<G2Plan> seen;                                       // (plans already timed: stages, threads, columns)
+        for (int code : {10, 16, 20, 110, 116, 120}) {
+            const int pmax = code % 100;
+            const bool wide = code >= 100;
+            if (wide && p->npair < 4) continue;
+            if (chan_candidate(p, n_chan, direction, pmax, wide)) continue;
             ++any;
-            bool same = last.nfac == p->q.nfac && last.tj == p->q.tj && last.ct == p->q.ct;
-            for (int i = 0; same && i < last.nfac; ++i) same = last.fac[i] == p->q.fac[i];
-            last = p->q;
+            bool same = false;
+            for (const G2Plan& o : seen) {
+                bool eq = o.nfac == p->q.nfac && o.tj == p->q.tj && o.ct == p->q.ct;
+                for (int i = 0; eq && i < o.nfac; ++i) eq = o.fac[i] == p->q.fac[i];
+                same = same || eq;
+            }
             if (same) continue;
+            seen.push_back(p->q);
             const float ms = time_current();
-            if (getenv("BBT_RTC_VERBOSE")) fprintf(stderr, "bbt: Channelize(%d) x %d streams, %d points per thread: %.3f ms (general %.3f)\n",
-                                                     n_chan, p->S, pmax, ms, best_plan.k2 ? -1.f : best_ms);
+            if (getenv("BBT_RTC_VERBOSE"))
+                fprintf(stderr, "bbt: Channelize(%d) x %d streams, %d points per thread, %d pairs x %d transforms per workgroup: "
+                                "%.3f ms (general %.3f)\n", n_chan, p->S, pmax, p->cp, p->q.ct / p->cp, ms,
+                        best_plan.k2 ? -1.f : best_ms);
             if (ms < best_ms) {
                 best_ms = ms;
-                pick = pmax;
+                pick = code;
                 best_plan = *p;
             }
         }
@@ -2460,7 +2473,9 @@ int bbt_chan_plan_create(bbt_chan_plan** plan, int n_chan, int n_stream, int dir
         // 14: 25 -> 73, 30: 44 -> 71).  So the plan is made for 10, 16 and 20 points, each candidate --
         // and the general kernel -- is timed once on scratch memory, and the fastest is kept (a few
         // hundred milliseconds per new length and stream count, remembered for the process).
-        // BBT_G2_TUNE=0: no timing, 10 points; BBT_G2_CHAN=none: the general kernels.
+        // On four stream pairs and more each is also tried `wide`: as many pairs as fit a workgroup of
+        // 1024 threads (whole lines: Channelize(3000) on 16 / 128 / 2048 streams 127 / 107 / 110 -> 200 / 201 / 203 G
+        // stream-samples/s).  BBT_G2_TUNE=0: no timing, 10 points; BBT_G2_CHAN=none: the general kernels.
         const char* chan_env = getenv("BBT_G2_CHAN");
         if (rtc_mode() && !(chan_env && !strcmp(chan_env, "none")) && chan_pick(p, n_chan, direction)) {
             delete p;

@@ -554,14 +554,16 @@ def test_lengths_that_are_not_powers_of_two_run_on_kernels_compiled_for_them():
     assert np.array_equal(got[0], got[1])
 
 
-@pytest.mark.parametrize('mode, points', [('0', None), ('require', None), ('require', 10), ('require', 16), ('require', 20)])
+@pytest.mark.parametrize('mode, points', [('0', None), ('require', None), ('require', 10), ('require', 16), ('require', 20),
+                                          ('require', 116)])
 def test_general_and_specialised_kernels_agree_with_the_oracle(mode, points):
     """BBT_RTC=0 keeps every such length on the general kernels (the fall-back when hipRTC is not
     available), BBT_RTC=require makes a failing compilation an error: one child process each runs
     one-kernel and two-level blocks, several streams, and channel counts either side of the
     engines' ranges, against the oracle.  A channelizer plan keeps the fastest of its candidates
     (bbt_hip.hip chan_pick); with `points` the timing is off and every channel count runs on the
-    kernels compiled for that many points per thread, so that each candidate is checked."""
+    kernels compiled for that many points per thread, so that each candidate is checked (116: 16
+    points in the `wide` form, as many stream pairs per workgroup as fit 1024 threads)."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -585,7 +587,7 @@ for n_fft, n_stream in ((630, 2), (6174, 4), (25725, 2), (131250, 6)) if %r else
     assert cv._ih_samples_per_frame == n_fft
     want, _ = orc.convolve(x, resp, samples_per_frame=n_fft - n_tap + 1, ih_samples_per_frame=1000)
     check(cv.read(), want)
-for n, n_stream in ((6, 2), (30, 2), (14, 6), (1000, 2), (6174, 2), (5000, 4), (360, 16), (2187, 2)):
+for n, n_stream in ((6, 2), (30, 2), (14, 6), (1000, 2), (6174, 2), (5000, 4), (360, 16), (2187, 2), (3000, 8), (1000, 24)):
     rng = np.random.default_rng(n)
     x = rng.standard_normal((37 * n, 2 * n_stream), dtype=np.float32).view(np.complex64)
     ch = bt.Channelize(bt.DeviceStream(x, '2020-01-01T00:00:00', 1 * u.MHz), n)
@@ -596,7 +598,9 @@ print('worst rel-L2 %%.2e, modules %%d' %% (worst, bt.hip.rtc_info()['modules'])
 """ % (ROOT, {'0': 'off', 'require': 'required'}[mode], points is None)
     env = dict(os.environ, BBT_RTC=mode)
     if points is not None:
-        env.update(BBT_G2_TUNE='0', BBT_G2_PMAX_CHAN=str(points))
+        env.update(BBT_G2_TUNE='0', BBT_G2_PMAX_CHAN=str(points % 100))
+        if points >= 100:
+            env.update(BBT_G2_CHAN_WIDE='1')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     modules = int(out.stdout.split()[-1])

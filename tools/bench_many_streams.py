@@ -1,6 +1,6 @@
 """Channelize with 256 / 1024 / 4096 channels on 4 ... 2048 streams (dev tool, GPU box): the case where
 one stream pair per workgroup reads 16 bytes of every complete sample (BBT_ROWS_NO_PP=1: that route).
-    python tools/bench_many_streams.py"""
+    python tools/bench_many_streams.py          (CHAN_N=1000,3000 CHAN_S=16,128: other channel and stream counts)"""
 import sys, time, os, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,11 +8,11 @@ import baseband_tasks_amd as bt
 dev = torch.device('cuda', 0)
 bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
 gc.disable()
-for S in ((4, 8, 16, 128, 2048) if os.environ.get('CHAN', '1') != '0' else ()):
+for S in ([int(a) for a in os.environ.get('CHAN_S', '4,8,16,128,2048').split(',')] if os.environ.get('CHAN', '1') != '0' else ()):
     n = (2**28) // S
     x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 1e6, samples_per_frame=2**16, frequency=300e6, sideband=1)
-    for nc in (256, 1024, 2048, 4096):
+    for nc in [int(a) for a in os.environ.get('CHAN_N', '256,1024,2048,4096').split(',')]:
         t = bt.Channelize(ds, nc)
         def step():
             t.invalidate_cache(); t.seek(0); return t.read_device(t.shape[0])
