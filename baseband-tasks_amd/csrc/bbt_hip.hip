@@ -2285,14 +2285,14 @@ extern "C" int bbt_tune_scratch(int release, int64_t* bytes) {
 // many as divide the pair count) x consecutive transforms while they still fit ONE wave (a
 // transform of 100 threads gains nothing from a neighbour: 1000 channels 160 G alone, 128 G in
 // twos).  0 = ok (k2 set), 1 = not available (g_err says why).
-// `wide` (many streams): as many pairs as fit a workgroup of 1024 threads and 96 KiB instead of 256
+// `wide` (many streams): as many pairs as fit a workgroup of 1024 threads and 144 KiB instead of 256
 // threads -- whole 128-byte lines at one workgroup per CU, as k_fft_rows_pp.
 static int chan_candidate(bbt_chan_plan* p, int n_chan, int direction, int pmax, bool wide = false) {
     G2Plan probe;
     if (!g2_plan(n_chan, 1, &probe, pmax)) return fail("no stage list for %d", n_chan);
     int cp = 1;
     while (cp < 8 && p->npair % (2 * cp) == 0 &&
-           (wide ? probe.tj * 2 * cp <= 1024 && (int64_t)n_chan * 2 * cp * 8 <= 96 * 1024 : probe.tj * 2 * cp <= 256))
+           (wide ? probe.tj * 2 * cp <= 1024 && (int64_t)n_chan * 2 * cp * 8 <= 144 * 1024 : probe.tj * 2 * cp <= 256))
         cp *= 2;
     int ct = cp;
     const int ct_cap = getenv("BBT_G2_CHAN_CT") ? atoi(getenv("BBT_G2_CHAN_CT")) : 256;      // (dev)
