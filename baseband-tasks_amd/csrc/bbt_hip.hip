@@ -2666,6 +2666,9 @@ static void launch_pfb(const bbt_pfb_plan* p, const float2* in, float2* out, int
 // are timed once on scratch memory (as chan_pick) and the choice is remembered for the process.
 // BBT_PFB_TUNE=0: the round-4 rule (two passes from 16 streams on); BBT_PFB_TWO_PASS=0 / 1,
 // BBT_PFB_PP=4 / 8 (+ BBT_PFB_GL) force a route (dev).
+#ifndef BBT_PFB_NI
+#define BBT_PFB_NI 192                // spectra per sweep of the window pass (k_pfb_fir_rows): 96 -> 192 +2-5 %, 384 no better
+#endif
 static int pfb_pick(bbt_pfb_plan* p, bool pp_ok) {
     const int n_tap = p->n_tap, n_stream = p->S;
     const bool two_ok = !p->split_real && n_stream >= 2 && (n_tap == 4 || n_tap == 8 || n_tap == 12 || n_tap == 16);
@@ -2883,7 +2886,7 @@ int bbt_pfb_execute(bbt_pfb_plan* p, const void* in_dev, void* out_dev, int64_t 
             // (one launch of each pass per slab: in pieces whose windowed rows would stay in the
             // Infinity Cache between the passes -- 48 ... 192 MiB -- it is SLOWER, 93-147 against
             // 148-159 G stream-samples/s for 16 / 128 streams: shorter launches, nothing to overlap)
-            constexpr int NI = 96;
+            constexpr int NI = BBT_PFB_NI;
             const long long row16 = (long long)p->n * p->npair;
             const dim3 grid((unsigned)((row16 + 255) / 256), (unsigned)((ns + NI - 1) / NI));
             const float4* src = reinterpret_cast<const float4*>(in + off);

@@ -401,10 +401,10 @@ def test_filter_bank_on_many_streams(sample_shape, n_tap, n_chan):
     16 streams on -- and for 4096 channels, which have no sliding-window kernel -- the window is a
     streaming pass over whole rows and the transform follows in place (`k_pfb_fir_rows` + the
     channelizer; 6 streams: the one-pass kernels): both against the oracle,
-    over more spectra than one sweep of the window pass (96) and a ragged last sweep."""
+    over more spectra than one sweep of the window pass (192) and a ragged last sweep."""
     if n_chan == 4096 and sample_shape[0] == 64:
         pytest.skip('(kept small)')
-    n_spec = 96 + 37
+    n_spec = 192 + 37
     n_in = (n_spec + n_tap - 1) * n_chan
     rng = np.random.default_rng(n_chan + sample_shape[0])
     x = rng.standard_normal((n_in,) + sample_shape + (2,), dtype=np.float32).view(np.complex64)[..., 0]
@@ -433,7 +433,7 @@ def test_filter_bank_routes_on_many_streams(route, n_tap, n_chan, monkeypatch):
     for k, v in route.items():
         monkeypatch.setenv(k, v)
     sample_shape = (16, 2)
-    n_spec = 96 + 37
+    n_spec = 192 + 37
     n_in = (n_spec + n_tap - 1) * n_chan
     rng = np.random.default_rng(n_chan + n_tap)
     x = rng.standard_normal((n_in,) + sample_shape + (2,), dtype=np.float32).view(np.complex64)[..., 0]
