@@ -8,7 +8,7 @@ from baseband_tasks_amd.fourier import HipFFTMaker
 dev = torch.device('cuda', 0)
 bt.hip.set_stream(torch.cuda.current_stream().cuda_stream)
 for S in [int(a) for a in sys.argv[1:]] or (2, 4, 16, 128):
-    n = 2**29 // S // 2 * 2
+    n = min(2**29 // S, 2**27)
     x = torch.view_as_complex(torch.randn((n, S, 2), device=dev, dtype=torch.float32))
     ds = bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6, samples_per_frame=2**20, frequency=800e6, sideband=1)
     line = f"S={S:4d}"
