@@ -1460,6 +1460,9 @@ __global__ __launch_bounds__(FPW* N / 16) void k_pfb(const float2* __restrict__ 
 // register i mod NTAP).  The transform follows in place (k_fft_rows_pp).  Real taps: the external
 // format (re_A im_A re_B im_B) is scaled as it is.
 //   grid (ceil(row16 / 256), ceil(n_spec / NI));  row16 = N * S / 2 sixteen-byte pieces per row
+#ifndef BBT_PFB_FIR_LB
+#define BBT_PFB_FIR_LB 0                 // 0: all NTAP rows of a group in flight
+#endif
 template <int NTAP, int NI>
 __global__ __launch_bounds__(256) void k_pfb_fir_rows(const float4* __restrict__ in, float4* __restrict__ out,
                                                       long long n_spec, long long row16, int npair, int N,
@@ -1479,23 +1482,29 @@ __global__ __launch_bounds__(256) void k_pfb_fir_rows(const float4* __restrict__
     for (int k = 0; k < NTAP; ++k) acc[k] = f4v{0.f, 0.f, 0.f, 0.f};
     const f4v* src = reinterpret_cast<const f4v*>(in) + i0 * row16 + idx;
     f4v* dst = reinterpret_cast<f4v*>(out) + i0 * row16 + idx;
+    // (the rows of a group in batches of LB loads in flight together: BBT_PFB_FIR_LB)
+    constexpr int LB = (BBT_PFB_FIR_LB > 0 && NTAP % BBT_PFB_FIR_LB == 0 && BBT_PFB_FIR_LB < NTAP) ? BBT_PFB_FIR_LB : NTAP;
     for (int g = 0; g < NI / NTAP + 1; ++g) {
-        f4v x[NTAP];
 #pragma unroll
-        for (int u = 0; u < NTAP; ++u) {                      // (the group's loads in flight together)
-            const long long r = (long long)g * NTAP + u;
-            x[u] = (r < rows && r < NI + NTAP - 1) ? src[r * row16] : f4v{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int u0 = 0; u0 < NTAP; u0 += LB) {
+            f4v x[LB];
 #pragma unroll
-        for (int u = 0; u < NTAP; ++u) {
-            const long long r = (long long)g * NTAP + u;
-            // row r is tap t of output r - t: register (u - t) mod NTAP
+            for (int i = 0; i < LB; ++i) {
+                const long long r = (long long)g * NTAP + u0 + i;
+                x[i] = (r < rows && r < NI + NTAP - 1) ? src[r * row16] : f4v{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-            for (int t = 0; t < NTAP; ++t) acc[(u - t + NTAP) % NTAP] += x[u] * h[t];
-            // output r - NTAP + 1 is complete (its last tap was this row): register (u + 1) mod NTAP
-            const long long k = r - (NTAP - 1);
-            if (k >= 0 && k < NI && k < outs) dst[k * row16] = acc[(u + 1) % NTAP];
-            acc[(u + 1) % NTAP] = f4v{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < LB; ++i) {
+                const int u = u0 + i;
+                const long long r = (long long)g * NTAP + u;
+                // row r is tap t of output r - t: register (u - t) mod NTAP
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) acc[(u - t + NTAP) % NTAP] += x[i] * h[t];
+                // output r - NTAP + 1 is complete (its last tap was this row): register (u + 1) mod NTAP
+                const long long k = r - (NTAP - 1);
+                if (k >= 0 && k < NI && k < outs) dst[k * row16] = acc[(u + 1) % NTAP];
+                acc[(u + 1) % NTAP] = f4v{0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
 }
