@@ -394,7 +394,7 @@ def test_config3_polyphase_filter_bank(golden):
     assert_parity(z[-3:], golden['c3_tail'], 'golden tail')
 
 
-@pytest.mark.parametrize('sample_shape', [(8, 2), (64, 2), (3, 2), (2,)])
+@pytest.mark.parametrize('sample_shape', [(8, 2), (64, 2), (3, 2), (2,), (4, 2)])
 @pytest.mark.parametrize('n_tap,n_chan', [(4, 1024), (12, 256), (16, 512), (16, 4096)])
 def test_filter_bank_on_many_streams(sample_shape, n_tap, n_chan):
     """`PolyphaseFilterBank` broadcasts over the trailing sample axes (reference pfb.py:136-154).  From
