@@ -1483,7 +1483,8 @@ __global__ __launch_bounds__(256) void k_pfb_fir_rows(const float4* __restrict__
     const f4v* src = reinterpret_cast<const f4v*>(in) + i0 * row16 + idx;
     f4v* dst = reinterpret_cast<f4v*>(out) + i0 * row16 + idx;
     // (the rows of a group in batches of LB loads in flight together: BBT_PFB_FIR_LB)
-    constexpr int LB = (BBT_PFB_FIR_LB > 0 && NTAP % BBT_PFB_FIR_LB == 0 && BBT_PFB_FIR_LB < NTAP) ? BBT_PFB_FIR_LB : NTAP;
+    constexpr int LBD = BBT_PFB_FIR_LB > 0 ? BBT_PFB_FIR_LB : 1;     // (no remainder by a literal zero)
+    constexpr int LB = (BBT_PFB_FIR_LB > 0 && NTAP % LBD == 0 && BBT_PFB_FIR_LB < NTAP) ? BBT_PFB_FIR_LB : NTAP;
     for (int g = 0; g < NI / NTAP + 1; ++g) {
 #pragma unroll
         for (int u0 = 0; u0 < NTAP; u0 += LB) {

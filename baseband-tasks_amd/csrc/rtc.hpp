@@ -46,12 +46,14 @@ static inline RtcApi& rtc_api() {
         const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
         const char* forced = getenv("BBT_HIPRTC_LIB");
         if (forced && *forced) api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        const char* only = getenv("BBT_HIPRTC_ONLY");      // (tests: no other copy if the named one fails)
         for (const char* nm : names) {
-            if (api.handle) break;
+            if (api.handle || (forced && *forced && only && *only == '1')) break;
             api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         }
         if (!api.handle) {
-            api.error = std::string("cannot load libhiprtc.so: ") + (dlerror() ? dlerror() : "?");
+            const char* why = dlerror();         // (one call: dlerror() clears the message it returns)
+            api.error = std::string("cannot load libhiprtc.so: ") + (why ? why : "?");
             return;
         }
         auto sym = [&](const char* s) {
@@ -103,7 +105,12 @@ static inline std::string rtc_arch() {
 }
 
 // Compile `source` to a code object for the current device's architecture.  0 = ok.
-static inline int rtc_compile(const std::string& source, std::vector<char>* code, std::string* log) {
+// `cached` (optional) in: false = do not read the disk cache (its file is then written anew);
+// out: whether the code object came from there.
+static inline int rtc_compile(const std::string& source, std::vector<char>* code, std::string* log,
+                              bool* cached = nullptr) {
+    const bool read_cache = cached == nullptr || *cached;
+    if (cached) *cached = false;
     RtcApi& api = rtc_api();
     if (!api.error.empty()) {
         *log = api.error;
@@ -131,9 +138,12 @@ static inline int rtc_compile(const std::string& source, std::vector<char>* code
             snprintf(name, sizeof name, "/bbt_g2_%016zx.co", key);
             cache_file = std::string(dir) + name;
             std::ifstream f(cache_file, std::ios::binary);
-            if (f) {
+            if (f && read_cache) {
                 code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-                if (!code->empty()) return 0;
+                if (!code->empty()) {
+                    if (cached) *cached = true;
+                    return 0;
+                }
             }
         }
     }
@@ -179,7 +189,8 @@ static inline int rtc_compile(const std::string& source, std::vector<char>* code
         if (f) {
             f.write(code->data(), (std::streamsize)code->size());
             f.close();
-            rename(tmp.c_str(), cache_file.c_str());
+            // (a short write -- disk full -- must not become a cache entry)
+            if (f.fail() || rename(tmp.c_str(), cache_file.c_str()) != 0) unlink(tmp.c_str());
         }
     }
     return 0;
@@ -207,9 +218,21 @@ static inline int rtc_module(const std::string& source, RtcModule** out, std::st
         return 0;
     }
     std::vector<char> code;
-    if (rtc_compile(source, &code, log)) return 1;
+    bool cached = true;
+    if (rtc_compile(source, &code, log, &cached)) return 1;
     RtcModule* m = new RtcModule;
-    const hipError_t e = hipModuleLoadData(&m->mod, code.data());
+    hipError_t e = hipModuleLoadData(&m->mod, code.data());
+    if (e != hipSuccess && cached) {
+        // a damaged or foreign file in BBT_RTC_CACHE: compile again (which replaces the file)
+        (void)hipGetLastError();
+        cached = false;
+        code.clear();
+        if (rtc_compile(source, &code, log, &cached)) {
+            delete m;
+            return 1;
+        }
+        e = hipModuleLoadData(&m->mod, code.data());
+    }
     if (e != hipSuccess) {
         *log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
         delete m;
@@ -220,6 +243,8 @@ static inline int rtc_module(const std::string& source, RtcModule** out, std::st
     return 0;
 }
 static inline int rtc_function(RtcModule* m, const char* name, hipFunction_t* fn, std::string* log) {
+    static std::mutex mu;               // (host threads that make plans of one length at the same time)
+    std::lock_guard<std::mutex> lock(mu);
     auto it = m->fn.find(name);
     if (it == m->fn.end()) {
         hipFunction_t f;

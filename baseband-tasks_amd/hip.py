@@ -784,9 +784,6 @@ class OsmPlan(_Plan):
             idx = idx_arr.ctypes.data_as(_pi32)
         check(lib().bbt_osm_plan_create(C.byref(self._h), self.n_fft, self.n_stream, n_resp,
                                         resp_ptr, on_dev, idx))
-        # (plans of more than one kernel run chunks of blocks on internal streams, the lanes;
-        # one-kernel plans run a deferred call on a stream of their own beside the caller's)
-        self._has_lanes = self.info()['n1'] > 1
 
     def info(self):
         ws, chunk, n1, n2 = _i64(), _int(), _int(), _int()

@@ -203,11 +203,20 @@ class Stream:
 
 
 class StreamEvent:
-    """An event recorded on an explicit stream (``None``: the package's current stream)."""
+    """An event recorded on an explicit stream (``None``: the package's current stream).
 
-    def __init__(self):
+    By default an ordering event (no timing, no system-scope fence: include/bbt_hip.h,
+    `bbt_event_create_ordering`), meant for stream-to-stream waits.  ``host_wait=True`` makes a
+    default event, the kind the HOST may wait for (`synchronize`) before it touches memory the
+    work in front of the event used.  (The hand-over of kernel results to a download queued on
+    another stream stays an ordering event: the library holds gfx950 code only, where the
+    agent-scope release at the end of a kernel writes its L2 lines back before the copy engine
+    reads them; the host waits for that download with `Stream.synchronize`, which fences.)"""
+
+    def __init__(self, host_wait=False):
         self._h = C.c_void_p()
-        hip.check(hip.lib().bbt_event_create_ordering(C.byref(self._h)))
+        create = hip.lib().bbt_event_create if host_wait else hip.lib().bbt_event_create_ordering
+        hip.check(create(C.byref(self._h)))
 
     def record(self, stream=None):
         handle = hip.get_stream() if stream is None else stream.handle
@@ -322,7 +331,8 @@ class HostUploader:
         up.dev = dev
         self._stream.wait(after)                          # the block's previous users (pool reuse)
         hip.check(hip.lib().bbt_memcpy_h2d(dev.ptr, view.ctypes.data, view.nbytes, self._stream.handle))
-        up.event = StreamEvent().record(self._stream)
+        # (the host waits for this one before it refills the staging buffer: a default event)
+        up.event = StreamEvent(host_wait=up.staging is not None).record(self._stream)
         if up.staging is not None:
             self._staging_event[up.staging] = up.event
         return up

@@ -668,6 +668,15 @@ print('modules %%d seconds %%.3f' %% (info['modules'], info['seconds']))
     assert modules == 1 and len(list(cache.glob('bbt_g2_*.co'))) == 1
     modules, second, _ = run(BBT_RTC='require', BBT_RTC_CACHE=str(cache))
     assert second < first / 3 and len(list(cache.glob('bbt_g2_*.co'))) == 1, (first, second)
+    # (3) a damaged file in the cache is compiled again and replaced, not an error for ever after
+    entry = list(cache.glob('bbt_g2_*.co'))[0]
+    good = entry.read_bytes()
+    entry.write_bytes(b'not a code object')
+    modules, _, _ = run(BBT_RTC='require', BBT_RTC_CACHE=str(cache))
+    assert modules == 1 and entry.read_bytes() == good
+    # (4) no hipRTC in the process: the general kernels, with the loader's reason in the warning
+    modules, _, err = run(BBT_HIPRTC_LIB=str(tmp_path / 'libnone.so'), BBT_RTC='1', BBT_HIPRTC_ONLY='1')
+    assert modules == 0 and 'general kernels' in err, err[-2000:]
 
 
 def test_config5_at_the_references_default_block():

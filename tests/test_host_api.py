@@ -532,6 +532,10 @@ class _FakeHip:
     def bbt_event_create_ordering(self, ref):
         return 0
 
+    def bbt_event_create(self, ref):
+        self.log.append(('host event',))
+        return 0
+
     def bbt_event_destroy(self, h):
         return 0
 
@@ -615,6 +619,26 @@ def test_host_uploader_takes_the_block_before_the_ordering_event_and_loads_each_
     assert up.fetch(41, 8).shape == (8, 1)             # reaches past the pending load: loaded anew
     assert up.loads == 5
     up.close()
+    # a stream without pinned memory goes through the two staging buffers, which the HOST waits
+    # for before it refills them: those uploads carry default events, the others ordering events
+    monkeypatch.setattr(hp, 'pinned_empty', lambda shape, dtype: np.empty(shape, dtype))
+
+    class Plain:
+        shape, dtype = data.shape, data.dtype
+
+        def seek(self, pos):
+            self.pos = pos
+
+        def read(self, count, out=None):
+            out[...] = data[self.pos:self.pos + count]
+            return out
+    fake.log.clear()
+    plain = Plain()                                     # (the uploader holds its stream weakly)
+    up = hp.HostUploader(plain)
+    for run in runs:
+        up.fetch(*run)
+    up.close()
+    assert fake.log.count(('host event',)) == len(runs)
 
 
 class _FakeLib:
@@ -662,7 +686,6 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     monkeypatch.setattr(hip, 'DEFER_JOIN', True)
     monkeypatch.setattr(hip, '_events', hip._EventPool())
     plan = hip.OsmPlan(2**20, 2, np.zeros((1, 2**20), np.complex64))
-    assert plan._has_lanes
     x = hip.DeviceArray((2**20, 2), np.complex64)
     y = hip.DeviceArray((1000, 2), np.complex64)
     desc = ([0], [0], [10], [1000])
