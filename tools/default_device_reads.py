@@ -1,6 +1,6 @@
 """Default-argument reads of device-resident chains (dev tool): `read_device()` of the whole
 stream with nothing tuned -- frames of one spectrum, the defaults' block lengths, chains of
-several tasks.     python tools/default_device_reads.py"""
+several tasks.     python tools/default_device_reads.py [label substring ...]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,12 @@ ds = lambda fc=1000e6, spf=2**20: bt.DeviceStream(x, '2020-01-01T00:00:00', 16e6
                                                   polarization=np.array(['X', 'Y']))
 
 
+ONLY = sys.argv[1:]        # (labels to run, as substrings; none: all)
+
+
 def timeit(make, label, per_sample=1):
+    if ONLY and not any(w in label for w in ONLY):
+        return
     t = make()
     def step():
         u = t
