@@ -1698,7 +1698,10 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
     } else {
         p->lanes = 1;
     }
-    if (p->lanes == 1) {
+    // (BBT_ASIDE=0, a development switch: one-kernel plans have no stream of their own and run
+    // every call on the caller's)
+    const char* aside_env = getenv("BBT_ASIDE");
+    if (p->lanes == 1 && !(aside_env && !strcmp(aside_env, "0"))) {
         // (no lanes: a deferred call runs on the tail stream, beside what the caller queues next)
         if (hipStreamCreateWithFlags(&p->tail_stream, hipStreamNonBlocking) != hipSuccess ||
             (!p->ev_fork && hipEventCreateWithFlags(&p->ev_fork, BBT_EV_ORDER) != hipSuccess) ||

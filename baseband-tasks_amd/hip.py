@@ -151,18 +151,25 @@ def _preload_torch_runtime(name='libamdhip64.so'):
         C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+# ROCm maps the HIP streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a
+# process of this package can have more streams than that (a plan's lanes and tail, the stream of
+# every one-kernel plan of a chain, upload, download, the caller's); streams that share a queue
+# take turns.  Rounds 4-5 set the variable to 16 here when it was unset, for the host path (an
+# upload and a download that share a queue: 2.38 instead of 2.57 Gsamples/s host to host).  Measured
+# at the end of round 5 (profiles/r05_hw_queues.txt, alternating runs in one box): with 8 or 16
+# queues reads of device-resident chains are SLOWER -- `Dedisperse` on 160 blocks 38 against 47 G,
+# `Power(Channelize(Dedisperse))` 35 against 44 G, `Resample` 133 against 154 G -- and the headline
+# (768 blocks per call) does not care (51.3-51.9 G either way).  The resident path is the product,
+# so the package leaves ROCm's default alone; a process that only streams from host memory may
+# export GPU_MAX_HW_QUEUES=16 before its first HIP call for the 8 % above.
+
+
 def lib():
     """The loaded library (loads on first use; raises if it is not built)."""
     global _lib
     if _lib is None:
         with _lock:
             if _lib is None:
-                # A process that uses the host path has more HIP streams (plan lanes and tail,
-                # upload, download, the caller's) than the 4 hardware queues ROCm maps streams to
-                # by default; an upload and a download that share one take turns (measured: 27
-                # GB/s each way instead of 41-45).  Only effective if the HIP runtime has not been
-                # initialised yet; an explicit setting wins.
-                os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
                 _preload_torch_runtime()
                 _preload_torch_runtime('libhiprtc.so')     # (csrc/rtc.hpp opens it by soname)
                 if not os.path.exists(LIB_PATH):
@@ -590,7 +597,8 @@ class DeviceArray:
         if other.nbytes != self.nbytes:
             raise ValueError("size mismatch in device to device copy")
         if self.nbytes:
-            check(lib().bbt_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _stream))
+            # (the source is only read: after the calls that still write it, beside those that read it too)
+            check(lib().bbt_memcpy_d2d(self.ptr, other.ptr_to_read(), self.nbytes, _stream))
         return self
 
     def to_host(self, out=None):
@@ -602,7 +610,7 @@ class DeviceArray:
             out[...] = tmp
             return out
         if self.nbytes:
-            check(lib().bbt_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, _stream))
+            check(lib().bbt_memcpy_d2h(out.ctypes.data, self.ptr_to_read(), self.nbytes, _stream))
             check(lib().bbt_stream_sync(_stream))
         return out
 
@@ -638,7 +646,7 @@ def copy_2d(dst, dst_pitch, src, src_pitch, src_offset, width, rows):
     """Device-to-device copy of ``rows`` runs of ``width`` bytes: run r goes
     from src + src_offset + r * src_pitch to dst + r * dst_pitch."""
     if rows and width:
-        check(lib().bbt_memcpy2d(dst.ptr, int(dst_pitch), src.ptr + int(src_offset), int(src_pitch),
+        check(lib().bbt_memcpy2d(dst.ptr, int(dst_pitch), src.ptr_to_read() + int(src_offset), int(src_pitch),
                                  int(width), int(rows), 2, _stream))
     return dst
 
@@ -647,7 +655,7 @@ def pad_streams_to_even(dev, n_stream):
     """(n, S) complex64 with odd S -> (n, S+1) with a zero stream appended."""
     n = dev.size // n_stream
     out = DeviceArray((n, n_stream + 1), dev.dtype)
-    check(lib().bbt_pad_streams(dev.ptr, out.ptr, n, n_stream, n_stream + 1, dev.dtype.itemsize, _stream))
+    check(lib().bbt_pad_streams(dev.ptr_to_read(), out.ptr, n, n_stream, n_stream + 1, dev.dtype.itemsize, _stream))
     return out
 
 
@@ -655,27 +663,27 @@ def strip_stream_pad(dev_padded, n_rows, n_stream, out):
     """inverse of pad_streams_to_even for rows of (S+1) -> S elements."""
     isz = dev_padded.dtype.itemsize
     if n_rows:
-        check(lib().bbt_memcpy2d(out.ptr, n_stream * isz, dev_padded.ptr, (n_stream + 1) * isz,
+        check(lib().bbt_memcpy2d(out.ptr, n_stream * isz, dev_padded.ptr_to_read(), (n_stream + 1) * isz,
                                  n_stream * isz, n_rows, 2, _stream))
     return out
 
 
 def detect_integrate(in_dev, out_dev, n_out, step, n_elem, mode, average=True):
     """Square (mode 0) / Power (1) / plain sum (2) over ``step`` samples."""
-    check(lib().bbt_detect_integrate(in_dev.ptr, out_dev.ptr, int(n_out), int(step), int(n_elem),
+    check(lib().bbt_detect_integrate(in_dev.ptr_to_read(), out_dev.ptr, int(n_out), int(step), int(n_elem),
                                      int(mode), int(bool(average)), _stream))
 
 
 def detect_power_axis(in_dev, out_dev, n_out, step, outer, inner, average=True):
     """Power (mode 1 of `detect_integrate`) for samples (outer, 2, inner)."""
-    check(lib().bbt_detect_power_axis(in_dev.ptr, out_dev.ptr, int(n_out), int(step), int(outer), int(inner),
+    check(lib().bbt_detect_power_axis(in_dev.ptr_to_read(), out_dev.ptr, int(n_out), int(step), int(outer), int(inner),
                                       int(bool(average)), _stream))
 
 
 def real_to_complex(x):
     """float32 DeviceArray -> complex64 with zero imaginary part (same shape)."""
     out = DeviceArray(x.shape, np.complex64)
-    check(lib().bbt_real_op(x.ptr, out.ptr, 0, out.size, 0, 0, _stream))
+    check(lib().bbt_real_op(x.ptr_to_read(), out.ptr, 0, out.size, 0, 0, _stream))
     return out
 
 
@@ -683,7 +691,7 @@ def real_part(z, out=None):
     """complex64 DeviceArray -> its real part (float32)."""
     if out is None:
         out = DeviceArray(z.shape, np.float32)
-    check(lib().bbt_real_op(z.ptr, out.ptr, 1, out.size, 0, 0, _stream))
+    check(lib().bbt_real_op(z.ptr_to_read(), out.ptr, 1, out.size, 0, 0, _stream))
     return out
 
 
@@ -691,7 +699,7 @@ def half_to_full_spectrum(z, n_chan, n_stream):
     """(n_spec, n_chan/2+1, n_stream) complex64 -> Hermitian (n_spec, n_chan, n_stream)."""
     n_spec = z.size // ((n_chan // 2 + 1) * n_stream)
     out = DeviceArray((n_spec, n_chan, n_stream), np.complex64)
-    check(lib().bbt_real_op(z.ptr, out.ptr, 2, out.size, int(n_chan), int(n_stream), _stream))
+    check(lib().bbt_real_op(z.ptr_to_read(), out.ptr, 2, out.size, int(n_chan), int(n_stream), _stream))
     return out
 
 
@@ -700,7 +708,7 @@ def keep_half_spectrum(z, n_chan, n_stream, out):
     n_spec = z.size // (n_chan * n_stream)
     half = n_chan // 2 + 1
     if n_spec:
-        check(lib().bbt_memcpy2d(out.ptr, half * n_stream * 8, z.ptr, n_chan * n_stream * 8,
+        check(lib().bbt_memcpy2d(out.ptr, half * n_stream * 8, z.ptr_to_read(), n_chan * n_stream * 8,
                                  half * n_stream * 8, n_spec, 2, _stream))
     return out
 
@@ -709,7 +717,7 @@ def split_real_pair_spectra(z, n_chan, n_stream, out, padded=False):
     """Spectra ``(n_spec, n_chan, n_stream/2)`` of complex streams z = a + i b
     -> half spectra ``(n_spec, n_chan/2+1, n_stream)`` of the real streams.
     ``padded``: z carries one more, unused, complex stream."""
-    check(lib().bbt_real_op(z.ptr, out.ptr, 6 if padded else 4, out.size, int(n_chan), int(n_stream),
+    check(lib().bbt_real_op(z.ptr_to_read(), out.ptr, 6 if padded else 4, out.size, int(n_chan), int(n_stream),
                             _stream))
     return out
 
@@ -717,18 +725,18 @@ def split_real_pair_spectra(z, n_chan, n_stream, out, padded=False):
 def merge_real_pair_spectra(z_half, n_chan, n_stream, out):
     """Half spectra ``(n_spec, n_chan/2+1, n_stream)`` of real streams ->
     ``(n_spec, n_chan, n_stream/2)`` spectra of the complex streams a + i b."""
-    check(lib().bbt_real_op(z_half.ptr, out.ptr, 5, out.size, int(n_chan), int(n_stream), _stream))
+    check(lib().bbt_real_op(z_half.ptr_to_read(), out.ptr, 5, out.size, int(n_chan), int(n_stream), _stream))
     return out
 
 
 def square_real(x, out):
-    check(lib().bbt_real_op(x.ptr, out.ptr, 3, out.size, 0, 0, _stream))
+    check(lib().bbt_real_op(x.ptr_to_read(), out.ptr, 3, out.size, 0, 0, _stream))
     return out
 
 
 def scale_streams(x, out, n_samples, n_elem, factor_dev):
     """out[i, e] = x[i, e] * factor[e] (complex64)."""
-    check(lib().bbt_scale_streams(x.ptr, out.ptr, int(n_samples), int(n_elem), factor_dev.ptr, _stream))
+    check(lib().bbt_scale_streams(x.ptr_to_read(), out.ptr, int(n_samples), int(n_elem), factor_dev.ptr, _stream))
 
 
 class _Plan:
@@ -808,7 +816,7 @@ class OsmPlan(_Plan):
         defer = DEFER_JOIN and owner.__class__ is _Allocation
         # the input is read: after the calls that still write it; the output is written: after
         # every call still owed to its allocation -- unless the caller vouches for the region
-        src = in_dev.ptr_to_read() if defer else in_dev.ptr
+        src = in_dev.ptr_to_read()
         dst = out_dev._ptr if (defer and out_dev.fresh) else out_dev.ptr
         if not defer:
             check(fn(self._h, src, dst, *args, _stream))
@@ -913,7 +921,7 @@ class ChanPlan(_Plan):
                                          int(direction)))
 
     def execute(self, in_dev, out_dev, n_spectra):
-        check(lib().bbt_chan_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_spectra), _stream))
+        check(lib().bbt_chan_execute(self._h, in_dev.ptr_to_read(), out_dev.ptr, int(n_spectra), _stream))
 
 
 class PfbPlan(_Plan):
@@ -929,7 +937,7 @@ class PfbPlan(_Plan):
                                         taps.ctypes.data_as(C.POINTER(C.c_float))))
 
     def execute(self, in_dev, out_dev, n_spectra):
-        check(lib().bbt_pfb_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_spectra), _stream))
+        check(lib().bbt_pfb_execute(self._h, in_dev.ptr_to_read(), out_dev.ptr, int(n_spectra), _stream))
 
 
 class FirPlan(_Plan):
@@ -946,7 +954,7 @@ class FirPlan(_Plan):
                                         response.ctypes.data_as(C.c_void_p)))
 
     def execute(self, in_dev, out_dev, n_out):
-        check(lib().bbt_fir_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_out), _stream))
+        check(lib().bbt_fir_execute(self._h, in_dev.ptr_to_read(), out_dev.ptr, int(n_out), _stream))
 
 
 class ShiftPlan(_Plan):
@@ -960,7 +968,7 @@ class ShiftPlan(_Plan):
                                           offsets.ctypes.data_as(_pi32)))
 
     def execute(self, in_dev, out_dev, n_out):
-        check(lib().bbt_shift_execute(self._h, in_dev.ptr, out_dev.ptr, int(n_out), _stream))
+        check(lib().bbt_shift_execute(self._h, in_dev.ptr_to_read(), out_dev.ptr, int(n_out), _stream))
 
 
 COMM_ID_BYTES = 128

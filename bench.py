@@ -677,10 +677,9 @@ def dry_run_rank(args):
 def run_rank(args):
     if os.environ.get('BBT_BENCH_DRYRUN'):
         return dry_run_rank(args)
-    # hardware queues for the streams of this process (plan lanes, tail, upload, download, ...):
-    # ROCm maps HIP streams onto GPU_MAX_HW_QUEUES (default 4) queues; with more streams than that
-    # an upload and a download can share one and take turns.  Does not change `value` (measured).
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+    # (GPU_MAX_HW_QUEUES is left at ROCm's default, as the package leaves it: rounds 4-5 set 16 here
+    # for the host-path leg (+8 %), `value` is the same with 4, 6, 8 or 16, and reads of resident
+    # chains shorter than the headline's lose up to 20 % with 8 or 16: profiles/r05_hw_queues.txt)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -710,6 +710,25 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     after = [e for e in fake.log[n0:] if e[0] in ('bbt_stream_wait_event', 'bbt_osm_plan_defer', 'bbt_osm_execute')]
     assert [e[0] for e in after] == ['bbt_osm_plan_defer', 'bbt_osm_execute'] and after[0][2] != ev
     assert len(x.owner.reads) == 2
+    # uses that only READ the input of a deferred call -- a copy out of it (the frame a sequential
+    # reader keeps from its last run, `_ensure_frames`), a plain kernel on it, a download -- go
+    # beside the deferred reader: no wait (found with tools/chain_timeline.py: the last run of
+    # Dedisperse(Resample(x)) started after the run before it had ended, the copy had waited for
+    # that run's lanes) ...
+    x2 = hip.DeviceArray((2**20, 2), np.complex64)
+    y2 = hip.DeviceArray((1000, 2), np.complex64)
+    plan.execute(x2, y2, *desc)
+    n0 = len(fake.log)
+    keep = hip.DeviceArray((10, 2), np.complex64)
+    keep.copy_from_device(x2[:10])
+    hip.scale_streams(x2[:10], keep, 10, 2, keep)
+    x2[:10].to_host()
+    assert 'bbt_stream_wait_event' not in [e[0] for e in fake.log[n0:]] and len(x2.owner.reads) == 1
+    # ... while a reader of the OUTPUT of a deferred call waits for its writer
+    n0 = len(fake.log)
+    keep.copy_from_device(y2[:10])
+    assert [e[0] for e in fake.log[n0:]] == ['bbt_stream_wait_event', 'bbt_memcpy_d2d'] and not y2.owner.writes
+    del x2, y2, keep
     n0 = len(fake.log)
     x.fill_bytes(0)
     waits = [e for e in fake.log[n0:] if e[0] == 'bbt_stream_wait_event']

@@ -11,6 +11,7 @@
 #   one     CONFIGS="config2 config5" [ENVS="A=1|B=2"]   tools/bench_one.py rows (optionally per env)
 #   next    ROWS=".."         rows of tools/bench_next.py
 #   timeline [ARGS=..]        kernel trace of the headline without timing events -> tools/timeline.py
+#   chain   LABEL=<label>     kernel trace of one chain of tools/default_device_reads.py -> tools/chain_timeline.py
 #   prof3   NAME=<n> CMD=".." kernel stats + FETCH_SIZE + WRITE_SIZE (three separate runs) of a command
 #   sq      [CMD=..]          SQ counters (two passes of 8) of a command (default: headline, 96 blocks)
 #   evidence                  round-end: suite, profiles of every config, timeline, SQ counters, bench
@@ -100,6 +101,12 @@ next)
     cat $OUT/rows.jsonl; tail -5 $OUT/err.txt ;;
 timeline)
     timeline $ARGS ;;
+chain)      # LABEL="Dedisperse(Resample": kernel trace of one chain of tools/default_device_reads.py -> tools/chain_timeline.py
+    ( cd /tmp
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/prof -o run -- python3 $R/tools/default_device_reads.py "${LABEL:?LABEL}" > $OUT/run.txt 2>&1; say "chain rc=$?" )
+    tail -3 $OUT/run.txt
+    python3 tools/chain_timeline.py $OUT/prof/run_results.db ${STRETCHES:-2} > $OUT/timeline.txt 2>&1
+    cat $OUT/timeline.txt ;;
 prof3)
     prof3 ${NAME:?NAME} $CMD ;;
 sq)
