@@ -160,8 +160,8 @@ def _preload_torch_runtime(name='libamdhip64.so'):
 # queues reads of device-resident chains are SLOWER -- `Dedisperse` on 160 blocks 38 against 47 G,
 # `Power(Channelize(Dedisperse))` 35 against 44 G, `Resample` 133 against 154 G -- and the headline
 # (768 blocks per call) does not care (51.3-51.9 G either way).  The resident path is the product,
-# so the package leaves ROCm's default alone; a process that only streams from host memory may
-# export GPU_MAX_HW_QUEUES=16 before its first HIP call for the 8 % above.
+# so the package leaves ROCm's default alone (the host path of the final round-5 run read 2.53
+# Gsamples/s with 4 queues: profiles/r05_bench_final.json).
 
 
 def lib():
