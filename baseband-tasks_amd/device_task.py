@@ -6,8 +6,6 @@ one host frame: baseband_tasks/base.py:459-465).  ``read`` copies to the host
 only what the caller asked for; ``read_device`` returns a zero-copy view of
 the cache (valid until the next read on the same task).
 """
-import os
-
 import numpy as np
 
 from . import hip
@@ -189,14 +187,8 @@ class DeviceTaskMixin:
                 span = self._input_span(first, first + 1)
             except Exception:
                 span = None
-            ramp = 1
             if span is not None and getattr(span[0], '_resident', False):
                 per = last - first
-            elif span is not None and produces_on_device(span[0]) and self.RAMP_FIRST_RUN > 1:
-                # The upstream task computes what a run needs before the run can start, and nothing
-                # else is in flight during the first of them: a shorter first run shortens that
-                # start (Dedisperse(Resample(x)): 250 of the read's 4700 us, tools/chain_timeline.py).
-                ramp = self.RAMP_FIRST_RUN
             done = 0
             while done < count:
                 pos = self.offset
@@ -205,8 +197,7 @@ class DeviceTaskMixin:
                 direct = pos == f0 * spf                  # (a run that starts inside a frame: that frame, via the cache)
                 f1 = f0 + 1
                 if direct:
-                    f1 = min(last, f0 + max(per // ramp, 1))
-                    ramp = 1
+                    f1 = min(last, f0 + per)
                     if self._frame_span(f0, f1)[1] - pos > left:
                         f1 = f0 + left // spf             # whole frames only; the rest of the request is a partial one
                     if f1 == f0:
@@ -247,10 +238,6 @@ class DeviceTaskMixin:
         if last - first > self.max_frames_per_call + 2:
             return None
         return self._input_span(first, last)
-
-    #: The first run of a piecewise `read_device` whose input is made by another device task is this
-    #: many times shorter than the others (1: all runs alike).  ``BBT_RAMP``.
-    RAMP_FIRST_RUN = int(os.environ.get('BBT_RAMP', '4'))
 
     #: Frames per run of the pipelined host path of ``read`` (upload, transforms and
     #: download of consecutive runs overlap); None: `max_frames_per_call`.
