@@ -26,7 +26,7 @@
 
 using namespace bbt;
 
-#define BBT_VERSION 151
+#define BBT_VERSION 152
 
 // ---------------------------------------------------------------------------
 // errors
@@ -686,6 +686,18 @@ int bbt_event_record(bbt_event ev, bbt_stream stream) {
 }
 int bbt_event_sync(bbt_event ev) {
     HIP_TRY(hipEventSynchronize((hipEvent_t)ev));
+    return 0;
+}
+int bbt_event_query(bbt_event ev, int* done) {
+    ARG_TRY(ev && done, "bbt_event_query: null argument");
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *done = 0;
+        return 0;
+    }
+    HIP_TRY(e);
+    *done = 1;
     return 0;
 }
 int bbt_stream_wait_event(bbt_stream stream, bbt_event ev) {

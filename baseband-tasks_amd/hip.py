@@ -65,6 +65,7 @@ SIGNATURES = {
     'bbt_event_destroy': [_vp],
     'bbt_event_record': [_vp, _vp],
     'bbt_event_sync': [_vp],
+    'bbt_event_query': [_vp, C.POINTER(C.c_int)],
     'bbt_stream_wait_event': [_vp, _vp],
     'bbt_host_register': [_vp, _sz],
     'bbt_host_unregister': [_vp],
@@ -113,7 +114,7 @@ SIGNATURES = {
 }
 
 #: oldest libbbt_hip.so whose entry points and argument meanings this binding assumes
-MIN_LIB_VERSION = 151
+MIN_LIB_VERSION = 152
 
 _lib = None
 _lock = threading.Lock()
@@ -180,14 +181,15 @@ def lib():
                 handle = C.CDLL(LIB_PATH)
                 handle.bbt_last_error.restype = C.c_char_p
                 handle.bbt_last_error.argtypes = []
-                for name, argtypes in SIGNATURES.items():
-                    fn = getattr(handle, name)
-                    fn.argtypes = argtypes
-                    fn.restype = _int
+                # (the version first: an older library lacks entry points the table below names)
                 if handle.bbt_version() < MIN_LIB_VERSION:
                     raise HipLibraryMissing(
                         f"{LIB_PATH} is version {handle.bbt_version()}, this package needs "
                         f">= {MIN_LIB_VERSION}: rebuild it (python -c 'import __graft_entry__ as g; g.build()').")
+                for name, argtypes in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.argtypes = argtypes
+                    fn.restype = _int
                 _lib = handle
     return _lib
 
@@ -364,6 +366,32 @@ class _Pending:
         self.keep = keep
 
 
+def _prune(owed):
+    """Let go of the leading entries of a list of deferred READERS whose calls have finished
+    (`bbt_event_query`: never blocks): each keeps its plan -- and through the plan its streams and
+    work buffers -- alive, and a task that was dropped long ago would otherwise be destroyed (a
+    device-wide wait: hipFree) in the middle of whatever read happens to push its entry out, 64
+    calls later.  Found with tools/chain_host_probe.py: `Dedisperse(Resample(x))` after other chains
+    on the same tensor, two calls of every read blocked 2.5-3 ms in `bbt_osm_plan_destroy` (18.6
+    instead of 29 G).  Readers only: a finished reader leaves nothing to make visible.  Returns
+    what is left (a tuple for a tuple, the list itself, shortened, for a list)."""
+    n, done = 0, C.c_int(0)
+    while n < len(owed):
+        if lib().bbt_event_query(owed[n].done.event, C.byref(done)) != 0 or not done.value:
+            break
+        n += 1
+    if not n:
+        return owed
+    gone = owed[:n]
+    if isinstance(owed, list):
+        del owed[:n]
+    else:
+        owed = owed[n:]
+    for p in gone:
+        p.done.release()
+    return owed
+
+
 class _Allocation:
     """Owns one block of the device memory pool, and the calls it is still owed: deferred plan
     calls that are WRITING somewhere in it (`writes`) or READING it (`reads`).  A later reader
@@ -388,7 +416,7 @@ class _Allocation:
         """Note a deferred call that writes (reads) this block.  The lists stay short: beyond
         _MAX_OWED entries the oldest is waited for on the current stream (it finished long ago:
         the wait costs nothing) and let go."""
-        owed = (self.writes if write else self.reads) + (pending,)
+        owed = (self.writes if write else _prune(self.reads)) + (pending,)
         if len(owed) > self._MAX_OWED:
             old, owed = owed[0], owed[1:]
             check(lib().bbt_stream_wait_event(_stream, old.done.event))
@@ -443,6 +471,7 @@ def _owe_foreign_read(owner, pending):
         except TypeError:
             return False
         entry = _foreign_reads[key] = (ref, [])
+    _prune(entry[1])
     entry[1].append(pending)
     if len(entry[1]) > _FOREIGN_MAX:
         old = entry[1].pop(0)

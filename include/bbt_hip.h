@@ -124,6 +124,11 @@ int bbt_event_create_ordering(bbt_event* ev);
 int bbt_event_destroy(bbt_event ev);
 int bbt_event_record(bbt_event ev, bbt_stream stream);
 int bbt_event_sync(bbt_event ev);
+/* *done = 1 if everything in front of the last record of `ev` has finished, else 0; never blocks.
+ * (The Python layer lets go of the plans and buffers that finished deferred calls still hold with
+ * it -- a deferred call's completion event, bbt_osm_plan_defer -- instead of keeping them until
+ * somebody waits: hip.py `_prune`.) */
+int bbt_event_query(bbt_event ev, int* done);
 int bbt_stream_wait_event(bbt_stream stream, bbt_event ev);   /* later work on `stream` waits for `ev` */
 int bbt_event_elapsed_ms(bbt_event start, bbt_event stop, float* ms);
 

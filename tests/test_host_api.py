@@ -649,6 +649,7 @@ class _FakeLib:
         self.log = []
         self.next_ptr = 0x100000
         self.events = 0
+        self.finished = set()                            # events `bbt_event_query` reports as done
 
     def __getattr__(self, name):
         def call(*args):
@@ -660,6 +661,9 @@ class _FakeLib:
                 args[0]._obj.value = 0xE000 + self.events
             elif name == 'bbt_osm_plan_create':
                 args[0]._obj.value = 0xABC0
+            elif name == 'bbt_event_query':              # (not logged: it queues nothing)
+                args[1]._obj.value = int(getattr(args[0], 'value', args[0]) in self.finished)
+                return 0
             elif name == 'bbt_osm_plan_info':
                 args[3]._obj.value = 256                 # n1
                 args[4]._obj.value = 4096
@@ -798,6 +802,47 @@ def test_deferred_plan_calls_leave_their_event_with_input_and_output(monkeypatch
     assert c.owner is a.owner                            # back to the first one ...
     n0 = len(fake.log)
     assert c.ptr and fake.log[n0][0] == 'bbt_stream_wait_event'      # ... after the call before last
+
+
+def test_finished_readers_let_go_of_their_plans(monkeypatch):
+    """Deferred calls that READ an input leave their completion event -- and a reference to their
+    plan -- with the input; nobody ever waits for a reader of a long-lived input (a tensor that
+    many tasks read), so the entries of calls that have FINISHED are dropped when the next one is
+    noted (`hip._prune`, `bbt_event_query`): a plan whose task was dropped is destroyed then, not
+    64 calls later in the middle of somebody's read (tools/chain_host_probe.py: 2.5-3 ms blocked
+    in `bbt_osm_plan_destroy`, twice per read).  No GPU: the logging stand-in for the library."""
+    from baseband_tasks_amd import hip
+    fake = _FakeLib()
+    monkeypatch.setattr(hip, '_lib', fake)
+    monkeypatch.setattr(hip, 'DEFER_JOIN', True)
+    monkeypatch.setattr(hip, '_events', hip._EventPool())
+    desc = ([0], [0], [10], [1000])
+
+    class Tensor:                                        # a foreign owner (weakly referable)
+        pass
+    tensor = Tensor()
+    for x in (hip.DeviceArray((2**20, 2), np.complex64),                               # the package's own memory
+              hip.DeviceArray((2**20, 2), np.complex64, ptr=0x7000000, owner=tensor)):  # somebody else's
+        readers = (lambda: x.owner.reads) if x.owner is not tensor else (lambda: hip._foreign_reads[id(tensor)][1])
+        old_plan = hip.OsmPlan(2**20, 2, np.zeros((1, 2**20), np.complex64))
+        y = hip.DeviceArray((1000, 2), np.complex64)
+        old_plan.execute(x, y, *desc)
+        old_plan.execute(x, y, *desc)
+        events = [e[2] for e in fake.log if e[0] == 'bbt_osm_plan_defer'][-2:]
+        assert y.ptr                                     # (the output was consumed; the input's side stays)
+        del old_plan, y                                  # the task is dropped: only the readers' entries hold the plan
+        assert len(readers()) == 2 and 'bbt_osm_plan_destroy' not in [e[0] for e in fake.log]
+        plan = hip.OsmPlan(2**20, 2, np.zeros((1, 2**20), np.complex64))
+        y = hip.DeviceArray((1000, 2), np.complex64)
+        plan.execute(x, y, *desc)                        # nothing has finished yet: all three are kept
+        assert len(readers()) == 3
+        fake.finished.update(events)
+        n0 = len(fake.log)
+        plan.execute(x, y, *desc)
+        assert len(readers()) == 2 and [e[0] for e in fake.log[n0:]].count('bbt_osm_plan_destroy') == 1
+        assert 'bbt_stream_wait_event' not in [e[0] for e in fake.log[n0:] if e[0] != 'bbt_stream_wait_event' or e[2] in events]
+        fake.log.clear()
+        fake.finished.clear()                            # (the pool hands the same events out again)
 
 
 def test_pipelined_read_after_an_unconsumed_device_read_keeps_two_buffers(monkeypatch):
