@@ -1129,7 +1129,7 @@ static int osm_run_chunk(bbt_osm_plan* p, const float2* in, float2* out, const O
                           (const cf*)p->qw1))
                 return 1;
             if (timed) HIP_TRY(hipEventRecord(e[1], st));
-            if (g2_launch(p->k2_row, dim3(p->n1, ch.nblk * p->npair), dim3(p->q2.threads()), st, work, p->n1, p->n2p,
+            if (g2_launch(p->k2_row, dim3((p->n1 + p->q2.ct - 1) / p->q2.ct, ch.nblk * p->npair), dim3(p->q2.threads()), st, work, p->n1, p->n2p,
                           (const cf*)p->resp, (const int*)p->resp_index, p->npair, (const cf*)p->qw2,
                           (const cf*)p->qw2r, (const cf*)p->tlo, (const cf*)p->thi, (const cf*)p->tws))
                 return 1;
@@ -1508,7 +1508,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         // The kernels specialised on this length (fft_gen2.hpp), compiled now; if that is not
         // possible the plan runs on the general ones.
         if (rtc_mode()) {
-            bool ok = g2_plan(p->n2, 1, &p->q2, g2_pmax(BBT_G2_KIND_ROW));
+            // (short rows: several neighbouring rows per workgroup, gen2_host.hpp g2_row_ct)
+            const int row_ct = p->n1 > 1 ? g2_row_ct(p->n2, g2_pmax(BBT_G2_KIND_ROW)) : 1;
+            bool ok = g2_plan(p->n2, row_ct, &p->q2, g2_pmax(BBT_G2_KIND_ROW));
             if (ok) p->q2r = g2_reversed(p->q2);
             if (ok && p->n1 > 1) {
                 // (a column tile is one workgroup: at most 1024 threads and 64 KiB of exchange area)

@@ -220,19 +220,39 @@ static inline G2Plan g2_reversed(const G2Plan& g) {
 // 490 x 3402 (5 and 4: three column workgroups leave room for no row workgroup) 29.5,
 // 980 x 1701 (9 and 3) 27.9 -- then the number of stages, then idle lanes.  So: workgroups of
 // 1, 2, 4 or 8 waves first, fewest stages next, fullest waves last.
+// Rows per workgroup of the row pass: a short row (N2 of a few hundred points: blocks of a few
+// 10^4 samples) needs a dozen threads, and a workgroup of one such row is a wave with three
+// quarters of its lanes idle -- 31 104 = 128 x 243 (default arguments at 1400 MHz, DM 10): row pass
+// 206 us per launch against 57 and 41 us for the column passes.  So a workgroup takes `ct`
+// neighbouring rows k1, interleaved like the columns of a column pass (lanes over the rows first:
+// 8 rows x 8 consecutive points = 128-byte runs), as many as fill one wave.  BBT_G2_ROW_CT caps it
+// (1: one row per workgroup, as before).
+static inline int g2_row_ct(int n2, int pmax) {
+    static const int cap = getenv("BBT_G2_ROW_CT") ? std::max(1, atoi(getenv("BBT_G2_ROW_CT"))) : 8;
+    std::vector<int> fac;
+    if (!g2_factor(n2, &fac, pmax)) return 1;
+    const int tj = g2_threads(n2, fac, pmax);
+    int ct = 1;
+    while (2 * ct <= cap && tj * 2 * ct <= 64) ct *= 2;
+    return ct;
+}
 static inline bool g2_choose_split(int64_t n, int ct, int max_n1, int max_n2, int* n1, int* n2) {
-    auto pow2_waves = [](int threads) {
+    // (workgroups of up to 4 waves pack a CU whatever their number: for short blocks, whose
+    // workgroups are that small, three waves are as good as two or four)
+    const bool small = n <= (1 << 17);
+    auto pow2_waves = [small](int threads) {
         const int w = threads / 64;
-        return w == 1 || w == 2 || w == 4 || w == 8;
+        return w == 1 || w == 2 || w == 4 || w == 8 || (small && w == 3);
     };
     bool found = false;
     double best[4] = {0, 0, 0, 0};
     for (int64_t d = 2; d <= max_n1 && d * 2 <= n; ++d) {
         if (n % d || n / d > max_n2 || n / d < d / 4) continue;
         G2Plan c, r;
-        if (!g2_plan((int)d, ct, &c, g2_pmax(BBT_G2_KIND_COL)) || !g2_plan((int)(n / d), 1, &r, g2_pmax(BBT_G2_KIND_ROW))) continue;
+        const int rct = g2_row_ct((int)(n / d), g2_pmax(BBT_G2_KIND_ROW));
+        if (!g2_plan((int)d, ct, &c, g2_pmax(BBT_G2_KIND_COL)) || !g2_plan((int)(n / d), rct, &r, g2_pmax(BBT_G2_KIND_ROW))) continue;
         if (c.lds_elems * 8 > 64 * 1024 || c.threads() > 1024 || r.threads() > 1024) continue;
-        const double eff = (double)(c.tj * ct) / c.threads() * (double)r.tj / r.threads();
+        const double eff = (double)(c.tj * ct) / c.threads() * (double)(r.tj * rct) / r.threads();
         const double key[4] = {(double)(!pow2_waves(c.threads()) + !pow2_waves(r.threads())),
                                (double)(c.nfac + r.nfac), -eff, (double)d};
         bool better = !found;

@@ -82,21 +82,25 @@ __device__ __forceinline__ void g2_col(v2* lds, const float2* __restrict__ in, f
     }
 }
 
-// Row pass, in place on row k1 of a (block, pair).  grid (N1, blocks * npair); see k_gen_row.
+// Row pass, in place on rows k1 of a (block, pair): G::ct neighbouring rows per workgroup (lanes
+// over the rows first; gen2_host.hpp g2_row_ct).  grid (ceil(N1 / ct), blocks * npair); see
+// k_gen_row.  Threads of rows past N1 run along on the last row and store nothing.
 template <class G, class GR>
 __device__ __forceinline__ void g2_row(v2* lds, float2* __restrict__ work, int N1, int N2p, const cf* __restrict__ resp,
                                        const int* __restrict__ resp_index, int npair,
                                        const cf* __restrict__ wn, const cf* __restrict__ wnr,
                                        const cf* __restrict__ tlo, const cf* __restrict__ thi,
                                        const cf* __restrict__ tws) {
-    constexpr int N2 = G::n;
-    const int k1 = blockIdx.x, sp = blockIdx.y % npair;
+    constexpr int N2 = G::n, ct = G::ct;
+    const int k1_mine = blockIdx.x * ct + (threadIdx.x & (ct - 1));
+    const bool live = k1_mine < N1;
+    const int k1 = live ? k1_mine : N1 - 1, sp = blockIdx.y % npair;
     f4* row = reinterpret_cast<f4*>(work) + ((long long)blockIdx.y * N1 + k1) * N2p;
     const cf* srow = tws + (long long)k1 * G::fac[0];
     GenRowSrc src{row, tlo, thi, srow, k1};
     const int c0 = resp_index[2 * sp], c1 = resp_index[2 * sp + 1];
     GenRespMul mul{resp + ((long long)c0 * N1 + k1) * N2, resp + ((long long)c1 * N1 + k1) * N2, c0 == c1};
-    GenRowDst dst{row, tlo, thi, srow, k1};
+    GenRowDst dst{row, tlo, thi, srow, k1, live};
     g2_conv_open<G, GR>(lds, wn, wnr, threadIdx.x, src, mul, dst);
 }
 

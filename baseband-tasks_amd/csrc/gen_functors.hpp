@@ -160,8 +160,10 @@ struct GenRowDst {
     const cf* thi;
     const cf* srow;
     int k1;
+    bool live = true;
     template <int R>
     __device__ __forceinline__ void store(int j, int m, c2 (&v)[R]) const {
+        if (!live) return;
         const cf a = big_twiddle(tlo, thi, k1 * j);
 #if BBT_G2_WORK_ST
         st_int(reinterpret_cast<float2*>(row + j), twmul_v<+1>(v[0], a));

@@ -497,7 +497,7 @@ def test_reference_default_geometry_golden(golden, tag, kw):
 
 
 @pytest.mark.parametrize('n_fft', [6, 60, 210, 1000, 2187, 6174, 7203, 8192,           # one workgroup
-                                   8232, 19200, 25725, 2 * 3**9, 131250, 1049760])  # two factors
+                                   8232, 19200, 25725, 31104, 2 * 3**9, 131250, 1049760])  # two factors (short rows: several per workgroup)
 def test_block_lengths_that_are_not_powers_of_two(n_fft):
     """Overlap-save blocks of every kind of 2^a 3^b 5^c 7^d length against the
     oracle (random response, so every bin matters; three streams)."""
