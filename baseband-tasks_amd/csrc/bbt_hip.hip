@@ -1502,7 +1502,9 @@ int bbt_osm_plan_create(bbt_osm_plan** plan, int64_t n_fft, int n_stream, int n_
         // columns 18.1, 4 columns 17.3 Gsamples/s for the 1 666 980-sample block)
         p->gen_ct = 1;
         if (p->n1 > 1) {
-            const int ct_cap = getenv("BBT_GEN_CT") ? atoi(getenv("BBT_GEN_CT")) : 8;         // (dev)
+            // (short blocks on the compiled kernels: as many columns as fill a wave, gen2_host.hpp g2_col_ct)
+            const int ct_cap = getenv("BBT_GEN_CT") ? atoi(getenv("BBT_GEN_CT"))         // (dev)
+                               : (rtc_mode() && n_fft <= (1 << 17)) ? g2_col_ct(p->n1, g2_pmax(BBT_G2_KIND_COL)) : 8;
             while (p->gen_ct < ct_cap && 2 * p->gen_ct * p->n1 <= 2 * BBT_GEN_MAX_LEN) p->gen_ct *= 2;
         }
         // The kernels specialised on this length (fft_gen2.hpp), compiled now; if that is not

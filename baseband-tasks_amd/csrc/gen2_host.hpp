@@ -236,6 +236,19 @@ static inline int g2_row_ct(int n2, int pmax) {
     while (2 * ct <= cap && tj * 2 * ct <= 64) ct *= 2;
     return ct;
 }
+// Columns per tile of a column pass of a SHORT block (n <= 2^17): a short column (N1 of a few
+// dozen points) needs two or four threads, and eight of them are a quarter of a wave reading
+// 128-byte runs; 16 or 32 columns fill the wave and read 256- / 512-byte runs.  Measured on the
+// 31 104-sample block (MI355X, round 5, BBT_GEN_CT): 36 x 864 with 8 / 16 / 32 columns 31.6 / 38.9 /
+// 41.9 G, 64 x 486 37.4 / 40.4 / 40.9, 162 x 192 (14 threads per column) 37.1 / 37.4 / 36.2.
+static inline int g2_col_ct(int n1, int pmax, int base = 8) {
+    std::vector<int> fac;
+    if (!g2_factor(n1, &fac, pmax)) return base;
+    const int tj = g2_threads(n1, fac, pmax);
+    int ct = base;
+    while (ct < 32 && tj * ct < 64) ct *= 2;
+    return ct;
+}
 static inline bool g2_choose_split(int64_t n, int ct, int max_n1, int max_n2, int* n1, int* n2) {
     // (workgroups of up to 4 waves pack a CU whatever their number: for short blocks, whose
     // workgroups are that small, three waves are as good as two or four)
@@ -245,24 +258,27 @@ static inline bool g2_choose_split(int64_t n, int ct, int max_n1, int max_n2, in
         return w == 1 || w == 2 || w == 4 || w == 8 || (small && w == 3);
     };
     bool found = false;
-    double best[4] = {0, 0, 0, 0};
+    double best[5] = {0, 0, 0, 0, 0};
     for (int64_t d = 2; d <= max_n1 && d * 2 <= n; ++d) {
         if (n % d || n / d > max_n2 || n / d < d / 4) continue;
+        if (small && d < 16 && n / 16 <= max_n2) continue;      // (as the 16 x N2 plans of power-of-two blocks: no shorter columns)
         G2Plan c, r;
         const int rct = g2_row_ct((int)(n / d), g2_pmax(BBT_G2_KIND_ROW));
-        if (!g2_plan((int)d, ct, &c, g2_pmax(BBT_G2_KIND_COL)) || !g2_plan((int)(n / d), rct, &r, g2_pmax(BBT_G2_KIND_ROW))) continue;
+        // (short blocks: the widest column tiles first -- the longest runs --, see g2_col_ct)
+        const int cct = small ? g2_col_ct((int)d, g2_pmax(BBT_G2_KIND_COL), ct) : ct;
+        if (!g2_plan((int)d, cct, &c, g2_pmax(BBT_G2_KIND_COL)) || !g2_plan((int)(n / d), rct, &r, g2_pmax(BBT_G2_KIND_ROW))) continue;
         if (c.lds_elems * 8 > 64 * 1024 || c.threads() > 1024 || r.threads() > 1024) continue;
-        const double eff = (double)(c.tj * ct) / c.threads() * (double)(r.tj * rct) / r.threads();
-        const double key[4] = {(double)(!pow2_waves(c.threads()) + !pow2_waves(r.threads())),
-                               (double)(c.nfac + r.nfac), -eff, (double)d};
+        const double eff = (double)(c.tj * cct) / c.threads() * (double)(r.tj * rct) / r.threads();
+        const double key[5] = {(double)(!pow2_waves(c.threads()) + !pow2_waves(r.threads())),
+                               (double)(c.nfac + r.nfac), -(double)cct, -eff, (double)d};
         bool better = !found;
-        for (int i = 0; i < 4 && !better; ++i) {
+        for (int i = 0; i < 5 && !better; ++i) {
             if (key[i] < best[i]) better = true;
             else if (key[i] > best[i]) break;
         }
         if (better) {
             found = true;
-            for (int i = 0; i < 4; ++i) best[i] = key[i];
+            for (int i = 0; i < 5; ++i) best[i] = key[i];
             *n1 = (int)d;
             *n2 = (int)(n / d);
         }
