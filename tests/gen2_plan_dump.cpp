@@ -35,8 +35,10 @@ int main(int argc, char** argv) {
             int n1 = 0, n2 = 0;
             if (!g2_choose_split(atoll(argv[i]), 8, 1024, 8192, &n1, &n2)) { printf("null\n"); continue; }
             G2Plan c, r;
-            g2_plan(n1, 8, &c, g2_pmax(BBT_G2_KIND_COL));
-            g2_plan(n2, 1, &r, g2_pmax(BBT_G2_KIND_ROW));
+            // (as bbt_osm_plan_create plans them: short blocks with wider column tiles, short rows several to a workgroup)
+            const bool small = atoll(argv[i]) <= (1 << 17);
+            g2_plan(n1, small ? g2_col_ct(n1, g2_pmax(BBT_G2_KIND_COL)) : 8, &c, g2_pmax(BBT_G2_KIND_COL));
+            g2_plan(n2, g2_row_ct(n2, g2_pmax(BBT_G2_KIND_ROW)), &r, g2_pmax(BBT_G2_KIND_ROW));
             printf("{\"n1\": %d, \"n2\": %d, \"col\": ", n1, n2);
             dump(c);
             printf(", \"row\": ");

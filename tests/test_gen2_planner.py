@@ -89,8 +89,27 @@ def test_split_rule_prefers_workgroups_that_pack_a_cu(dump):
     for n, got in zip((1666980, 3936600, 1049760, 93312), dump('split', 1666980, 3936600, 1049760, 93312)):
         assert got['n1'] * got['n2'] == n and got['n2'] <= 8192 and got['n1'] <= 1024
         for k in ('col', 'row'):
-            assert got[k]['threads'] // 64 in (1, 2, 4, 8), (n, got[k])
+            # (blocks up to 2^17 samples: their workgroups are small, three waves pack as well)
+            assert got[k]['threads'] // 64 in ((1, 2, 3, 4, 8) if n <= 2**17 else (1, 2, 4, 8)), (n, got[k])
+    assert [(g['n1'], g['n2']) for g in dump('split', 1666980, 3936600, 1049760)] == [(540, 3087), (486, 8100), (240, 4374)]
     assert dump('split', 11059200) == [None]         # (N2 <= 8192 needs N1 >= 1350: the general rule takes over)
+
+
+def test_short_blocks_fill_their_waves(dump):
+    """Blocks of a few 10^4 samples (the defaults at low DM: 31 104 = 2^7 3^5 at 1400 MHz, DM 10) split
+    into columns and rows that need a dozen threads each: a column tile takes 16 or 32 columns, a
+    row workgroup up to 8 rows, so that neither kernel runs waves that are mostly idle (measured:
+    Dedisperse on 31 104-sample blocks 26.7 -> 44.7 Gsamples/s), and no column is shorter than 16
+    points.  Reference: the block lengths of base.py:750-758 with fourier/numpy.py:99-126."""
+    got, = dump('split', 31104)
+    assert (got['n1'], got['n2']) == (36, 864) and got['col']['ct'] == 32
+    for n in (8232, 19200, 20000, 23328, 25725, 31104, 39366, 46656, 54432, 65610, 93312, 100000):
+        g, = dump('split', n)
+        assert g['n1'] * g['n2'] == n and g['n1'] >= 16
+        for k in ('col', 'row'):
+            fill = g[k]['tj'] * g[k]['ct'] / g[k]['threads']
+            # (a 16-point column is one thread's work and a tile has at most 32 columns: half a wave)
+            assert fill >= 0.5, (n, k, g[k])
 
 
 def _hiprtc():
