@@ -112,6 +112,35 @@ def test_short_blocks_fill_their_waves(dump):
             assert fill >= 0.5, (n, k, g[k])
 
 
+def test_wide_column_tiles_of_short_blocks_are_sound(dump):
+    """The plans the split rule picks for short blocks, with their 16- / 32-column tiles and several
+    rows per workgroup: registers, threads and exchange area within what the kernels have, and the
+    model reproduces numpy.fft on both halves.  10 080 and 10 206 are Resample's blocks on
+    10 000-sample frames with pad 16 / 32 and 64 (tests/test_gpu_parity.py,
+    test_random_filter_bank_channelizer_and_resampler_geometries; sampling.py:211-220 of the reference)."""
+    m = model()
+    for n in (8232, 10080, 10206, 19200, 20000, 31104, 46656, 65610, 93312, 100000, 129024):
+        g, = dump('split', n)
+        assert g is not None and g['n1'] * g['n2'] == n
+        for k, pmax, lds_cap in (('col', 20, 64 * 1024), ('row', 20, 160 * 1024)):     # (BBT_G2_PMAX for both)
+            p = g[k]
+            fac, tj, nn = p['fac'], p['tj'], p['n']
+            assert int(np.prod(fac)) == nn and all(2 <= r <= min(16, pmax) for r in fac)
+            assert p['threads'] % 64 == 0 and tj * p['ct'] <= p['threads'] <= 1024
+            assert p['lds_elems'] * 8 <= lds_cap, (n, k, p)
+            ns, need = 1, 0
+            for s, r in enumerate(fac):
+                b = -(-(nn // r) // tj)
+                assert b <= 4 and b * r <= pmax and p['slots'] >= b * r, (n, k, p)
+                assert p['pitch'][s] >= ns * r
+                if s + 1 < len(fac):
+                    need = max(need, (nn // (ns * r)) * p['pitch'][s])
+                ns *= r
+            assert p['lds_elems'] >= need * p['ct'], (n, k, p)
+            if nn <= 3500:
+                m.run(nn, fac=fac, sign=-1, tj=tj, pitches=p['pitch'][:len(fac) - 1], verbose=False)
+
+
 def _hiprtc():
     for name in ('libhiprtc.so.7', 'libhiprtc.so', '/opt/rocm/lib/libhiprtc.so'):
         try:
