@@ -51,6 +51,23 @@ int main(int argc, char** argv) {
         const G2Plan gr = g2_reversed(g);
         printf("#include \"gen2_kernels.hpp\"\n%s%sBBT_G2_KERNEL_OSM_SMALL(k_small, GA, GB, 0)\nBBT_G2_KERNEL_FFT_ROWS(k_rows, GA, -1, 0)\n",
                g2_trait_source("GA", g).c_str(), g2_trait_source("GB", gr).c_str());
+    } else if (!strcmp(argv[1], "source2")) {
+        // the translation unit bbt_osm_plan_create writes for a two-level block (row kernel + both column passes)
+        int n1 = 0, n2 = 0;
+        const long long n = atoll(argv[2]);
+        if (!g2_choose_split(n, 8, 1024, 8192, &n1, &n2)) return 1;
+        G2Plan q1, q2;
+        const int ct = n <= (1 << 17) ? g2_col_ct(n1, g2_pmax(BBT_G2_KIND_COL)) : 8;
+        if (!g2_plan(n2, g2_row_ct(n2, g2_pmax(BBT_G2_KIND_ROW)), &q2, g2_pmax(BBT_G2_KIND_ROW)) ||
+            !g2_plan(n1, ct, &q1, g2_pmax(BBT_G2_KIND_COL)))
+            return 1;
+        const G2Plan q2r = g2_reversed(q2);
+        const char* w2 = q2.threads() >= 448 ? "4" : "0";
+        const char* w1 = q1.threads() >= 448 ? "4" : "0";
+        printf("#include \"gen2_kernels.hpp\"\n%s%s%sBBT_G2_KERNEL_ROW(k_row, GA, GB, %s)\n"
+               "BBT_G2_KERNEL_COL(k_first, GC, true, %s)\nBBT_G2_KERNEL_COL(k_last, GC, false, %s)\n",
+               g2_trait_source("GA", q2).c_str(), g2_trait_source("GB", q2r).c_str(), g2_trait_source("GC", q1).c_str(),
+               w2, w1, w1);
     }
     return 0;
 }

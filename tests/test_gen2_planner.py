@@ -150,13 +150,8 @@ def _hiprtc():
     return None
 
 
-def test_generated_source_compiles_through_hiprtc(dump):
-    """What csrc/rtc.hpp does at plan time, without a device: source for one length -> hipRTC with
-    the library's options -> a code object for gfx950 that holds both entry points."""
-    rtc = _hiprtc()
-    if rtc is None:
-        pytest.skip('libhiprtc.so not found')
-    src = subprocess.check_output([dump.exe, 'source', '6174'], text=True).encode()
+def _compile(rtc, src):
+    """csrc/rtc.hpp's call of hipRTC, with the library's options; returns the code object."""
     prog = C.c_void_p()
     assert rtc.hiprtcCreateProgram(C.byref(prog), src, b'bbt_g2.hip', 0, None, None) == 0
     opts = [b'--offload-arch=gfx950', b'-I' + CSRC.encode(), b'-O3', b'-std=c++17', b'-Wno-unused-value',
@@ -170,5 +165,41 @@ def test_generated_source_compiles_through_hiprtc(dump):
     assert rtc.hiprtcGetCodeSize(prog, C.byref(n)) == 0 and n.value > 10000
     code = C.create_string_buffer(n.value)
     assert rtc.hiprtcGetCode(prog, code) == 0
-    assert b'k_small' in code.raw and b'k_rows' in code.raw
     rtc.hiprtcDestroyProgram(C.byref(prog))
+    return code.raw
+
+
+def test_generated_source_compiles_through_hiprtc(dump):
+    """What csrc/rtc.hpp does at plan time, without a device: source for one length -> hipRTC with
+    the library's options -> a code object for gfx950 that holds both entry points."""
+    rtc = _hiprtc()
+    if rtc is None:
+        pytest.skip('libhiprtc.so not found')
+    code = _compile(rtc, subprocess.check_output([dump.exe, 'source', '6174'], text=True).encode())
+    assert b'k_small' in code and b'k_rows' in code
+
+
+@pytest.mark.parametrize('n', [10080, 10206, 31104])
+def test_two_level_source_of_short_blocks_compiles(dump, n):
+    """The translation unit of a short two-level block (row kernel with several rows per workgroup,
+    column passes with 16 / 32 columns per tile), as bbt_osm_plan_create writes it: compiles for
+    gfx950 with its three entry points.  10 080 / 10 206: Resample's blocks on 10000-sample frames."""
+    rtc = _hiprtc()
+    if rtc is None:
+        pytest.skip('libhiprtc.so not found')
+    src = subprocess.check_output([dump.exe, 'source2', str(n)], text=True)
+    assert 'BBT_G2_KERNEL_COL(k_first' in src
+    code = _compile(rtc, src.encode())
+    assert b'k_row' in code and b'k_first' in code and b'k_last' in code
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if os.path.exists(readelf):
+        # (what the kernels take: no scratch memory -- nothing spilled --, exchange areas as planned)
+        obj = os.path.join(os.path.dirname(dump.exe), f'g2_{n}.co')
+        with open(obj, 'wb') as f:
+            f.write(code)
+        notes = subprocess.check_output([readelf, '--notes', obj], text=True)
+        import re
+        found = re.findall(r'\.group_segment_fixed_size: (\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size: (\d+)', notes, re.S)
+        assert sorted(name for _, name, _ in found) == ['k_first', 'k_last', 'k_row']
+        for lds, name, scratch in found:
+            assert int(scratch) == 0 and int(lds) <= 64 * 1024, (n, name, lds, scratch)
